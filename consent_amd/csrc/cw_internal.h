@@ -1,0 +1,39 @@
+/* cw_internal.h -- engine object shared by the translation units of libconsent_amd.so. */
+#ifndef CW_INTERNAL_H
+#define CW_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/consent_amd.h"
+
+#define CW_MAX_STAGES 8
+
+struct cw_engine {
+    cw_params prm;
+    int device;
+    hipStream_t stream;
+    hipDeviceProp_t prop;
+    /* growable device scratch owned by the engine (never shrinks) */
+    void* scratch;
+    size_t scratch_bytes;
+    /* staging for cw_run (host buffers) */
+    void* dev_in;
+    size_t dev_in_bytes;
+    void* dev_out;
+    size_t dev_out_bytes;
+    /* per-stage timing of the last run */
+    hipEvent_t ev[CW_MAX_STAGES + 1];
+    int n_stages;
+    const char* stage_name[CW_MAX_STAGES];
+    float stage_ms[CW_MAX_STAGES];
+    bool timings_valid;
+};
+
+#define CW_HIP(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return CW_E_NO_DEVICE;   \
+    } while (0)
+
+#endif

@@ -1,0 +1,140 @@
+/*
+ * consent_amd.h -- C ABI of the MI355X window-correction engine (libconsent_amd.so).
+ *
+ * Drop-in boundary for CONSENT's per-window consensus operator.  Each entry point states the
+ * reference interface it stands in for (paths are under the CONSENT source tree, src/):
+ *
+ *   cw_run / cw_run_device   <- computeConsensusReadCorrection      (correctionMSA.h:8,  correctionMSA.cpp:29-49)
+ *                               computeConsensusAssemblyPolishing   (correctionMSA.h:10, correctionMSA.cpp:51-71)
+ *                               i.e. MSABMAAC (call sites correctionMSA.cpp:32,54) + weightConsensus
+ *                               (correctionMSA.cpp:6-27) + polishCorrection (correctionDBG.h:11)
+ *                               -- batched over windows, because one window per call cannot feed a GPU.
+ *   cw_pack_window           <- the vector<string> pile handed to those operators
+ *                               (CONSENT-correction.cpp:35-37, CONSENT-polishing.cpp:46-49): 2-bit packing
+ *                               with the reference's own alphabet (utils.cpp:21-32: A=00 C=01 G=10 else=11).
+ *   cw_extract_piles_device  <- getAlignmentWindowsSequences (alignmentWindows.h, alignmentWindows.cpp:87-149),
+ *                               device-side pile extraction from 2-bit reads + Overlap tuples.
+ *   cw_window_positions      <- getAlignmentWindowsPositions (alignmentWindows.cpp:27-85) (host).
+ *
+ * Plain pointers and sizes only; the caller owns every buffer; nothing is retained past return.
+ * No C++ exception crosses this boundary.  All functions return 0 on success or a negative cw_status.
+ */
+#ifndef CONSENT_AMD_H
+#define CONSENT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cw_status {
+    CW_OK = 0,
+    CW_E_INVALID = -1,   /* bad argument / malformed batch                      */
+    CW_E_NO_DEVICE = -2, /* no HIP device, or the HIP runtime reported an error  */
+    CW_E_NOMEM = -3,     /* device or host allocation failed                     */
+    CW_E_CAPACITY = -4,  /* at least one window overflowed an output or scratch capacity: its win_status says which */
+    CW_E_INTERNAL = -5
+} cw_status;
+
+/* Per-window outcome (cw_result.win_status). */
+enum {
+    CW_WIN_CONSENSUS = 0, /* consensus computed (correctionMSA.cpp:38-48)                        */
+    CW_WIN_TEMPLATE = 1,  /* MSA empty -> raw template returned (correctionMSA.cpp:34-36)        */
+    CW_WIN_OVERFLOW = 2   /* a capacity was exceeded; no output for this window                  */
+};
+
+/* The five parameters of the operator that its body actually uses (correctionMSA.cpp:29-49). */
+typedef struct cw_params {
+    uint32_t k;            /* merSize     -k (main.cpp:20) */
+    uint32_t solid;        /* solidThresh -f (main.cpp:23) */
+    uint32_t common_kmers; /* commonKMers -c (main.cpp:21) */
+    uint32_t min_anchors;  /* minAnchors  -A (main.cpp:22) */
+    uint32_t max_msa;      /* maxMSA      -M (main.cpp:25) */
+} cw_params;
+
+/*
+ * A batch of window piles.  Sequence s of window w has global index win_first_seq[w] + s; index
+ * win_first_seq[w] itself is the template (pile[0], alignmentWindows.cpp:100).
+ * Bases are 2-bit codes, 16 per 32-bit word, base j of a sequence in word seq_word_off[s] + j/16 at
+ * bits [2*(j%16), 2*(j%16)+1].  Every sequence starts on a word boundary.
+ */
+typedef struct cw_batch {
+    uint32_t n_windows;
+    uint32_t n_seqs;
+    uint64_t n_words;
+    const uint32_t* win_first_seq; /* [n_windows + 1] */
+    const uint32_t* seq_len;       /* [n_seqs] bases  */
+    const uint64_t* seq_word_off;  /* [n_seqs]        */
+    const uint32_t* bases;         /* [n_words]       */
+} cw_batch;
+
+/*
+ * Outputs.  Window w may write cons[cons_off[w] .. cons_off[w+1]) and solid[solid_off[w] .. solid_off[w+1]).
+ * cons holds ASCII ACGT/acgt (lower case = weakly supported, correctionMSA.cpp:18-22).
+ * solid holds the window's k-mers (2-bit codes, MSB-first, str2num order) whose pile-wide count is
+ * >= params.solid, ascending: everything the caller's downstream code asks of merCounts
+ * (correctionAlignment.cpp:6-15).  solid/solid_off/solid_len may all be NULL to skip that output.
+ */
+typedef struct cw_result {
+    char* cons;
+    const uint64_t* cons_off; /* [n_windows + 1] */
+    uint32_t* cons_len;       /* [n_windows]     */
+    uint8_t* win_status;      /* [n_windows]     */
+    uint32_t* solid;
+    const uint64_t* solid_off; /* [n_windows + 1] */
+    uint32_t* solid_len;       /* [n_windows]     */
+} cw_result;
+
+typedef struct cw_engine cw_engine;
+
+/* Library / build identification: returns a static string such as "consent_amd 0.1 gfx950". */
+const char* cw_version(void);
+const char* cw_strerror(int status);
+
+/* Engine bound to one HIP device (one process per GPU). */
+int cw_create(const cw_params* params, int device, cw_engine** out);
+void cw_destroy(cw_engine* e);
+
+/* Host buffers in, host buffers out (H2D, kernels, D2H, synchronous). */
+int cw_run(cw_engine* e, const cw_batch* batch, const cw_result* result);
+
+/* Every pointer inside batch/result is a DEVICE pointer; asynchronous on `hip_stream` (a hipStream_t,
+ * NULL = the engine's own stream); statuses are checked by the caller after synchronising.  */
+int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* result, void* hip_stream);
+
+/* Milliseconds spent in each device stage of the last cw_run / cw_run_device on this engine, measured
+ * with HIP events on the launch stream.  n_stages entries are written (at most cap); names are static. */
+int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages);
+
+/* Pack one ASCII window pile (n strings, lens[i] bytes each, not NUL-terminated) at the tail of host
+ * arrays laid out as cw_batch.  words_cap counts 32-bit words available at bases_out.  Returns the
+ * number of words written, or a negative cw_status.  Non-ACGT bytes pack as T (utils.cpp:28). */
+int64_t cw_pack_sequence(const char* seq, uint32_t len, uint32_t* bases_out, uint64_t words_cap);
+
+/* ---- synthetic PacBio/ONT-profile piles (bench + tests; SURVEY 8d generator) --------------------- */
+typedef struct cw_synth_spec {
+    uint64_t seed;        /* window w draws from seed + first_window + w            */
+    uint64_t first_window;
+    uint32_t n_windows;
+    uint32_t depth;       /* support sequences per window (pile size = depth + 1)     */
+    uint32_t window_len;  /* template length, 500                                     */
+    uint32_t err_permille;/* total error rate, 120 = 12 %                             */
+    uint32_t sub_w, ins_w, del_w; /* error mix, PacBio 10:60:30, ONT 30:30:40          */
+    uint32_t seq_stride_words;    /* words reserved per sequence (>= (window_len+60)/16+1) */
+} cw_synth_spec;
+
+/* Sizes of the arrays a synthetic batch needs. */
+int cw_synth_sizes(const cw_synth_spec* spec, uint32_t* n_seqs, uint64_t* n_words);
+/* Fill host arrays (win_first_seq[n_windows+1], seq_len[n_seqs], seq_word_off[n_seqs], bases[n_words]). */
+int cw_synth_host(const cw_synth_spec* spec, uint32_t* win_first_seq, uint32_t* seq_len, uint64_t* seq_word_off,
+                  uint32_t* bases);
+/* Same arrays as DEVICE pointers, generated by a HIP kernel on `hip_stream`. */
+int cw_synth_device(cw_engine* e, const cw_synth_spec* spec, uint32_t* win_first_seq, uint32_t* seq_len,
+                    uint64_t* seq_word_off, uint32_t* bases, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONSENT_AMD_H */

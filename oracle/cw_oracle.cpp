@@ -1,0 +1,783 @@
+/*
+ * cw_oracle.cpp -- CPU restatement of CONSENT's per-window consensus path (see cw_oracle.hpp for
+ * the parity status of every row).  TEST INFRASTRUCTURE: never linked into the product.
+ *
+ * Written for clarity, not speed: strings and node-based containers, one window at a time.
+ */
+#include "cw_oracle.hpp"
+#include "cw_policy.h"
+
+#include <algorithm>
+#include <cassert>
+#include <climits>
+#include <set>
+
+namespace cwo {
+
+/* ------------------------------------------------------------------------------------------------
+ * A11 -- alphabet helpers
+ * ---------------------------------------------------------------------------------------------- */
+static inline unsigned base_code(char c) {
+    switch (c) { /* utils.cpp:24-28: everything that is not A/C/G becomes T */
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    default: return 3;
+    }
+}
+
+kmer_t str2num(const std::string& s) {
+    kmer_t v = 0;
+    for (char c : s) v = (v << 2) | base_code(c);
+    return v;
+}
+
+std::string kmer2str(kmer_t v, unsigned k) {
+    std::string s(k, 'A');
+    for (unsigned i = 0; i < k; ++i) {
+        s[k - 1 - i] = "ACGT"[v & 3];
+        v >>= 2;
+    }
+    return s;
+}
+
+std::string revcomp(const std::string& s) {
+    /* reverseComplement.cpp:33-40 fills ACGT/acgt only; the static table is zero elsewhere. */
+    std::string r(s.size(), '\0');
+    for (size_t i = 0; i < s.size(); ++i) {
+        char c = s[s.size() - 1 - i], o = '\0';
+        switch (c) {
+        case 'A': o = 'T'; break; case 'T': o = 'A'; break; case 'C': o = 'G'; break; case 'G': o = 'C'; break;
+        case 'a': o = 't'; break; case 't': o = 'a'; break; case 'c': o = 'g'; break; case 'g': o = 'c'; break;
+        default: break;
+        }
+        r[i] = o;
+    }
+    return r;
+}
+
+static inline bool is_upper(char c) { return 'A' <= c && c <= 'Z'; } /* utils.cpp:56-58 */
+static inline uint32_t count_of(const KmerCounts& m, kmer_t key) {
+    auto it = m.find(key);
+    return it == m.end() ? 0u : it->second;
+}
+static std::string upper_copy(std::string s) {
+    for (char& c : s)
+        if ('a' <= c && c <= 'z') c = (char)(c - 'a' + 'A');
+    return s;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A4d -- partial-order alignment of one segment pile (POA, Lee 2002; alignment engine and graph update as
+ *        in spoa's scalar engine; rank order and consensus rule per cw_policy.h)
+ * ---------------------------------------------------------------------------------------------- */
+namespace {
+
+struct PoaEdge { int from, to; };
+struct PoaNode {
+    char base;
+    int coverage;                         /* sequences whose path runs through this node */
+    std::vector<int> in_edges, out_edges; /* indices into edges, insertion order */
+    std::vector<int> aligned;             /* other nodes of the same MSA column   */
+};
+
+struct PoaGraph {
+    std::vector<PoaNode> nodes;
+    std::vector<PoaEdge> edges;
+    std::vector<int> rank2node, node2rank;
+    int n_sequences = 0;
+    int template_nodes = 0; /* nodes 0 .. template_nodes-1 are the first sequence's chain */
+
+    int add_node(char b) {
+        nodes.push_back(PoaNode{b, 1, {}, {}, {}});
+        return (int)nodes.size() - 1;
+    }
+    void add_edge(int from, int to) {
+        for (int e : nodes[from].out_edges)
+            if (edges[e].to == to) return;
+        edges.push_back(PoaEdge{from, to});
+        nodes[from].out_edges.push_back((int)edges.size() - 1);
+        nodes[to].in_edges.push_back((int)edges.size() - 1);
+    }
+    /* Rank order policy (cw_policy.h "rank order"): the order is maintained incrementally, never re-sorted.
+       Columns (a node + its aligned nodes) always occupy consecutive ranks.
+       place_after_column(v, p): v joins p's column -> goes right after the last member of that column.
+       place_before_column(v, q): v is an insertion whose next ranked path node is q -> goes right before the
+       first member of q's column; q == -1 -> appended at the end. */
+    int column_first(int v) const {
+        int r = node2rank[v];
+        for (int a : nodes[v].aligned) r = std::min(r, node2rank[a]);
+        return r;
+    }
+    int column_last(int v) const {
+        int r = node2rank[v];
+        for (int a : nodes[v].aligned) r = std::max(r, node2rank[a]);
+        return r;
+    }
+    void insert_rank(int v, int at) {
+        rank2node.insert(rank2node.begin() + at, v);
+        node2rank.resize(nodes.size(), -1);
+        for (int r = at; r < (int)rank2node.size(); ++r) node2rank[rank2node[r]] = r;
+    }
+    void place_before_column(int v, int q) { insert_rank(v, q == -1 ? (int)rank2node.size() : column_first(q)); }
+    void place_after_column(int v, int p) {
+        /* called after v was linked into p's column: exclude v itself when looking for the block end */
+        int r = node2rank[p];
+        for (int a : nodes[p].aligned) if (a != v) r = std::max(r, node2rank[a]);
+        insert_rank(v, r + 1);
+    }
+    bool order_is_valid() const {
+        for (const PoaEdge& e : edges) if (node2rank[e.from] >= node2rank[e.to]) return false;
+        for (int v = 0; v < (int)nodes.size(); ++v)
+            if (column_last(v) - column_first(v) != (int)nodes[v].aligned.size()) return false;
+        return true;
+    }
+
+    /* Global alignment, linear gaps.  Returns (node or -1, seq index or -1) pairs in order. */
+    std::vector<std::pair<int, int>> align(const std::string& seq, Stats* st) const {
+        std::vector<std::pair<int, int>> path;
+        const int n = (int)nodes.size(), L = (int)seq.size();
+        if (n == 0 || L == 0) return path;
+        const int cols = L + 1;
+        const int g = CW_POA_GAP;
+        std::vector<int32_t> H((size_t)(n + 1) * cols);
+        auto at = [&](int i, int j) -> int32_t& { return H[(size_t)i * cols + j]; };
+        auto pred_row = [&](const PoaNode& nd, size_t p) { return node2rank[edges[nd.in_edges[p]].from] + 1; };
+
+        for (int j = 0; j < cols; ++j) at(0, j) = j * g;
+        for (int i = 1; i <= n; ++i) {
+            const PoaNode& nd = nodes[rank2node[i - 1]];
+            int32_t best = nd.in_edges.empty() ? 0 : INT_MIN;
+            for (size_t p = 0; p < nd.in_edges.size(); ++p) best = std::max(best, at(pred_row(nd, p), 0));
+            at(i, 0) = best + g;
+        }
+        for (int i = 1; i <= n; ++i) {
+            const PoaNode& nd = nodes[rank2node[i - 1]];
+            const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+            for (size_t p = 0; p < np; ++p) {
+                const int pi = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                for (int j = 1; j < cols; ++j) {
+                    int32_t s = (seq[j - 1] == nd.base) ? CW_POA_MATCH : CW_POA_MISMATCH;
+                    int32_t v = std::max(at(pi, j - 1) + s, at(pi, j) + g);
+                    at(i, j) = (p == 0) ? v : std::max(at(i, j), v);
+                }
+            }
+            for (int j = 1; j < cols; ++j) at(i, j) = std::max(at(i, j - 1) + g, at(i, j));
+        }
+        if (st) { st->dp_cells += (uint64_t)n * L; st->alignments++; }
+
+        int bi = -1;
+        int32_t bs = INT_MIN;
+        for (int i = 1; i <= n; ++i) {
+            if (!nodes[rank2node[i - 1]].out_edges.empty()) continue;
+            if (bi == -1 || bs < at(i, L)) { bs = at(i, L); bi = i; }
+        }
+        int i = bi, j = L;
+        while (!(i == 0 && j == 0)) {
+            const int32_t h = at(i, j);
+            int pi = i, pj = j;
+            bool found = false;
+            if (i != 0 && j != 0) {
+                const PoaNode& nd = nodes[rank2node[i - 1]];
+                int32_t s = (seq[j - 1] == nd.base) ? CW_POA_MATCH : CW_POA_MISMATCH;
+                const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+                for (size_t p = 0; p < np && !found; ++p) {
+                    int r = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                    if (h == at(r, j - 1) + s) { pi = r; pj = j - 1; found = true; }
+                }
+            }
+            if (!found && i != 0) {
+                const PoaNode& nd = nodes[rank2node[i - 1]];
+                const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+                for (size_t p = 0; p < np && !found; ++p) {
+                    int r = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                    if (h == at(r, j) + g) { pi = r; pj = j; found = true; }
+                }
+            }
+            if (!found && j != 0) {
+                if (h == at(i, j - 1) + g) { pi = i; pj = j - 1; found = true; }
+            }
+            assert(found);
+            path.emplace_back(i == pi ? -1 : rank2node[i - 1], j == pj ? -1 : j - 1);
+            i = pi; j = pj;
+        }
+        std::reverse(path.begin(), path.end());
+        return path;
+    }
+
+    void add_sequence(const std::string& seq, Stats* st) {
+        if (seq.empty()) return;
+        n_sequences++;
+        if (nodes.empty()) {
+            for (size_t t = 0; t < seq.size(); ++t) {
+                int v = add_node(seq[t]);
+                if (t) add_edge(v - 1, v);
+                place_before_column(v, -1);
+            }
+            template_nodes = (int)nodes.size();
+            return;
+        }
+        std::vector<std::pair<int, int>> aln = align(seq, st);
+        /* global mode: every sequence base is on the path, so there is no unaligned head or tail */
+        int head = -1;
+        for (size_t t = 0; t < aln.size(); ++t) {
+            const std::pair<int, int>& pr = aln[t];
+            if (pr.second == -1) continue;                 /* graph node against a gap */
+            const char b = seq[pr.second];
+            int cur;
+            if (pr.first == -1) {                          /* insertion: fresh node before the next ranked path node */
+                int q = -1;
+                for (size_t u = t + 1; u < aln.size(); ++u)
+                    if (aln[u].second != -1 && aln[u].first != -1) { q = aln[u].first; break; }
+                cur = add_node(b);
+                place_before_column(cur, q);
+            } else if (nodes[pr.first].base == b) {
+                cur = pr.first;
+                nodes[cur].coverage++;
+            } else {
+                cur = -1;
+                for (int a : nodes[pr.first].aligned)
+                    if (nodes[a].base == b) { cur = a; nodes[a].coverage++; break; }
+                if (cur == -1) {                           /* new member of pr.first's column */
+                    cur = add_node(b);
+                    std::vector<int> column = nodes[pr.first].aligned;
+                    for (int a : column) {
+                        nodes[cur].aligned.push_back(a);
+                        nodes[a].aligned.push_back(cur);
+                    }
+                    nodes[cur].aligned.push_back(pr.first);
+                    nodes[pr.first].aligned.push_back(cur);
+                    place_after_column(cur, pr.first);
+                }
+            }
+            if (head != -1) add_edge(head, cur);
+            head = cur;
+        }
+        assert(order_is_valid());
+    }
+
+    /* Column-majority consensus over the MSA the graph encodes (one column per aligned group, in
+       topological order).  A column whose gap count strictly exceeds every base count is dropped;
+       otherwise the most frequent base is emitted; ties between bases go to the template's base when
+       it is among the tied, else to the smallest code (A<C<G<T).  See cw_policy.h. */
+    std::string consensus() const {
+        std::string out;
+        const int n = (int)nodes.size();
+        for (int r = 0; r < n;) {
+            const int lead = rank2node[r];
+            const int width = 1 + (int)nodes[lead].aligned.size();
+            int cnt[4] = {0, 0, 0, 0};
+            int tpl_code = -1;
+            for (int c = 0; c < width; ++c) {
+                const int v = rank2node[r + c];
+                const int code = (int)base_code(nodes[v].base);
+                cnt[code] += nodes[v].coverage;
+                if (v < template_nodes) tpl_code = code;
+            }
+            const int gaps = n_sequences - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+            int top = 0;
+            for (int c = 1; c < 4; ++c) if (cnt[c] > cnt[top]) top = c;
+            if (!(gaps > cnt[top])) {
+                if (tpl_code != -1 && cnt[tpl_code] == cnt[top]) top = tpl_code;
+                out.push_back("ACGT"[top]);
+            }
+            r += width;
+        }
+        return out;
+    }
+};
+
+} // namespace
+
+std::string poa_consensus(const std::vector<std::string>& seqs, Stats* st) {
+    PoaGraph g;
+    for (const std::string& s : seqs) g.add_sequence(s, st);
+    if (st) st->max_nodes = std::max<uint64_t>(st->max_nodes, g.nodes.size());
+    return g.consensus();
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A4 -- k-mer index, anchor chain, segmentation, per-segment POA (published algorithm; see cw_policy.h)
+ * ---------------------------------------------------------------------------------------------- */
+bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anchor_support, unsigned min_anchors,
+                   unsigned max_msa, std::string& consensus, KmerCounts& counts, Stats* st) {
+    struct Occ { uint32_t seq; int32_t pos; };
+    std::unordered_map<kmer_t, std::vector<Occ>> index;
+    std::set<kmer_t> repeated;
+    const kmer_t mask = (k >= 32) ? ~(kmer_t)0 : (((kmer_t)1 << (2 * k)) - 1);
+
+    /* A4a: pile-wide counts + occurrence lists; a k-mer seen twice in one sequence is repeated. */
+    for (uint32_t s = 0; s < pile.size(); ++s) {
+        const std::string& r = pile[s];
+        if (r.size() < k) continue;
+        std::unordered_map<kmer_t, uint32_t> local;
+        kmer_t v = 0;
+        for (size_t i = 0; i < r.size(); ++i) {
+            v = ((v << 2) | base_code(r[i])) & mask;
+            if (i + 1 < k) continue;
+            int32_t pos = (int32_t)(i + 1 - k);
+            index[v].push_back(Occ{s, pos});
+            counts[v]++;
+            if (++local[v] > 1) repeated.insert(v);
+            if (st) st->kmers++;
+        }
+    }
+    for (kmer_t v : repeated) index.erase(v);
+    for (auto it = index.begin(); it != index.end();) {
+        if ((double)it->second.size() < anchor_support) it = index.erase(it);
+        else ++it;
+    }
+
+    /* Template anchors in template order. */
+    std::vector<kmer_t> tpl;
+    if (!pile.empty() && pile[0].size() >= k) {
+        kmer_t v = 0;
+        for (size_t i = 0; i < pile[0].size(); ++i) {
+            v = ((v << 2) | base_code(pile[0][i])) & mask;
+            if (i + 1 >= k && index.count(v)) tpl.push_back(v);
+        }
+    }
+    if (st) st->tpl_anchors += tpl.size();
+
+    /* A4b: longest ordered chain. */
+    auto pair_score = [&](kmer_t a, kmer_t b) -> int {
+        const std::vector<Occ>& va = index[a];
+        const std::vector<Occ>& vb = index[b];
+        size_t i = 0, j = 0;
+        int n = 0;
+        while (i < va.size() && j < vb.size()) {
+            if (va[i].seq == vb[j].seq) { if (va[i].pos < vb[j].pos) ++n; ++i; ++j; }
+            else if (va[i].seq < vb[j].seq) ++i;
+            else ++j;
+        }
+        if (st) st->pair_tests++;
+        return n;
+    };
+    const int A = (int)tpl.size();
+    std::vector<int> len(A, 0), nxt(A, -1);
+    std::vector<long> sc(A, 0);
+    for (int a = A - 1; a >= 0; --a) {
+        int best_len = -1, best_next = -1;
+        long best_sc = 0;
+        for (int b = a + 1; b < A; ++b) {
+            int s = pair_score(tpl[a], tpl[b]);
+            if ((double)s >= anchor_support) {
+                if (len[b] > best_len) { best_len = len[b]; best_sc = sc[b] + s; best_next = b; }
+                else if (len[b] == best_len && sc[b] + s > best_sc) { best_sc = sc[b] + s; best_next = b; }
+            }
+        }
+        len[a] = best_len + 1; sc[a] = best_sc; nxt[a] = best_next;
+    }
+    int start = -1, top_len = 0;
+    long top_sc = 0;
+    for (int a = A - 1; a >= 0; --a) {
+        if (len[a] > top_len) { top_len = len[a]; top_sc = sc[a]; start = a; }
+        else if (len[a] == top_len && sc[a] > top_sc) { top_sc = sc[a]; start = a; }
+    }
+    std::vector<kmer_t> chain;
+    for (int a = start; a != -1; a = nxt[a]) chain.push_back(tpl[a]);
+    if (st) st->chain_len += chain.size();
+    if (chain.size() < min_anchors || chain.empty()) return false;
+
+    /* A4c + A4d */
+    auto pos_in = [&](kmer_t a, uint32_t s) -> int32_t {
+        for (const Occ& o : index[a]) if (o.seq == s) return o.pos;
+        return -1;
+    };
+    const size_t m = chain.size();
+    consensus.clear();
+    for (size_t seg = 0; seg <= m; ++seg) {
+        std::vector<std::string> members;
+        for (uint32_t s = 0; s < pile.size() && members.size() < max_msa; ++s) {
+            const std::string& r = pile[s];
+            std::string piece;
+            if (seg == 0) {
+                int32_t p = pos_in(chain[0], s);
+                if (p == -1) continue;
+                piece = r.substr(0, (size_t)p);
+            } else if (seg == m) {
+                int32_t p = pos_in(chain[m - 1], s);
+                if (p == -1) continue;
+                piece = r.substr((size_t)p);
+            } else {
+                int32_t p1 = pos_in(chain[seg - 1], s), p2 = pos_in(chain[seg], s);
+                if (p1 == -1 || p2 == -1 || p1 >= p2) continue;
+                piece = r.substr((size_t)p1, (size_t)(p2 - p1));
+            }
+            if (!piece.empty()) members.push_back(piece);
+        }
+        if (st) {
+            st->segments++;
+            if (!members.empty()) st->poa_segments++;
+            for (auto& x : members) st->max_seg_len = std::max<uint64_t>(st->max_seg_len, x.size());
+        }
+        consensus += poa_consensus(members, st);
+    }
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A5 -- weightConsensus (correctionMSA.cpp:6-27)
+ * ---------------------------------------------------------------------------------------------- */
+std::string weight_consensus(std::string cons, const KmerCounts& counts, unsigned k, unsigned solid) {
+    /* :14 the loop bound is length-k+1 in unsigned arithmetic; callers guarantee length >= k (:43). */
+    for (unsigned i = 0; i + k <= cons.size(); ++i) {
+        std::string word = upper_copy(cons.substr(i, k));           /* :15-16 */
+        bool strong = count_of(counts, str2num(word)) >= solid;      /* :17 */
+        for (unsigned j = i; j < i + k; ++j) {                        /* :18 / :20, inclusive end i+k-1 */
+            char c = cons[j];
+            if (strong) { if ('a' <= c && c <= 'z') c = (char)(c - 32); }
+            else        { if ('A' <= c && c <= 'Z') c = (char)(c + 32); }
+            cons[j] = c;
+        }
+    }
+    return cons;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A8 -- getNeighbours (DBG.cpp:18-54)
+ * ---------------------------------------------------------------------------------------------- */
+std::vector<std::string> neighbours(std::string kmer, unsigned k, int left, const KmerCounts& counts, unsigned solid) {
+    std::vector<std::string> out;
+    kmer = upper_copy(kmer);                                   /* :22 */
+    if (left == 1) kmer = revcomp(kmer);                       /* :24-26 */
+    const std::string stem = kmer.substr(1);                   /* :27 */
+    for (int nuc = 0; nuc < 4; ++nuc) {                        /* :29 */
+        kmer_t key = (str2num(stem) << 2) + (kmer_t)nuc;       /* :30-32 */
+        std::string cand;
+        if (left == 1) {                                       /* :33-37 */
+            cand = revcomp(kmer2str(key, k));
+            key = str2num(cand);
+        } else {
+            cand = stem + "ACGT"[nuc];                         /* :42 via concatNucR :5-16 */
+        }
+        if (count_of(counts, key) >= solid) out.push_back(cand); /* :38-44 */
+    }
+    /* :48-52 std::sort on <=4 elements == insertion sort == stable; descending count. */
+    std::stable_sort(out.begin(), out.end(), [&](const std::string& a, const std::string& b) {
+        return count_of(counts, str2num(a)) > count_of(counts, str2num(b));
+    });
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A9 -- extendLeft / extendRight (DBG.cpp:56-75, :77-96)
+ * ---------------------------------------------------------------------------------------------- */
+unsigned extend_left(const KmerCounts& counts, unsigned k, unsigned ext_len, std::string& lr, unsigned solid) {
+    unsigned dist = 0;
+    std::vector<std::string> nb = neighbours(lr.substr(0, k), k, 1, counts, solid);   /* :62 */
+    while (nb.size() == 1 && dist < ext_len) {                                        /* :66 */
+        lr = nb[0].substr(0, nb[0].size() - (k - 1)) + lr;                            /* :67 */
+        dist += (unsigned)nb[0].size() - (k - 1);                                     /* :68 */
+        nb = neighbours(lr.substr(0, k), k, 1, counts, solid);                        /* :70 */
+    }
+    return dist;
+}
+
+unsigned extend_right(const KmerCounts& counts, unsigned k, unsigned ext_len, std::string& lr, unsigned solid) {
+    unsigned dist = 0;
+    std::vector<std::string> nb = neighbours(lr.substr(lr.size() - k), k, 0, counts, solid);  /* :83 */
+    while (!nb.empty() && dist < ext_len) {                                                   /* :87 */
+        lr = lr + nb[0].substr(k - 1);                                                        /* :88 */
+        dist += (unsigned)nb[0].size() - (k - 1);                                             /* :89 */
+        nb = neighbours(lr.substr(lr.size() - k), k, 0, counts, solid);                       /* :91 */
+    }
+    return dist;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A10 -- link (DBG.cpp:99-169).  cur_k == mer_size == min_order on every call the reference makes
+ * (correctionDBG.cpp:164, DBG.cpp:149), so they are folded into k.
+ * ---------------------------------------------------------------------------------------------- */
+static int link_path(const KmerCounts& counts, const std::string& dst_seed, unsigned k, std::set<std::string>& visited,
+                     unsigned* branches, unsigned dist, const std::string& cur_ext, std::string& found_path,
+                     unsigned max_len, unsigned max_branches, unsigned solid, Stats* st) {
+    if (st) st->link_calls++;
+    if (*branches > max_branches || dist > max_len) {          /* :100-103 */
+        found_path = std::string();
+        return 0;
+    }
+    std::string src_anchor = cur_ext.substr(cur_ext.size() - k);   /* :105 */
+    const std::string tgt = dst_seed.substr(0, k);                  /* :106 (and :123,:143: candidates have length k) */
+    bool found = (src_anchor == tgt);                               /* :109 */
+    std::string path = cur_ext;                                     /* :111 */
+
+    std::vector<std::string> nb = neighbours(src_anchor, k, 0, counts, solid);   /* :115 */
+    if (st) st->nbr_calls++;
+    size_t it = 0;
+
+    while (!found && nb.size() == 1 && it < nb.size() && dist <= max_len) {      /* :119 */
+        const std::string cand = nb[it];
+        bool seen = visited.count(cand) != 0;                                    /* :121 */
+        found = (cand == tgt);                                                   /* :123 */
+        if (!found && !seen) {                                                   /* :124 */
+            visited.insert(cand);
+            path += cand[k - 1];
+            dist += (unsigned)cand.size() - (k - 1);
+            src_anchor = path.substr(path.size() - k);                           /* :130 */
+            nb = neighbours(src_anchor, k, 0, counts, solid);                    /* :131 */
+            if (st) st->nbr_calls++;
+            it = 0;
+        } else if (found) {
+            path += cand[k - 1];                                                 /* :134 */
+        } else {
+            ++it;                                                                /* :136 */
+        }
+    }
+    while (!found && nb.size() > 1 && it < nb.size() && dist <= max_len) {       /* :141 */
+        const std::string cand = nb[it];
+        bool seen = visited.count(cand) != 0;
+        found = (cand == tgt);
+        if (!found && !seen) {                                                   /* :146 */
+            visited.insert(cand);
+            (*branches)++;
+            found = link_path(counts, dst_seed, k, visited, branches, dist + (unsigned)cand.size() - (k - 1),
+                              path + cand[k - 1], found_path, max_len, max_branches, solid, st) != 0;   /* :149 */
+            if (!found) ++it;
+            else return 1;                                                       /* :153 */
+        } else if (found) {
+            path += cand[k - 1];                                                 /* :156 */
+        } else {
+            ++it;
+        }
+    }
+    if (!found) return 0;                                                        /* :163 */
+    found_path = path + dst_seed.substr(k);                                      /* :166 (empty suffix) */
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A6a/A6b -- getNextSrc/getNextDst/getAnchors (correctionDBG.cpp:13-91)
+ * ---------------------------------------------------------------------------------------------- */
+int next_src(const std::string& s, unsigned beg, unsigned m) {
+    unsigned run = 0, i = beg;
+    while (i < s.size() && (is_upper(s[i]) || run < m)) {
+        if (is_upper(s[i])) run++; else run = 0;
+        i++;
+    }
+    return run >= m ? (int)i - 1 : -1;
+}
+
+int next_dst(const std::string& s, unsigned beg, unsigned m) {
+    unsigned run = 0, i = beg;
+    while (i < s.size() && run < m) {
+        if (is_upper(s[i])) run++; else run = 0;
+        i++;
+    }
+    return run >= m ? (int)i - 1 : -1;
+}
+
+namespace {
+struct AnchorPair { std::string src, dst; unsigned src_off, dst_off; };
+}
+
+static std::vector<AnchorPair> zone_anchors(const KmerCounts& counts, const std::string& src_zone, const std::string& dst_zone,
+                                            unsigned k, unsigned keep) {
+    auto unique_words = [&](const std::string& zone) {
+        std::vector<std::pair<std::string, unsigned>> out;      /* (word, its only offset), zone order */
+        const unsigned n = (unsigned)zone.size() - k + 1;
+        for (unsigned i = 0; i < n; ++i) {
+            std::string w = zone.substr(i, k);
+            unsigned occ = 0;
+            for (unsigned j = 0; j < n; ++j) if (zone.compare(j, k, w) == 0) occ++;
+            if (occ == 1) out.emplace_back(w, i);               /* :67,:69 */
+        }
+        return out;
+    };
+    auto srcs = unique_words(src_zone), dsts = unique_words(dst_zone);
+    std::vector<AnchorPair> all;
+    for (auto& s : srcs) for (auto& d : dsts) all.push_back(AnchorPair{s.first, d.first, s.second, d.second});  /* :66-74 */
+    /* :77-83 -- at most 16 pairs => libstdc++ std::sort is a plain insertion sort => stable. */
+    std::stable_sort(all.begin(), all.end(), [&](const AnchorPair& a, const AnchorPair& b) {
+        int oa = (int)(count_of(counts, str2num(a.src)) + count_of(counts, str2num(a.dst)));
+        int ob = (int)(count_of(counts, str2num(b.src)) + count_of(counts, str2num(b.dst)));
+        return oa > ob;
+    });
+    if (all.size() > keep) all.resize(keep);                     /* :85-88 */
+    return all;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A6 -- polishCorrection (correctionDBG.cpp:93-205)
+ * ---------------------------------------------------------------------------------------------- */
+std::string polish(std::string read, const KmerCounts& counts, unsigned k, unsigned solid, Stats* st) {
+    std::set<std::string> visited;                               /* :94 -- never cleared */
+    const unsigned zone = CW_DBG_ZONE, max_branches = CW_DBG_MAX_BRANCHES;
+    unsigned tmp_src_beg = 0, tmp_src_end = 0, tmp_dst_beg = 0, tmp_dst_end = 0;   /* :104, live across iterations */
+
+    unsigned i = 0;
+    while (i < read.size() && !is_upper(read[i])) i++;           /* :116-119 */
+    if (i > 0 && i < read.size() && read.size() - i >= k) {      /* :121 */
+        int ext_len = (int)i;
+        std::string old = read;
+        read = read.substr(i);
+        int ext = (int)extend_left(counts, k, (unsigned)ext_len, read, solid);     /* :125 */
+        if (ext < ext_len) {
+            read = old.substr(0, (size_t)(ext_len - ext)) + read;                   /* :127 */
+            i = i - (unsigned)(ext_len - ext);                                      /* :128 */
+        }
+    }
+
+    while (i < read.size()) {                                    /* :133 */
+        int src_end = next_src(read, i, k + zone);
+        int dst_end = next_dst(read, (unsigned)(src_end + 1), k + zone);
+        int src_beg = src_end - (int)k - (int)zone + 1;
+        int dst_beg = dst_end - (int)k - (int)zone + 1;
+        if (src_end != -1 && dst_end != -1) {                    /* :140 */
+            std::string region;
+            std::string src_zone = read.substr((size_t)src_beg, k + zone);
+            std::string dst_zone = read.substr((size_t)dst_beg, k + zone);
+            std::vector<AnchorPair> anchors = zone_anchors(counts, src_zone, dst_zone, k, CW_DBG_MAX_ANCHORS);
+            size_t a = 0;
+            while (a < anchors.size() && region.empty()) {       /* :150 */
+                const AnchorPair& ap = anchors[a];
+                tmp_src_beg = (unsigned)src_beg + ap.src_off;    /* :153-156 */
+                tmp_src_end = tmp_src_beg + k - 1;
+                tmp_dst_beg = (unsigned)dst_beg + ap.dst_off;
+                tmp_dst_end = tmp_dst_beg + k - 1;
+                if (ap.src != ap.dst) {                          /* :158 */
+                    unsigned branches = 0;
+                    region.clear();
+                    /* :163 -- double arithmetic, evaluated left to right, truncated to unsigned. */
+                    unsigned gap = tmp_dst_beg - tmp_src_end - 1;
+                    volatile double t0 = 15.0 / 100.0 * 2.0;
+                    volatile double t1 = t0 * (double)gap;
+                    volatile double t2 = t1 + (double)gap;
+                    volatile double t3 = t2 + (double)k;
+                    unsigned max_size = (unsigned)t3;
+                    link_path(counts, ap.dst, k, visited, &branches, 0, ap.src, region, max_size, max_branches, solid, st);
+                }
+                a++;
+            }
+            if (!region.empty()) {                               /* :169 */
+                std::string r = read.substr(tmp_src_beg, tmp_dst_end - tmp_src_beg + 1);
+                int b = (int)read.find(r);                       /* :173 first occurrence */
+                if (b != -1) {
+                    read.replace((size_t)b, r.size(), region);
+                    i = (unsigned)b;
+                } else {
+                    i = tmp_dst_beg > i ? tmp_dst_beg : (unsigned)dst_beg;
+                }
+            } else {
+                i = tmp_dst_beg > i ? tmp_dst_beg : (unsigned)dst_beg;   /* :182 */
+            }
+        } else {
+            i = (unsigned)read.size();                           /* :185 */
+        }
+    }
+
+    i = (unsigned)read.size() - 1;                               /* :189 */
+    while (i > 0 && !is_upper(read[i])) i--;
+    if (i > 0 && i < read.size() - 1 && i + 1 >= k) {            /* :194 */
+        int ext_len = (int)(read.size() - 1 - i);
+        std::string old = read;
+        read = read.substr(0, i + 1);
+        int ext = (int)extend_right(counts, k, (unsigned)ext_len, read, solid);
+        if (ext < ext_len) read += old.substr(old.size() - (size_t)(ext_len - ext), (size_t)(ext_len - ext));   /* :200 */
+    }
+    return read;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A3 -- computeConsensusReadCorrection / computeConsensusAssemblyPolishing (correctionMSA.cpp:29-71)
+ * ---------------------------------------------------------------------------------------------- */
+WindowResult window_consensus(const std::vector<std::string>& pile, const Params& p, Stats* st) {
+    WindowResult out;
+    int sup = std::min((int)p.common_kmers, (int)pile.size() / 2);                 /* :31 */
+    std::string cons;
+    bool ok = segmented_poa(pile, p.k, (double)sup, p.min_anchors, p.max_msa, cons, out.counts, st);   /* :32 */
+    if (!ok) {                                                                      /* :34-36 */
+        out.consensus = pile.empty() ? std::string() : pile[0];
+        out.status = 1;
+        return out;
+    }
+    if (cons.size() >= p.k) {                                                       /* :43-46 */
+        cons = weight_consensus(cons, out.counts, p.k, p.solid);
+        cons = polish(cons, out.counts, p.k, p.solid, st);
+    }
+    out.consensus = cons;
+    out.status = 0;
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A1 -- getCoverages + getAlignmentWindowsPositions (alignmentWindows.cpp:5-85)
+ * ---------------------------------------------------------------------------------------------- */
+std::vector<std::pair<uint32_t, uint32_t>> window_positions(uint32_t tpl_len, const std::vector<Ovl>& ovl,
+                                                            unsigned min_support, unsigned window_size, int window_overlap) {
+    std::vector<uint32_t> cov(tpl_len, 0);
+    for (const Ovl& o : ovl)
+        for (uint32_t i = o.q_start; i <= o.q_end && i < tpl_len; ++i) cov[i]++;   /* :15-22, ends inclusive */
+    std::vector<std::pair<uint32_t, uint32_t>> out;
+    uint32_t cur = 0, beg = 0, i = 0;
+    while (i < tpl_len) {                                       /* :39 */
+        if (cur >= window_size) {
+            out.emplace_back(beg, beg + cur - 1);
+            if (window_overlap) i = i - (uint32_t)window_overlap;
+            beg = i;
+            cur = 0;
+        }
+        if (cov[i] < min_support) { cur = 0; i++; beg = i; }
+        else { cur++; i++; }
+    }
+    bool pushed = false;                                        /* :59-79 trailing window */
+    uint32_t end = tpl_len - 1;
+    cur = 0;
+    i = tpl_len - 1;
+    while (i > 0 && !pushed) {
+        if (cur >= window_size) {
+            out.emplace_back(end - cur + 1, end);
+            pushed = true;
+            end = i;
+            cur = 0;
+        }
+        if (cov[i] < min_support) { cur = 0; i--; end = i; }
+        else { cur++; i--; }
+    }
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A2 -- getAlignmentWindowsSequences (alignmentWindows.cpp:87-149)
+ * ---------------------------------------------------------------------------------------------- */
+static std::string clamp_substr(const std::string& s, long pos, long n) {
+    /* std::string::substr semantics for pos <= size (the reference never passes pos > size on
+       well-formed PAF; it would throw).  n is taken modulo 2^64 like the size_t conversion. */
+    if (pos < 0 || (size_t)pos > s.size()) return std::string();
+    return s.substr((size_t)pos, (size_t)n);
+}
+
+std::vector<std::string> window_pile(const std::vector<Ovl>& ovl, const std::string& tpl,
+                                     const std::vector<std::string>& targets, uint32_t q_beg, uint32_t q_end, unsigned k) {
+    std::vector<std::string> pile;
+    uint32_t length = q_end - q_beg + 1;
+    if ((uint64_t)q_beg + length - 1 >= tpl.size()) return pile;   /* :95-97 */
+    pile.push_back(tpl.substr(q_beg, length));                      /* :100 */
+    for (const Ovl& al : ovl) {
+        uint32_t t_beg = al.t_start, t_end = al.t_end, shift;
+        length = q_end - q_beg + 1;
+        shift = (q_beg > al.q_start) ? q_beg - al.q_start : 0;      /* :110-114 */
+        bool spans = ((al.q_start <= q_beg && al.q_end > q_beg) || (q_end <= al.q_end && al.q_start < q_end));
+        if (!(spans && al.t_start + shift <= al.t_end)) continue;   /* :117 */
+        if (q_beg < al.q_start && al.q_end < q_end) {               /* :119-123 */
+            shift = 0;
+            t_beg = (uint32_t)std::max(0, (int)al.t_start - ((int)al.q_start - (int)q_beg));
+            t_end = (uint32_t)std::min((int)al.t_len - 1, (int)al.t_end + ((int)q_end - (int)al.q_end));
+            length = t_end - t_beg + 1;
+        } else if (q_beg < al.q_start) {                            /* :124-127 */
+            shift = 0;
+            t_beg = (uint32_t)std::max(0, (int)al.t_start - ((int)al.q_start - (int)q_beg));
+            length = (uint32_t)std::min((int)length, std::min((int)al.t_len - 1, (int)t_beg + (int)length - 1) - (int)t_beg + 1);
+        } else if (al.q_end < q_end) {                              /* :128-130 */
+            t_end = (uint32_t)std::min((int)al.t_len - 1, (int)al.t_end + ((int)q_end - (int)al.q_end));
+            length = (uint32_t)std::min((int)length, (int)t_end - std::max(0, (int)t_end - (int)length + 1) + 1);
+        }
+        std::string seq = clamp_substr(targets[al.t_id], (long)t_beg, (long)t_end - (long)t_beg + 1);   /* :133 */
+        if (al.strand) seq = revcomp(seq);                                                              /* :134-136 */
+        seq = clamp_substr(seq, (long)shift, (long)length);                                             /* :138 */
+        if (seq.size() >= k) pile.push_back(seq);                                                       /* :141 */
+    }
+    return pile;
+}
+
+} // namespace cwo

@@ -1,0 +1,78 @@
+/*
+ * cw_policy.h -- every free policy of the segmented-POA restatement, named in one place.
+ *
+ * TEST INFRASTRUCTURE / SHARED CONSTANTS.  This header carries no algorithm, only constants; it is the
+ * single file both the CPU oracle (oracle/) and the HIP engine (consent_amd/csrc/) include so that
+ * the two sides cannot drift apart on a tie-break.
+ *
+ * Why these are "policies": the reference calls `MSABMAAC(piles, merSize, bmeanSup, solidThresh,
+ * minAnchors, maxMSA, path)` (/root/reference/src/correctionMSA.cpp:32,54) which lives in the
+ * un-vendored submodule Malfoy/BMEAN (+ the spoa library bundled inside it, reference Makefile:3).
+ * Neither is present under /root/reference and the commit pins are unknown (.gitmodules has URLs
+ * only), so the arithmetic below restates the *published* algorithm (CONSENT README.md:93-100,
+ * Sci Rep 11:761; spoa = Lee 2002 POA + heaviest bundle, Vaser 2017) and every decision the
+ * publication leaves open is a constant here.  PARITY FOR THESE ROWS IS UNPINNED.
+ */
+#ifndef CW_POLICY_H
+#define CW_POLICY_H
+
+/* --- POA alignment engine (A4d) ------------------------------------------------------------- */
+/* Global (Needleman-Wunsch) alignment of each segment string against the partial-order graph:   */
+/* segments are cut at shared anchors, so both ends are pinned and a global mode is the natural  */
+/* choice.  Linear gap model.  Scores are spoa's command-line defaults (m=5, n=-4, g=-8).        */
+#define CW_POA_MATCH      5
+#define CW_POA_MISMATCH (-4)
+#define CW_POA_GAP      (-8)
+
+/* Traceback preference at a cell (spoa sisd engine order): diagonal through the in-edges in     */
+/* insertion order, then vertical (graph node against a gap) through the in-edges in insertion   */
+/* order, then horizontal (sequence base against a gap).                                         */
+/* End cell for the global mode: the sink node (no out-edge) of LOWEST topological rank among    */
+/* those with the best last-column score (strict '<' while scanning ranks upward).               */
+
+/* Rank order of the graph (rows of the DP, columns of the MSA): maintained incrementally, never     */
+/* re-sorted.  The first sequence's nodes take ranks 0..len-1.  A fresh node created for a sequence   */
+/* base is ranked (a) right after the last member of the column it joins, when it is a mismatch       */
+/* against an existing node, or (b) right before the first member of the column of the next path      */
+/* node that already has a rank (at the very end if there is none), when it is an insertion.          */
+/* The members of one column therefore always hold consecutive ranks.  Only two things depend on the  */
+/* order beyond being topological: the tie-break between equally good end nodes, and the order in    */
+/* which independent insertion columns appear in the consensus.                                       */
+
+/* Consensus of a segment = column-majority vote over the MSA encoded by the graph (BMEAN's        */
+/* "easy consensus"), NOT the heaviest bundle: with anchors that occasionally hit a spurious copy of  */
+/* a k-mer, one member of a segment can be hundreds of bases longer than the others, and a           */
+/* sum-of-weights path would follow that singleton detour.  Columns = aligned groups in topological  */
+/* order.  gaps = sequences - sum(base counts).  Column dropped iff gaps > every base count.         */
+/* Otherwise the most frequent base; ties -> the template's base if tied for the top, else the       */
+/* smallest code (A<C<G<T).                                                                          */
+
+/* --- anchor index (A4a) --------------------------------------------------------------------- */
+/* A k-mer occurring twice inside ANY single sequence of the pile is never an anchor.            */
+/* A k-mer must occur in at least `anchor_support` distinct sequences (compared as                */
+/* occurrences < support  =>  dropped; support 0 keeps everything).                              */
+
+/* --- chaining (A4b) ------------------------------------------------------------------------- */
+/* score(a,b) = number of sequences that contain both anchors with pos(a) < pos(b).              */
+/* Sequences holding them in the opposite order are simply not counted (no veto).                */
+/* Edge a->b (a before b on the template) is usable iff score(a,b) >= anchor_support.            */
+/* best(a) = longest chain starting at a; ties on length -> larger summed score; remaining ties  */
+/* -> the SMALLEST successor index (strict '>' while scanning successors upward).                */
+/* Chain start: scan template anchors from last to first, strict '>' on length, then strict '>'  */
+/* on score => on full ties the LARGEST start index wins.                                        */
+
+/* --- segmentation (A4c) --------------------------------------------------------------------- */
+/* Segment 0      : seq[0, pos(c0))               for sequences holding c0.                      */
+/* Segment i      : seq[pos(c_{i-1}), pos(c_i))   for sequences holding both, in that order;     */
+/*                  a sequence lacking either anchor (or holding them reversed) is left out of   */
+/*                  that segment only.                                                           */
+/* Segment m      : seq[pos(c_{m-1}), end)        for sequences holding c_{m-1}.                 */
+/* Empty strings are skipped.  Members keep pile order (template first); the first `max_msa`     */
+/* non-empty members are aligned, the rest ignored.                                              */
+
+/* --- DBG polish constants that ARE pinned by in-tree reference code -------------------------- */
+#define CW_DBG_ZONE          3   /* correctionDBG.cpp:102 */
+#define CW_DBG_MAX_BRANCHES 50   /* correctionDBG.cpp:100 */
+#define CW_DBG_MAX_ANCHORS   5   /* correctionDBG.cpp:144 */
+
+#endif /* CW_POLICY_H */
