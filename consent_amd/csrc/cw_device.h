@@ -1,0 +1,137 @@
+/*
+ * cw_device.h -- device-side data layout and small helpers shared by the kernels of the engine.
+ *
+ * Data layout in HBM for one batch (all arrays engine-owned scratch unless marked caller):
+ *   caller  bases[]            2-bit, 16 bases / u32, MSB first; every sequence word-aligned
+ *   caller  seq_len[], seq_word_off[], win_first_seq[]
+ *   scratch WinInfo win[W]     per-window bookkeeping (status, offsets into the arrays below)
+ *   scratch solid_key/cnt[]    per window: ascending solid k-mers + their exact pile-wide counts
+ *   scratch seg_off/seg_len[]  per window: one slot per segment of the anchor chain (in chain order)
+ *   scratch arena[]            per window: segment consensus characters ('A','C','G','T')
+ *   scratch tasks[], members[] POA work items emitted by the index kernel (bump-allocated, batch-wide)
+ */
+#ifndef CW_DEVICE_H
+#define CW_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/consent_amd.h"
+#include "../../include/cw_policy.h"
+
+#define CW_NONE16 0xFFFFu
+#define CW_NEG (-(1 << 28))
+
+struct WinInfo {
+    uint32_t status;     /* CW_WIN_* */
+    uint32_t n_seqs;     /* pile size N */
+    uint32_t tpl_len;    /* length of the template (sequence 0) */
+    uint32_t n_kmers;    /* k-mers in the whole pile */
+    uint32_t solid_base; /* first slot in solid_key/solid_cnt */
+    uint32_t solid_cap;
+    uint32_t n_solid;
+    uint32_t seg_base;   /* first slot in seg_off/seg_len */
+    uint32_t seg_cap;
+    uint32_t n_segs;     /* chain nodes + 1, 0 when there is no consensus */
+    uint32_t arena_base; /* first byte in arena */
+    uint32_t arena_cap;
+    uint32_t arena_used;
+    uint32_t pad[3];
+};
+
+struct PoaTask {
+    uint32_t window;
+    uint32_t seg_slot;   /* absolute index into seg_off/seg_len */
+    uint32_t member_off; /* absolute index into members[] */
+    uint32_t n_members;
+    uint32_t max_len;    /* longest member */
+    uint32_t out_off;    /* absolute byte offset in arena */
+    uint32_t out_cap;
+    uint32_t state;      /* 0 pending, 1 done, 2 needs the large-graph path, 3 failed (capacity) */
+};
+
+struct PoaMember {
+    uint32_t seq;   /* absolute sequence index */
+    uint16_t start; /* first base of the piece */
+    uint16_t len;
+};
+
+/* Batch-wide counters (one struct in scratch, zeroed before every run). */
+struct BatchCounters {
+    uint32_t n_tasks;
+    uint32_t n_members;
+    uint32_t next_task;    /* work-stealing cursor of the LDS POA kernel */
+    uint32_t n_big;        /* tasks deferred to the large-graph kernel */
+    uint32_t next_big;
+    uint32_t next_window;  /* work-stealing cursor of the index kernel */
+    uint32_t next_finish;  /* work-stealing cursor of the finish kernel */
+    uint32_t any_overflow;
+};
+
+struct DevBatch {
+    uint32_t n_windows;
+    const uint32_t* win_first_seq;
+    const uint32_t* seq_len;
+    const uint64_t* seq_word_off;
+    const uint32_t* bases;
+};
+
+struct DevScratch {
+    WinInfo* win;
+    uint32_t* solid_key;
+    uint32_t* solid_cnt;
+    uint32_t* seg_off;
+    uint32_t* seg_len;
+    uint8_t* arena;
+    PoaTask* tasks;
+    uint32_t task_cap;
+    PoaMember* members;
+    uint32_t member_cap;
+    uint32_t* big_list; /* indices of tasks for the large-graph kernel */
+    uint32_t big_cap;
+    BatchCounters* ctr;
+    uint8_t* big_scratch; /* per-wave slabs of the large-graph kernel */
+    uint64_t big_slab_bytes;
+    uint32_t big_slots;
+};
+
+/* ---- packed-sequence access ------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t cw_base_at(const uint32_t* w, uint32_t j) { return (w[j >> 4] >> (30 - 2 * (j & 15))) & 3u; }
+
+/* k-mer starting at base p (k <= 16), str2num order (first base most significant). */
+__device__ __forceinline__ uint32_t cw_kmer_at(const uint32_t* w, uint32_t p, uint32_t k) {
+    const uint32_t wi = p >> 4, sh = 2 * (p & 15);
+    uint64_t x = (uint64_t)w[wi] << 32;
+    if ((p & 15) + k > 16) x |= w[wi + 1];
+    x <<= sh;
+    return (uint32_t)(x >> (64 - 2 * k));
+}
+
+__device__ __forceinline__ int cw_lane() { return (int)(threadIdx.x & 63); }
+
+/* Compiler + hardware ordering point for LDS traffic between the lanes of ONE wave. */
+__device__ __forceinline__ void cw_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int cw_wave_max(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int cw_wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+/* inclusive prefix max over the 64 lanes */
+__device__ __forceinline__ int cw_wave_scan_max(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v = max(v, t);
+    }
+    return v;
+}
+__device__ __forceinline__ int cw_bcast(int v, int src) { return __shfl(v, src); }
+
+#endif

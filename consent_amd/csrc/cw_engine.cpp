@@ -1,0 +1,287 @@
+/*
+ * cw_engine.cpp -- host side of libconsent_amd.so: engine life cycle, scratch sizing, kernel launches,
+ * host-buffer staging, per-stage timing.  C ABI declared in include/consent_amd.h.
+ */
+#include "cw_internal.h"
+#include "cw_device.h"
+#include "cw_index.h"
+#include "cw_poa.h"
+#include "cw_finish.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t big_slab_bytes() {
+    size_t b = (size_t)CW_POAB_HC * 4;
+    b += (size_t)CW_POAB_NC * 21 + (size_t)CW_POAB_EC * 6 + 2 * (CW_POAB_NC + 1) + 4 * (CW_POAB_NC + CW_POAB_LC + 2) + (CW_POAB_LC + 1);
+    return align_up(b, 256);
+}
+
+struct ScratchPlan {
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, ctr, big, total;
+    uint64_t solid_cap, seg_cap, arena_cap;
+    uint32_t task_cap, member_cap, big_slots;
+};
+
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots) {
+    ScratchPlan p;
+    memset(&p, 0, sizeof(p));
+    p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
+    p.seg_cap = (uint64_t)n_windows * (CW_TMAX + 2);
+    p.arena_cap = (uint64_t)n_windows * (8ull * (CW_TMAX + 16) + 1024);
+    uint64_t tc = 64ull * n_windows + 1024, mc = 2048ull * n_windows + 4096;
+    p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
+    p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
+    p.big_slots = big_slots;
+    size_t o = 0;
+    auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
+    put(p.win, (size_t)n_windows * sizeof(WinInfo));
+    put(p.solid_key, p.solid_cap * 4);
+    put(p.solid_cnt, p.solid_cap * 4);
+    put(p.seg_off, p.seg_cap * 4);
+    put(p.seg_len, p.seg_cap * 4);
+    put(p.arena, p.arena_cap);
+    put(p.tasks, (size_t)p.task_cap * sizeof(PoaTask));
+    put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
+    put(p.big_list, (size_t)p.task_cap * 4);
+    put(p.ctr, sizeof(BatchCounters));
+    put(p.big, (size_t)big_slots * big_slab_bytes());
+    p.total = o;
+    return p;
+}
+
+int ensure(void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return CW_OK;
+    if (*ptr) { if (hipFree(*ptr) != hipSuccess) return CW_E_NO_DEVICE; *ptr = nullptr; *have = 0; }
+    if (hipMalloc(ptr, need) != hipSuccess) { *ptr = nullptr; return CW_E_NOMEM; }
+    *have = need;
+    return CW_OK;
+}
+
+int check_params(const cw_params* p) {
+    if (!p) return CW_E_INVALID;
+    if (p->k < 2 || p->k > 9) return CW_E_INVALID; /* direct-addressed count table: 4^k nibbles in LDS */
+    if (p->solid < 1 || p->max_msa < 1) return CW_E_INVALID;
+    return CW_OK;
+}
+
+void mark(cw_engine* e, hipStream_t st, const char* name) {
+    if (e->n_stages < CW_MAX_STAGES) {
+        e->stage_name[e->n_stages] = name;
+        e->n_stages++;
+        (void)hipEventRecord(e->ev[e->n_stages], st);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* cw_version(void) { return "consent_amd 0.1 (gfx950, HIP)"; }
+
+const char* cw_strerror(int s) {
+    switch (s) {
+    case CW_OK: return "ok";
+    case CW_E_INVALID: return "invalid argument or malformed batch";
+    case CW_E_NO_DEVICE: return "no HIP device or HIP runtime error";
+    case CW_E_NOMEM: return "out of memory";
+    case CW_E_CAPACITY: return "at least one window exceeded a capacity (see win_status)";
+    case CW_E_INTERNAL: return "internal error";
+    default: return "unknown status";
+    }
+}
+
+int cw_create(const cw_params* params, int device, cw_engine** out) {
+    if (!out) return CW_E_INVALID;
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CW_E_NO_DEVICE;
+    cw_engine* e = new (std::nothrow) cw_engine();
+    if (!e) return CW_E_NOMEM;
+    memset(e, 0, sizeof(*e));
+    e->prm = *params;
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&e->prop, device) != hipSuccess ||
+        hipStreamCreate(&e->stream) != hipSuccess) {
+        delete e;
+        return CW_E_NO_DEVICE;
+    }
+    for (int i = 0; i <= CW_MAX_STAGES; ++i)
+        if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
+    if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
+        delete e;
+        return CW_E_NO_DEVICE;
+    }
+    *out = e;
+    return CW_OK;
+}
+
+void cw_destroy(cw_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    if (e->scratch) (void)hipFree(e->scratch);
+    if (e->dev_in) (void)hipFree(e->dev_in);
+    if (e->dev_out) (void)hipFree(e->dev_out);
+    for (int i = 0; i <= CW_MAX_STAGES; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
+    if (!e || !batch || !res || !res->cons || !res->cons_off || !res->cons_len || !res->win_status) return CW_E_INVALID;
+    if ((res->solid != nullptr) != (res->solid_off != nullptr) || (res->solid != nullptr) != (res->solid_len != nullptr)) return CW_E_INVALID;
+    if (batch->n_windows == 0) return CW_OK;
+    if (!batch->win_first_seq || !batch->seq_len || !batch->seq_word_off || !batch->bases) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+
+    uint32_t big_slots = 256;
+    if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots);
+    int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)e->scratch;
+
+    DevBatch db;
+    db.n_windows = batch->n_windows;
+    db.win_first_seq = batch->win_first_seq; db.seq_len = batch->seq_len; db.seq_word_off = batch->seq_word_off; db.bases = batch->bases;
+    DevScratch sc;
+    sc.win = (WinInfo*)(base + p.win);
+    sc.solid_key = (uint32_t*)(base + p.solid_key); sc.solid_cnt = (uint32_t*)(base + p.solid_cnt);
+    sc.seg_off = (uint32_t*)(base + p.seg_off); sc.seg_len = (uint32_t*)(base + p.seg_len);
+    sc.arena = base + p.arena;
+    sc.tasks = (PoaTask*)(base + p.tasks); sc.task_cap = p.task_cap;
+    sc.members = (PoaMember*)(base + p.members); sc.member_cap = p.member_cap;
+    sc.big_list = (uint32_t*)(base + p.big_list); sc.big_cap = p.task_cap;
+    sc.ctr = (BatchCounters*)(base + p.ctr);
+    sc.big_scratch = base + p.big; sc.big_slab_bytes = big_slab_bytes(); sc.big_slots = p.big_slots;
+    FinOut fo;
+    fo.cons = res->cons; fo.cons_off = res->cons_off; fo.cons_len = res->cons_len; fo.win_status = res->win_status;
+    fo.solid = res->solid; fo.solid_off = res->solid_off; fo.solid_len = res->solid_len;
+
+    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    e->n_stages = 0;
+    e->timings_valid = false;
+    CW_HIP(hipEventRecord(e->ev[0], st));
+    CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
+    cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
+    mark(e, st, "setup");
+    {
+        const uint32_t grid = batch->n_windows < (uint32_t)cus ? batch->n_windows : (uint32_t)cus;
+        cw_index_kernel<<<grid, CW_IDX_THREADS, CW_IDX_LDS_BYTES, st>>>(db, sc, e->prm);
+    }
+    mark(e, st, "index");
+    cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
+    mark(e, st, "poa");
+    cw_poa_big_kernel<<<p.big_slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
+    mark(e, st, "poa_big");
+    {
+        uint32_t grid = (batch->n_windows + CW_FIN_WAVES - 1) / CW_FIN_WAVES;
+        if (grid > (uint32_t)cus * 2) grid = (uint32_t)cus * 2;
+        cw_finish_kernel<<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
+    }
+    mark(e, st, "finish");
+    CW_HIP(hipGetLastError());
+    e->timings_valid = true;
+    return CW_OK;
+}
+
+int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages) {
+    if (!e || !n_stages) return CW_E_INVALID;
+    *n_stages = 0;
+    if (!e->timings_valid) return CW_OK;
+    CW_HIP(hipSetDevice(e->device));
+    CW_HIP(hipEventSynchronize(e->ev[e->n_stages]));
+    for (int i = 0; i < e->n_stages && i < cap; ++i) {
+        float t = 0.f;
+        CW_HIP(hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]));
+        e->stage_ms[i] = t;
+        if (ms) ms[i] = t;
+        if (names) names[i] = e->stage_name[i];
+        *n_stages = i + 1;
+    }
+    return CW_OK;
+}
+
+/* Debug/inspection: copy the engine's per-window bookkeeping of the last run (16 u32 per window) to host. */
+int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
+    if (!e || !out16 || !e->scratch) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    CW_HIP(hipMemcpy(out16, e->scratch, (size_t)n_windows * sizeof(WinInfo), hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+
+int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
+    if (!e || !b || !r || !r->cons || !r->cons_off || !r->cons_len || !r->win_status) return CW_E_INVALID;
+    if (b->n_windows == 0) return CW_OK;
+    if (!b->win_first_seq || !b->seq_len || !b->seq_word_off || !b->bases) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    const uint32_t W = b->n_windows, S = b->n_seqs;
+    /* light validation of the host batch */
+    if (b->win_first_seq[0] != 0 || b->win_first_seq[W] != S) return CW_E_INVALID;
+    for (uint32_t w = 0; w < W; ++w) if (b->win_first_seq[w + 1] < b->win_first_seq[w]) return CW_E_INVALID;
+    for (uint32_t s = 0; s < S; ++s)
+        if (b->seq_word_off[s] + ((uint64_t)b->seq_len[s] + 15) / 16 > b->n_words || b->seq_len[s] > 65535u) return CW_E_INVALID;
+    const bool want_solid = r->solid != nullptr;
+    if (want_solid && (!r->solid_off || !r->solid_len)) return CW_E_INVALID;
+
+    size_t o = 0;
+    auto put = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t i_wfs = put((size_t)(W + 1) * 4), i_len = put((size_t)S * 4), i_off = put((size_t)S * 8), i_bases = put((size_t)(b->n_words + 1) * 4);
+    const size_t in_bytes = o;
+    o = 0;
+    const uint64_t cons_total = r->cons_off[W];
+    const uint64_t solid_total = want_solid ? r->solid_off[W] : 0;
+    const size_t o_cons = put(cons_total), o_coff = put((size_t)(W + 1) * 8), o_clen = put((size_t)W * 4), o_stat = put(W),
+                 o_solid = put(solid_total * 4), o_soff = put((size_t)(W + 1) * 8), o_slen = put((size_t)W * 4);
+    const size_t out_bytes = o;
+    int rc = ensure(&e->dev_in, &e->dev_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = ensure(&e->dev_out, &e->dev_out_bytes, out_bytes);
+    if (rc) return rc;
+    uint8_t* din = (uint8_t*)e->dev_in;
+    uint8_t* dout = (uint8_t*)e->dev_out;
+    hipStream_t st = e->stream;
+    CW_HIP(hipMemcpyAsync(din + i_wfs, b->win_first_seq, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+    CW_HIP(hipMemcpyAsync(din + i_len, b->seq_len, (size_t)S * 4, hipMemcpyHostToDevice, st));
+    CW_HIP(hipMemcpyAsync(din + i_off, b->seq_word_off, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    CW_HIP(hipMemcpyAsync(din + i_bases, b->bases, (size_t)b->n_words * 4, hipMemcpyHostToDevice, st));
+    CW_HIP(hipMemsetAsync(din + i_bases + (size_t)b->n_words * 4, 0, 4, st));
+    CW_HIP(hipMemcpyAsync(dout + o_coff, r->cons_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+    if (want_solid) CW_HIP(hipMemcpyAsync(dout + o_soff, r->solid_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+
+    cw_batch db = *b;
+    db.win_first_seq = (const uint32_t*)(din + i_wfs); db.seq_len = (const uint32_t*)(din + i_len);
+    db.seq_word_off = (const uint64_t*)(din + i_off); db.bases = (const uint32_t*)(din + i_bases);
+    cw_result dr;
+    dr.cons = (char*)(dout + o_cons); dr.cons_off = (const uint64_t*)(dout + o_coff); dr.cons_len = (uint32_t*)(dout + o_clen);
+    dr.win_status = dout + o_stat;
+    dr.solid = want_solid ? (uint32_t*)(dout + o_solid) : nullptr;
+    dr.solid_off = want_solid ? (const uint64_t*)(dout + o_soff) : nullptr;
+    dr.solid_len = want_solid ? (uint32_t*)(dout + o_slen) : nullptr;
+    rc = cw_run_device(e, &db, &dr, st);
+    if (rc) return rc;
+    CW_HIP(hipMemcpyAsync(r->cons, dout + o_cons, cons_total, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipMemcpyAsync(r->cons_len, dout + o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipMemcpyAsync(r->win_status, dout + o_stat, W, hipMemcpyDeviceToHost, st));
+    if (want_solid) {
+        CW_HIP(hipMemcpyAsync(r->solid, dout + o_solid, solid_total * 4, hipMemcpyDeviceToHost, st));
+        CW_HIP(hipMemcpyAsync(r->solid_len, dout + o_slen, (size_t)W * 4, hipMemcpyDeviceToHost, st));
+    }
+    CW_HIP(hipStreamSynchronize(st));
+    for (uint32_t w = 0; w < W; ++w) if (r->win_status[w] == CW_WIN_OVERFLOW) return CW_E_CAPACITY;
+    return CW_OK;
+}
+
+} // extern "C"

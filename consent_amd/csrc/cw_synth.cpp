@@ -79,7 +79,7 @@ int64_t cw_pack_sequence(const char* seq, uint32_t len, uint32_t* out, uint64_t 
         case 'G': case 'g': c = 2; break;
         default: c = 3; break;
         }
-        out[j >> 4] |= c << (2 * (j & 15));
+        out[j >> 4] |= c << (30 - 2 * (j & 15));
     }
     return (int64_t)need;
 }

@@ -83,7 +83,7 @@ __host__ __device__ inline uint32_t synth_sequence(uint64_t wseed, uint32_t s, u
         }
         if (!emit) continue;
         if (emitted >= drop) {
-            cur |= b << (2 * (out & 15u));
+            cur |= b << (30 - 2 * (out & 15u));
             if ((out & 15u) == 15u) { words[out >> 4] = cur; cur = 0; }
             out++;
         }

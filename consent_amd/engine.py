@@ -1,0 +1,303 @@
+"""ctypes binding of the C ABI (include/consent_amd.h) + the host-side mirror of CONSENT's operator.
+
+Mirrors ``computeConsensusReadCorrection`` / ``computeConsensusAssemblyPolishing``
+(reference src/correctionMSA.h:8,10): same argument names and meaning, batched over windows.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+WIN_CONSENSUS, WIN_TEMPLATE, WIN_OVERFLOW = 0, 1, 2
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """cw_params: merSize, solidThresh, commonKMers, minAnchors, maxMSA (reference main.cpp:17-26 names)."""
+
+    _fields_ = [("k", C.c_uint32), ("solid", C.c_uint32), ("common_kmers", C.c_uint32), ("min_anchors", C.c_uint32), ("max_msa", C.c_uint32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_windows", C.c_uint32),
+        ("n_seqs", C.c_uint32),
+        ("n_words", C.c_uint64),
+        ("win_first_seq", C.c_void_p),
+        ("seq_len", C.c_void_p),
+        ("seq_word_off", C.c_void_p),
+        ("bases", C.c_void_p),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("cons", C.c_void_p),
+        ("cons_off", C.c_void_p),
+        ("cons_len", C.c_void_p),
+        ("win_status", C.c_void_p),
+        ("solid", C.c_void_p),
+        ("solid_off", C.c_void_p),
+        ("solid_len", C.c_void_p),
+    ]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("first_window", C.c_uint64),
+        ("n_windows", C.c_uint32),
+        ("depth", C.c_uint32),
+        ("window_len", C.c_uint32),
+        ("err_permille", C.c_uint32),
+        ("sub_w", C.c_uint32),
+        ("ins_w", C.c_uint32),
+        ("del_w", C.c_uint32),
+        ("seq_stride_words", C.c_uint32),
+    ]
+
+    @classmethod
+    def pacbio(cls, n_windows, depth, first_window=0, seed=0xC0115E17, window_len=500):
+        return cls(seed, first_window, n_windows, depth, window_len, 120, 10, 60, 30, (window_len + 60) // 16 + 2)
+
+    @classmethod
+    def ont(cls, n_windows, depth, first_window=0, seed=0xC0115E17, window_len=500):
+        return cls(seed, first_window, n_windows, depth, window_len, 120, 30, 30, 40, (window_len + 60) // 16 + 2)
+
+
+def lib_path():
+    return os.path.join(_HERE, "libconsent_amd.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libconsent_amd.so.  Fails loudly: there is no fallback implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise EngineError(f"{p} is missing: build it with `python -m consent_amd._build` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(p)
+    lib.cw_version.restype = C.c_char_p
+    lib.cw_strerror.restype = C.c_char_p
+    lib.cw_strerror.argtypes = [C.c_int]
+    lib.cw_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+    lib.cw_destroy.argtypes = [C.c_void_p]
+    lib.cw_destroy.restype = None
+    lib.cw_run.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result)]
+    lib.cw_run_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_void_p]
+    lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+    lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    lib.cw_pack_sequence.restype = C.c_int64
+    lib.cw_synth_sizes.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.cw_synth_host.argtypes = [C.POINTER(SynthSpec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cw_synth_device.argtypes = [C.c_void_p, C.POINTER(SynthSpec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _LIB = lib
+    return lib
+
+
+def _check(lib, rc, what, allow_capacity=False):
+    if rc == 0 or (allow_capacity and rc == -4):
+        return rc
+    raise EngineError(f"{what}: {lib.cw_strerror(rc).decode()} ({rc})")
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class HostBatch:
+    """Host arrays laid out as cw_batch."""
+
+    def __init__(self, win_first_seq, seq_len, seq_word_off, bases):
+        self.win_first_seq = np.ascontiguousarray(win_first_seq, np.uint32)
+        self.seq_len = np.ascontiguousarray(seq_len, np.uint32)
+        self.seq_word_off = np.ascontiguousarray(seq_word_off, np.uint64)
+        self.bases = np.ascontiguousarray(bases, np.uint32)
+
+    @property
+    def n_windows(self):
+        return len(self.win_first_seq) - 1
+
+    def c_struct(self):
+        return Batch(self.n_windows, len(self.seq_len), len(self.bases), _ptr(self.win_first_seq), _ptr(self.seq_len), _ptr(self.seq_word_off), _ptr(self.bases))
+
+    def pile(self, w):
+        """Decode window w back to a list of ASCII strings (test helper)."""
+        out = []
+        for s in range(int(self.win_first_seq[w]), int(self.win_first_seq[w + 1])):
+            n = int(self.seq_len[s])
+            o = int(self.seq_word_off[s])
+            words = self.bases[o : o + (n + 15) // 16]
+            codes = ((words[:, None] >> (30 - 2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).reshape(-1)[:n]
+            out.append(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode())
+        return out
+
+    def slice(self, w0, w1):
+        s0, s1 = int(self.win_first_seq[w0]), int(self.win_first_seq[w1])
+        return HostBatch(self.win_first_seq[w0 : w1 + 1] - s0, self.seq_len[s0:s1], self.seq_word_off[s0:s1], self.bases)
+
+
+def pack_piles(piles):
+    """List of piles (each a list of ACGT strings, template first) -> HostBatch (reference 2-bit alphabet, utils.cpp:21-32)."""
+    lib = load_library()
+    n_seqs = sum(len(p) for p in piles)
+    wfs = np.zeros(len(piles) + 1, np.uint32)
+    lens = np.zeros(n_seqs, np.uint32)
+    offs = np.zeros(n_seqs, np.uint64)
+    total_words = sum((len(s) + 15) // 16 for p in piles for s in p)
+    bases = np.zeros(max(total_words, 1), np.uint32)
+    si = 0
+    wo = 0
+    for w, p in enumerate(piles):
+        wfs[w] = si
+        for s in p:
+            raw = s.encode()
+            lens[si] = len(raw)
+            offs[si] = wo
+            got = lib.cw_pack_sequence(raw, len(raw), C.c_void_p(bases.ctypes.data + 4 * wo), total_words - wo)
+            if got < 0:
+                raise EngineError("cw_pack_sequence failed")
+            wo += got
+            si += 1
+    wfs[len(piles)] = si
+    return HostBatch(wfs, lens, offs, bases)
+
+
+def synth_host(spec):
+    lib = load_library()
+    ns, nw = C.c_uint32(), C.c_uint64()
+    _check(lib, lib.cw_synth_sizes(C.byref(spec), C.byref(ns), C.byref(nw)), "cw_synth_sizes")
+    wfs = np.zeros(spec.n_windows + 1, np.uint32)
+    lens = np.zeros(ns.value, np.uint32)
+    offs = np.zeros(ns.value, np.uint64)
+    bases = np.zeros(nw.value, np.uint32)
+    _check(lib, lib.cw_synth_host(C.byref(spec), _ptr(wfs), _ptr(lens), _ptr(offs), _ptr(bases)), "cw_synth_host")
+    return HostBatch(wfs, lens, offs, bases)
+
+
+class WindowResults:
+    def __init__(self, cons, cons_off, cons_len, status, solid=None, solid_off=None, solid_len=None):
+        self.cons, self.cons_off, self.cons_len, self.status = cons, cons_off, cons_len, status
+        self.solid, self.solid_off, self.solid_len = solid, solid_off, solid_len
+
+    def consensus(self, w):
+        o = int(self.cons_off[w])
+        return self.cons[o : o + int(self.cons_len[w])].tobytes().decode()
+
+    def solid_kmers(self, w):
+        o = int(self.solid_off[w])
+        return self.solid[o : o + int(self.solid_len[w])]
+
+
+def alloc_results(batch, want_solid=True, solid_thresh=4, k=9):
+    W = batch.n_windows
+    wfs = batch.win_first_seq.astype(np.int64)
+    tpl = batch.seq_len[wfs[:-1]].astype(np.int64)
+    cap = 3 * tpl + 256
+    cons_off = np.zeros(W + 1, np.uint64)
+    cons_off[1:] = np.cumsum(cap)
+    cons = np.zeros(int(cons_off[-1]), np.uint8)
+    cons_len = np.zeros(W, np.uint32)
+    status = np.full(W, 255, np.uint8)
+    if not want_solid:
+        return WindowResults(cons, cons_off, cons_len, status)
+    csum = np.concatenate([[0], np.cumsum(batch.seq_len.astype(np.int64))])
+    per_win = csum[wfs[1:]] - csum[wfs[:-1]]
+    scap = per_win // max(1, solid_thresh) + 16
+    solid_off = np.zeros(W + 1, np.uint64)
+    solid_off[1:] = np.cumsum(scap)
+    solid = np.zeros(int(solid_off[-1]), np.uint32)
+    solid_len = np.zeros(W, np.uint32)
+    return WindowResults(cons, cons_off, cons_len, status, solid, solid_off, solid_len)
+
+
+def _result_struct(r):
+    return Result(
+        _ptr(r.cons), _ptr(r.cons_off), _ptr(r.cons_len), _ptr(r.status),
+        _ptr(r.solid) if r.solid is not None else None,
+        _ptr(r.solid_off) if r.solid is not None else None,
+        _ptr(r.solid_len) if r.solid is not None else None,
+    )
+
+
+class Engine:
+    """One engine per process per GPU (cw_create / cw_destroy)."""
+
+    def __init__(self, params, device=0):
+        self.lib = load_library()
+        self.params = params
+        self.handle = C.c_void_p()
+        _check(self.lib, self.lib.cw_create(C.byref(params), device, C.byref(self.handle)), "cw_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.cw_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, batch, want_solid=True):
+        """Host buffers in, host buffers out (cw_run).  Windows that overflow a capacity carry WIN_OVERFLOW."""
+        res = alloc_results(batch, want_solid, self.params.solid, self.params.k)
+        b = batch.c_struct()
+        r = _result_struct(res)
+        _check(self.lib, self.lib.cw_run(self.handle, C.byref(b), C.byref(r)), "cw_run", allow_capacity=True)
+        return res
+
+    def run_device(self, batch_struct, result_struct, stream=None):
+        _check(self.lib, self.lib.cw_run_device(self.handle, C.byref(batch_struct), C.byref(result_struct), stream), "cw_run_device")
+
+    def timings(self):
+        ms = (C.c_float * 8)()
+        names = (C.c_char_p * 8)()
+        n = C.c_int()
+        _check(self.lib, self.lib.cw_last_timings(self.handle, ms, names, 8, C.byref(n)), "cw_last_timings")
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def win_info(self, n_windows):
+        a = np.zeros((n_windows, 16), np.uint32)
+        _check(self.lib, self.lib.cw_debug_win_info(self.handle, n_windows, _ptr(a)), "cw_debug_win_info")
+        return a
+
+
+def _operator(piles, merSize, commonKMers, minAnchors, solidThresh, maxMSA, device):
+    eng = Engine(Params(merSize, solidThresh, commonKMers, minAnchors, maxMSA), device)
+    try:
+        res = eng.run(pack_piles(piles), want_solid=True)
+    finally:
+        eng.close()
+    out = []
+    for w in range(len(piles)):
+        if res.status[w] == WIN_OVERFLOW:
+            raise EngineError(f"window {w}: capacity overflow")
+        out.append((res.consensus(w), res.solid_kmers(w).copy()))
+    return out
+
+
+def compute_consensus_read_correction(readId, piles, pilesPos, minSupport, merSize, commonKMers, minAnchors, solidThresh, windowSize, maxMSA, path="", device=0):
+    """Batched mirror of computeConsensusReadCorrection (reference src/correctionMSA.cpp:29-49).
+
+    ``piles`` is a list of window piles (template first).  As in the reference body, ``readId``, ``pilesPos``,
+    ``minSupport``, ``windowSize`` and ``path`` do not influence the result.  Returns, per window,
+    ``(consensus, solid_kmers)``: the case-annotated consensus and the ascending k-mers whose pile-wide count
+    is >= solidThresh (what callers read from the reference's merCounts map).
+    """
+    return _operator(piles, merSize, commonKMers, minAnchors, solidThresh, maxMSA, device)
+
+
+def compute_consensus_assembly_polishing(id, readId, piles, pilesPos, minSupport, merSize, commonKMers, minAnchors, solidThresh, windowSize, maxMSA, path="", nbThreads=1, device=0):
+    """Batched mirror of computeConsensusAssemblyPolishing (reference src/correctionMSA.cpp:51-71); same body."""
+    return _operator(piles, merSize, commonKMers, minAnchors, solidThresh, maxMSA, device)

@@ -12,9 +12,6 @@
  *   cw_pack_window           <- the vector<string> pile handed to those operators
  *                               (CONSENT-correction.cpp:35-37, CONSENT-polishing.cpp:46-49): 2-bit packing
  *                               with the reference's own alphabet (utils.cpp:21-32: A=00 C=01 G=10 else=11).
- *   cw_extract_piles_device  <- getAlignmentWindowsSequences (alignmentWindows.h, alignmentWindows.cpp:87-149),
- *                               device-side pile extraction from 2-bit reads + Overlap tuples.
- *   cw_window_positions      <- getAlignmentWindowsPositions (alignmentWindows.cpp:27-85) (host).
  *
  * Plain pointers and sizes only; the caller owns every buffer; nothing is retained past return.
  * No C++ exception crosses this boundary.  All functions return 0 on success or a negative cw_status.
@@ -57,8 +54,10 @@ typedef struct cw_params {
 /*
  * A batch of window piles.  Sequence s of window w has global index win_first_seq[w] + s; index
  * win_first_seq[w] itself is the template (pile[0], alignmentWindows.cpp:100).
- * Bases are 2-bit codes, 16 per 32-bit word, base j of a sequence in word seq_word_off[s] + j/16 at
- * bits [2*(j%16), 2*(j%16)+1].  Every sequence starts on a word boundary.
+ * Bases are 2-bit codes (A=0 C=1 G=2 T=3), 16 per 32-bit word, most significant first: base j of a
+ * sequence sits in word seq_word_off[s] + j/16 at bits [30-2*(j%16), 31-2*(j%16)], so that a k-mer read
+ * off the words is already in str2num order.  Every sequence starts on a word boundary; unused low
+ * bits of its last word are zero.
  */
 typedef struct cw_batch {
     uint32_t n_windows;
@@ -107,6 +106,11 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* result, 
 /* Milliseconds spent in each device stage of the last cw_run / cw_run_device on this engine, measured
  * with HIP events on the launch stream.  n_stages entries are written (at most cap); names are static. */
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages);
+
+/* Inspection aid for tests: copies the engine's per-window bookkeeping of the last run to host, 16 uint32 per
+ * window: status, n_seqs, tpl_len, n_kmers, solid_base, solid_cap, n_solid, seg_base, seg_cap, n_segs,
+ * arena_base, arena_cap, arena_used, 3 reserved. */
+int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16);
 
 /* Pack one ASCII window pile (n strings, lens[i] bytes each, not NUL-terminated) at the tail of host
  * arrays laid out as cw_batch.  words_cap counts 32-bit words available at bases_out.  Returns the

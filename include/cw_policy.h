@@ -1,7 +1,7 @@
 /*
  * cw_policy.h -- every free policy of the segmented-POA restatement, named in one place.
  *
- * TEST INFRASTRUCTURE / SHARED CONSTANTS.  This header carries no algorithm, only constants; it is the
+ * SHARED CONSTANTS (not oracle code).  This header carries no algorithm, only constants; it is the
  * single file both the CPU oracle (oracle/) and the HIP engine (consent_amd/csrc/) include so that
  * the two sides cannot drift apart on a tie-break.
  *

@@ -5,7 +5,7 @@
  * Written for clarity, not speed: strings and node-based containers, one window at a time.
  */
 #include "cw_oracle.hpp"
-#include "cw_policy.h"
+#include "../include/cw_policy.h"
 
 #include <algorithm>
 #include <cassert>

@@ -16,7 +16,7 @@ using namespace cwo;
 static std::string unpack(const cw_batch* b, uint32_t s) {
     std::string out(b->seq_len[s], 'A');
     const uint32_t* w = b->bases + b->seq_word_off[s];
-    for (uint32_t j = 0; j < b->seq_len[s]; ++j) out[j] = "ACGT"[(w[j >> 4] >> (2 * (j & 15))) & 3];
+    for (uint32_t j = 0; j < b->seq_len[s]; ++j) out[j] = "ACGT"[(w[j >> 4] >> (30 - 2 * (j & 15))) & 3];
     return out;
 }
 
