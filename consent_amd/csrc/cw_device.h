@@ -61,11 +61,14 @@ struct BatchCounters {
     uint32_t n_tasks;
     uint32_t n_members;
     uint32_t next_task;    /* work-stealing cursor of the LDS POA kernel */
-    uint32_t n_big;        /* tasks deferred to the large-graph kernel */
+    uint32_t n_big;        /* tasks deferred to tier G */
     uint32_t next_big;
     uint32_t next_window;  /* work-stealing cursor of the index kernel */
     uint32_t next_finish;  /* work-stealing cursor of the finish kernel */
     uint32_t any_overflow;
+    uint32_t n_mid;        /* tasks for tier M */
+    uint32_t next_mid;
+    unsigned long long prof[24]; /* cycle totals per phase (wall_clock64), see cw_debug_profile */
 };
 
 struct DevBatch {
@@ -87,10 +90,14 @@ struct DevScratch {
     uint32_t task_cap;
     PoaMember* members;
     uint32_t member_cap;
-    uint32_t* big_list; /* indices of tasks for the large-graph kernel */
-    uint32_t big_cap;
+    uint32_t* big_list; /* indices of tasks for tier G */
+    uint32_t* mid_list; /* indices of tasks for tier M */
+    uint32_t big_cap;   /* capacity of both lists */
     BatchCounters* ctr;
-    uint8_t* big_scratch; /* per-wave slabs of the large-graph kernel */
+    uint8_t* mid_scratch; /* per-wave DP slabs of tier M */
+    uint64_t mid_slab_bytes;
+    uint32_t mid_slots;
+    uint8_t* big_scratch; /* per-wave slabs of tier G */
     uint64_t big_slab_bytes;
     uint32_t big_slots;
 };
@@ -106,6 +113,15 @@ __device__ __forceinline__ uint32_t cw_kmer_at(const uint32_t* w, uint32_t p, ui
     x <<= sh;
     return (uint32_t)(x >> (64 - 2 * k));
 }
+
+/* phase profiling: lane/thread 0 of a work unit adds elapsed s_memtime ticks into ctr->prof[slot] */
+#define CW_PROF_T0() unsigned long long _pt = __builtin_readcyclecounter()
+#define CW_PROF(ctr, slot, leader)                                                        \
+    do {                                                                                  \
+        unsigned long long _now = __builtin_readcyclecounter();                           \
+        if (leader) atomicAdd(&(ctr)->prof[slot], _now - _pt);                            \
+        _pt = _now;                                                                       \
+    } while (0)
 
 __device__ __forceinline__ int cw_lane() { return (int)(threadIdx.x & 63); }
 

@@ -24,12 +24,14 @@ size_t big_slab_bytes() {
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, ctr, big, total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, mid_list, ctr, big, mid, total;
     uint64_t solid_cap, seg_cap, arena_cap;
-    uint32_t task_cap, member_cap, big_slots;
+    uint32_t task_cap, member_cap, big_slots, mid_slots;
 };
 
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots) {
+size_t mid_slab_bytes() { return align_up((size_t)CW_POAM_HC * 2, 256); }
+
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots, uint32_t mid_slots) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
@@ -39,6 +41,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
     p.big_slots = big_slots;
+    p.mid_slots = mid_slots;
     size_t o = 0;
     auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
     put(p.win, (size_t)n_windows * sizeof(WinInfo));
@@ -50,8 +53,10 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     put(p.tasks, (size_t)p.task_cap * sizeof(PoaTask));
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
     put(p.big_list, (size_t)p.task_cap * 4);
+    put(p.mid_list, (size_t)p.task_cap * 4);
     put(p.ctr, sizeof(BatchCounters));
     put(p.big, (size_t)big_slots * big_slab_bytes());
+    put(p.mid, (size_t)mid_slots * mid_slab_bytes());
     p.total = o;
     return p;
 }
@@ -118,6 +123,7 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
         return CW_E_NO_DEVICE;
@@ -148,7 +154,12 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
 
     uint32_t big_slots = 256;
     if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots);
+    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    const uint32_t mid_blocks_per_cu = 3;
+    const uint32_t mid_slots = (uint32_t)cus * mid_blocks_per_cu * CW_POAM_WAVES;
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots, mid_slots);
+    e->last_mid_slots = mid_slots;
+    e->last_windows = batch->n_windows; e->last_words = batch->n_words; e->last_big_slots = big_slots;
     int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)e->scratch;
@@ -164,13 +175,14 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.tasks = (PoaTask*)(base + p.tasks); sc.task_cap = p.task_cap;
     sc.members = (PoaMember*)(base + p.members); sc.member_cap = p.member_cap;
     sc.big_list = (uint32_t*)(base + p.big_list); sc.big_cap = p.task_cap;
+    sc.mid_list = (uint32_t*)(base + p.mid_list);
+    sc.mid_scratch = base + p.mid; sc.mid_slab_bytes = mid_slab_bytes(); sc.mid_slots = p.mid_slots;
     sc.ctr = (BatchCounters*)(base + p.ctr);
     sc.big_scratch = base + p.big; sc.big_slab_bytes = big_slab_bytes(); sc.big_slots = p.big_slots;
     FinOut fo;
     fo.cons = res->cons; fo.cons_off = res->cons_off; fo.cons_len = res->cons_len; fo.win_status = res->win_status;
     fo.solid = res->solid; fo.solid_off = res->solid_off; fo.solid_len = res->solid_len;
 
-    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     e->n_stages = 0;
     e->timings_valid = false;
     CW_HIP(hipEventRecord(e->ev[0], st));
@@ -184,6 +196,8 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     mark(e, st, "index");
     cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
     mark(e, st, "poa");
+    cw_poa_mid_kernel<<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
+    mark(e, st, "poa_mid");
     cw_poa_big_kernel<<<p.big_slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     mark(e, st, "poa_big");
     {
@@ -219,6 +233,18 @@ int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
     if (!e || !out16 || !e->scratch) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
     CW_HIP(hipMemcpy(out16, e->scratch, (size_t)n_windows * sizeof(WinInfo), hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+
+/* Debug/inspection: the 10 batch counters (u32) and 24 per-phase cycle totals (u64) of the last run. */
+int cw_debug_profile(cw_engine* e, uint32_t* counters8, unsigned long long* prof24) {
+    if (!e || !e->scratch || !counters8 || !prof24) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, e->last_big_slots, e->last_mid_slots);
+    BatchCounters c;
+    CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
+    memcpy(counters8, &c, 40);
+    memcpy(prof24, c.prof, sizeof(c.prof));
     return CW_OK;
 }
 

@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const uint32_t N = wi->n_seqs;
         const uint32_t L0 = wi->tpl_len;
 
+        CW_PROF_T0();
         /* ================= phase A: counts ================= */
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 0, tid == 0);
         /* exact counts for the keys whose 4-bit counter saturated */
         for (uint32_t sp = 0; sp < N; sp += 2) {
             const uint32_t s = sp + (tid >> 9);
@@ -207,6 +209,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than the exact table holds */
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             continue;
@@ -270,6 +273,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (!fits) continue;
         }
 
+        CW_PROF(sc.ctr, 2, tid == 0);
         /* ================= phase B: anchor candidates ================= */
         const uint32_t nk0 = L0 >= k ? L0 - k + 1 : 0;
         const int sup_min = min((int)prm.common_kmers, (int)N / 2); /* correctionMSA.cpp:31 */
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             cw_wave_sync();
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 3, tid == 0);
         /* candidates in template order */
         uint32_t A;
         {
@@ -328,12 +333,12 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (ok) { tcand[tid] = (int16_t)off; cand_tp[off] = (uint16_t)tid; }
         }
         __syncthreads();
-        const uint32_t Np = N;
-        if ((uint64_t)A * Np > p_cap) {
+        const uint32_t Ap = A | 1u; /* P is sequence-major: P[s * Ap + a]; odd stride spreads the banks */
+        if ((uint64_t)Ap * N > p_cap) {
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             continue;
         }
-        for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) P[i] = CW_NONE16;
+        for (uint32_t i = tid; i < Ap * N; i += CW_IDX_THREADS) P[i] = CW_NONE16;
         __syncthreads();
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
             const uint32_t len = b.seq_len[s0 + s];
@@ -343,38 +348,52 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const int e = cw_tpl_lookup(th, tkey, cw_kmer_at(words, p, k));
                 if (e < 0) continue;
                 const int a = tcand[e];
-                if (a >= 0) P[(uint32_t)a * Np + s] = (uint16_t)p;
+                if (a >= 0) P[s * Ap + (uint32_t)a] = (uint16_t)p;
             }
         }
         __syncthreads();
 
+        CW_PROF(sc.ctr, 4, tid == 0);
         /* ================= phase C: chain ================= */
-        if (wave == 0) {
-            int maxlvl = -1;
+        /* best(a) for a = A-1 .. 0: every thread scores one successor b > a against all N sequences, then a
+           block-wide lexicographic max (length, summed score, smallest b) picks the link (cw_policy.h). */
+        {
+            unsigned long long* red = (unsigned long long*)(misc + 16); /* 16 x u64 */
             for (int a = (int)A - 1; a >= 0; --a) {
-                int best_len = -1, best_next = -1, best_sc = 0;
-                for (int lv = maxlvl; lv >= 0 && best_len < 0; --lv) {
-                    for (int bb = lvl_head[lv]; bb != -1; bb = bnext[bb]) {
-                        int cnt = 0;
-                        for (uint32_t s = lane; s < N; s += 64) {
-                            const uint32_t pa = P[(uint32_t)a * Np + s], pb = P[(uint32_t)bb * Np + s];
-                            cnt += (pa != CW_NONE16 && pb != CW_NONE16 && pa < pb) ? 1 : 0;
+                const uint32_t bb = (uint32_t)a + 1u + (uint32_t)tid;
+                unsigned long long key = 0ull;
+                if ((uint32_t)a + 1u + (uint32_t)(wave * 64) < A) { /* wave-uniform: this wave owns at least one b */
+                    if (bb < A) {
+                        uint32_t cnt = 0;
+                        for (uint32_t s = 0; s < N; ++s) {
+                            const uint32_t pa = P[s * Ap + (uint32_t)a], pb = P[s * Ap + bb];
+                            cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
                         }
-                        cnt = cw_wave_sum(cnt);
-                        if (cnt >= sup_min) {
-                            const int cand = csc[bb] + cnt;
-                            if (best_len < 0 || cand > best_sc) { best_len = lv; best_sc = cand; best_next = bb; }
-                        }
+                        if ((int)cnt >= sup_min)
+                            key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
+                                  (unsigned long long)(0xFFFFu - bb);
+                    }
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long ok = __shfl_xor(key, o);
+                        key = ok > key ? ok : key;
                     }
                 }
-                const int la = best_len + 1;
-                if (lane == 0) {
-                    clen[a] = (int16_t)la; csc[a] = best_sc; cnxt[a] = (int16_t)best_next;
-                    bnext[a] = lvl_head[la]; lvl_head[la] = (int16_t)a;
+                if (lane == 0) red[wave] = key;
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned long long best = 0ull;
+                    for (int q = 0; q < CW_IDX_WAVES; ++q) best = red[q] > best ? red[q] : best;
+                    if (best == 0ull) { clen[a] = 0; csc[a] = 0; cnxt[a] = -1; }
+                    else {
+                        clen[a] = (int16_t)(best >> 48); /* stored length+1 of b == length of a */
+                        csc[a] = (int32_t)((best >> 16) & 0xFFFFFFFFull);
+                        cnxt[a] = (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
+                    }
                 }
-                maxlvl = max(maxlvl, la);
-                cw_wave_sync();
+                __syncthreads();
             }
+        }
+        if (wave == 0) {
             /* chain start: longest, then best score, then largest index; a chain needs at least one edge */
             int b_len = 0, b_sc = 0, b_a = -1;
             for (int a = (int)A - 1 - lane; a >= 0; a -= 64) {
@@ -396,6 +415,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (lane == 0) misc[0] = (uint32_t)m;
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 5, tid == 0);
         const uint32_t m = misc[0];
         if (m == 0 || m < prm.min_anchors) {
             if (tid == 0) wi->status = CW_WIN_TEMPLATE;
@@ -419,8 +439,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
+                    const uint32_t pa = ca >= 0 ? P[s * Ap + (uint32_t)ca] : 0u;
+                    const uint32_t pb = cb >= 0 ? P[s * Ap + (uint32_t)cb] : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
@@ -473,8 +493,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
+                    const uint32_t pa = ca >= 0 ? P[s * Ap + (uint32_t)ca] : 0u;
+                    const uint32_t pb = cb >= 0 ? P[s * Ap + (uint32_t)cb] : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
@@ -491,12 +511,20 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (lane == 0) {
                 PoaTask t;
                 t.window = w; t.seg_slot = slot; t.member_off = m_off; t.n_members = n_mem; t.max_len = mx;
-                t.out_off = abs_off; t.out_cap = need; t.state = 0;
+                t.out_off = abs_off; t.out_cap = need;
+                /* the graph has at least max_len nodes once its longest member is in: (max_len+1)^2 cells */
+                const bool to_mid = (mx + 1) * (mx + 1) > 4096u || mx > 255u;
+                t.state = to_mid ? 2u : 0u;
                 sc.tasks[t_idx] = t;
+                if (to_mid) {
+                    const uint32_t bi = atomicAdd(&sc.ctr->n_mid, 1u);
+                    if (bi < sc.big_cap) sc.mid_list[bi] = t_idx; else misc[2] = 1;
+                }
                 sc.seg_off[slot] = abs_off; sc.seg_len[slot] = 0;
             }
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 6, tid == 0);
         if (tid == 0) {
             if (misc[2]) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             else { wi->n_segs = m + 1; wi->arena_used = misc[1]; }

@@ -28,6 +28,8 @@ struct cw_engine {
     const char* stage_name[CW_MAX_STAGES];
     float stage_ms[CW_MAX_STAGES];
     bool timings_valid;
+    uint32_t last_windows, last_big_slots, last_mid_slots;
+    uint64_t last_words;
 };
 
 #define CW_HIP(expr)                                   \

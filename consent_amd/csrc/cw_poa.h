@@ -1,10 +1,11 @@
 /*
  * cw_poa.h -- partial-order alignment of one segment pile per wavefront (A4d).
  *
- * One 64-lane wave owns one task from the list the index kernel emitted.  The graph (nodes, in-edge
- * lists, MSA columns, rank order) and the DP matrix live in a per-wave slab: LDS for the common case
- * (cw_poa_kernel), a global slab for the rare oversized graph (cw_poa_big_kernel).  Same code, two
- * instantiations.
+ * One 64-lane wave owns one task from the list the index kernel emitted.  Same code, three memory tiers:
+ *   S (cw_poa_kernel)      graph + DP matrix in LDS            small segments (most tasks)
+ *   M (cw_poa_mid_kernel)  graph in LDS, matrix in an L2-resident per-wave slab   long segments
+ *   G (cw_poa_big_kernel)  everything in a per-wave global slab                   the rare huge graph
+ * A task that outgrows its tier is handed to the next one and redone there from scratch.
  *
  *   DP fill     lanes = sequence positions (columns); rows = graph nodes in rank order; the horizontal
  *               gap recurrence H[i][j] = max(H[i][j], H[i][j-1]+g) is a wave-level inclusive prefix-max
@@ -21,12 +22,18 @@
 
 #include "cw_device.h"
 
-/* LDS-path capacities (per wave) */
+/* tier S: graph and DP matrix in LDS (per wave) */
 #define CW_POA_NC 160   /* nodes            */
 #define CW_POA_EC 448   /* edges            */
 #define CW_POA_LC 255   /* member length    */
 #define CW_POA_HC 4096  /* DP cells (int16) */
-/* global-slab capacities (per wave) */
+/* tier M: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2-resident */
+#define CW_POAM_NC 512
+#define CW_POAM_EC 1280
+#define CW_POAM_LC 511
+#define CW_POAM_HC ((CW_POAM_NC + 1) * (CW_POAM_LC + 1))
+#define CW_POAM_WAVES 2
+/* tier G: everything in a per-wave global slab (int32 cells) */
 #define CW_POAB_NC 2048
 #define CW_POAB_EC 8192
 #define CW_POAB_LC 1023
@@ -65,10 +72,11 @@ __device__ __forceinline__ size_t poa_mem_bytes(uint32_t nc, uint32_t ec, uint32
 }
 
 template <typename HT>
-__device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc) {
+__device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, HT* h_ext = nullptr) {
     PoaMem<HT> M;
     uint8_t* p = base;
-    M.H = (HT*)p; p += (size_t)hc * sizeof(HT);
+    if (h_ext) M.H = h_ext;
+    else { M.H = (HT*)p; p += (size_t)hc * sizeof(HT); }
     M.ncov = (uint16_t*)p; p += 2 * nc;
     M.nal = (uint16_t*)p; p += 6 * nc;
     M.in_head = (uint16_t*)p; p += 2 * nc;
@@ -92,7 +100,10 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
 
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded. */
 template <typename HT>
-__device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane) {
+__device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
+                       unsigned long long (&acc)[6]) {
+    unsigned long long _pt = __builtin_readcyclecounter();
+#define POA_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
     bool csr_ok = false;
@@ -145,9 +156,57 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             cw_wave_sync();
         }
 
+        POA_PROF(0);
         /* ---- DP fill ---- */
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         cw_wave_sync();
+        if (cols <= 128) {
+            /* rows of <= 2 chunks: the previous row stays in registers, so a chain of nodes never waits on memory */
+            const bool two = cols > 64;
+            const int j0 = lane, j1 = 64 + lane;
+            const bool act0 = j0 < cols, act1 = two && j1 < cols;
+            const int s0q = (j0 > 0 && act0) ? (int)M.sq[j0 - 1] : -1, s1q = act1 ? (int)M.sq[j1 - 1] : -1;
+            int prev0 = j0 * G, prev1 = j1 * G; /* row 0 */
+            for (int r = 0; r < n; ++r) {
+                const int i = r + 1;
+                const int base = M.nbase[M.r2n[r]];
+                const int p0 = M.poff[r], p1 = M.poff[r + 1];
+                const int sc0 = (s0q == base) ? MS : XS, sc1 = (s1q == base) ? MS : XS;
+                int v0 = CW_NEG, v1 = CW_NEG;
+                const int np = (p0 == p1) ? 1 : p1 - p0;
+                for (int q = 0; q < np; ++q) {
+                    const int prow = (p0 == p1) ? 0 : (int)M.plist[p0 + q];
+                    int up0, up1, dg0, dg1;
+                    if (prow == i - 1) {
+                        up0 = prev0; up1 = prev1;
+                        const int sh0 = __shfl_up(prev0, 1), sh1 = __shfl_up(prev1, 1), last0 = __shfl(prev0, 63);
+                        dg0 = lane ? sh0 : CW_NEG;
+                        dg1 = lane ? sh1 : last0;
+                    } else {
+                        cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
+                        const int pr = prow * cols;
+                        up0 = act0 ? (int)M.H[pr + j0] : CW_NEG;
+                        dg0 = (act0 && j0 > 0) ? (int)M.H[pr + j0 - 1] : CW_NEG;
+                        up1 = act1 ? (int)M.H[pr + j1] : CW_NEG;
+                        dg1 = act1 ? (int)M.H[pr + j1 - 1] : CW_NEG;
+                    }
+                    v0 = max(v0, max(dg0 + sc0, up0 + G));
+                    v1 = max(v1, max(dg1 + sc1, up1 + G));
+                }
+                int w0 = act0 ? v0 - j0 * G : CW_NEG;
+                w0 = cw_wave_scan_max(w0, lane);
+                prev0 = w0 + j0 * G;
+                if (act0) M.H[i * cols + j0] = (HT)prev0;
+                if (two) {
+                    int w1 = act1 ? v1 - j1 * G : CW_NEG;
+                    w1 = cw_wave_scan_max(w1, lane);
+                    w1 = max(w1, __shfl(w0, 63));
+                    prev1 = w1 + j1 * G;
+                    if (act1) M.H[i * cols + j1] = (HT)prev1;
+                }
+            }
+            cw_wave_sync();
+        } else
         for (int r = 0; r < n; ++r) {
             const int i = r + 1;
             const int base = M.nbase[M.r2n[r]];
@@ -181,6 +240,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             cw_wave_sync();
         }
 
+        POA_PROF(1);
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
         int bi;
         {
@@ -235,6 +295,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             }
         }
         cw_wave_sync();
+        POA_PROF(2);
 
         /* ---- merge the path into the graph (wave-uniform, rank shifts by all lanes) ---- */
         {
@@ -331,6 +392,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             }
         }
         cw_wave_sync();
+        POA_PROF(3);
     }
 
     /* ---- column-majority consensus ---- */
@@ -370,26 +432,67 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
     }
     if (out_len > t.out_cap) return 3;
     if (lane == 0) sc.seg_len[t.seg_slot] = out_len;
+    POA_PROF(4);
+#undef POA_PROF
     return 1;
 }
 
-/* ---- LDS instantiation: one task per wave, work-stealing over the task list --------------------- */
-#define CW_POA_SLAB_BYTES                                                                                                     \
-    ((CW_POA_HC * 2 + CW_POA_NC * (1 + 2 + 1 + 6 + 2 + 2 + 2 + 1 + 2 + 2) + CW_POA_EC * 6 + 2 * (CW_POA_NC + 1) +                \
-      4 * (CW_POA_NC + CW_POA_LC + 2) + (CW_POA_LC + 1) + 15) / 16 * 16)
+/* ---- tier S: one task per wave, graph + DP matrix in LDS, work-stealing over the task list -------- */
+#define CW_POA_GRAPH_BYTES(NC, EC, LC) ((NC) * 21 + (EC) * 6 + 2 * ((NC) + 1) + 4 * ((NC) + (LC) + 2) + ((LC) + 1))
+#define CW_POA_SLAB_BYTES ((CW_POA_HC * 2 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + 15) / 16 * 16)
+#define CW_POAM_SLAB_BYTES ((CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC) + 15) / 16 * 16)
+
+__device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, const unsigned long long (&acc)[6], int lane) {
+    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[base + q], acc[q]);
+}
 
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC);
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t ti = 0;
         if (lane == 0) ti = atomicAdd(&sc.ctr->next_task, 1u);
         ti = (uint32_t)__shfl((int)ti, 0);
         if (ti >= n_tasks) break;
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int16_t>(M, t, b, sc, lane);
+        if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
+        const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
+        if (lane == 0) {
+            if (rc == 2) {
+                const uint32_t bi = atomicAdd(&sc.ctr->n_mid, 1u);
+                if (bi < sc.big_cap) sc.mid_list[bi] = ti;
+                else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            } else if (rc == 3) {
+                sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
+            }
+            sc.tasks[ti].state = (uint32_t)rc;
+        }
+        cw_wave_sync();
+    }
+    poa_flush_prof(sc, 8, acc, lane);
+}
+
+/* ---- tier M: graph in LDS, DP matrix in this wave's global slab --------------------------------- */
+__global__ void __launch_bounds__(64 * CW_POAM_WAVES) cw_poa_mid_kernel(DevBatch b, DevScratch sc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t gw = blockIdx.x * CW_POAM_WAVES + wave;
+    if (gw >= sc.mid_slots) return;
+    int16_t* hslab = (int16_t*)(sc.mid_scratch + (size_t)gw * sc.mid_slab_bytes);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POAM_SLAB_BYTES, CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_HC, hslab);
+    const uint32_t n_mid = min(sc.ctr->n_mid, sc.big_cap);
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (;;) {
+        uint32_t mi = 0;
+        if (lane == 0) mi = atomicAdd(&sc.ctr->next_mid, 1u);
+        mi = (uint32_t)__shfl((int)mi, 0);
+        if (mi >= n_mid) break;
+        const uint32_t ti = sc.mid_list[mi];
+        const PoaTask t = sc.tasks[ti];
+        const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
         if (lane == 0) {
             if (rc == 2) {
                 const uint32_t bi = atomicAdd(&sc.ctr->n_big, 1u);
@@ -402,15 +505,17 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         }
         cw_wave_sync();
     }
+    poa_flush_prof(sc, 14, acc, lane);
 }
 
-/* ---- global-slab instantiation for graphs that do not fit the LDS caps -------------------------- */
+/* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch b, DevScratch sc) {
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * CW_POA_WAVES + (threadIdx.x >> 6);
     if (gw >= sc.big_slots) return;
     const PoaMem<int32_t> M = poa_carve<int32_t>(sc.big_scratch + (size_t)gw * sc.big_slab_bytes, CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC);
     const uint32_t n_big = min(sc.ctr->n_big, sc.big_cap);
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t bi = 0;
         if (lane == 0) bi = atomicAdd(&sc.ctr->next_big, 1u);
@@ -418,13 +523,14 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch 
         if (bi >= n_big) break;
         const uint32_t ti = sc.big_list[bi];
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int32_t>(M, t, b, sc, lane);
+        const int rc = poa_run<int32_t>(M, t, b, sc, lane, acc);
         if (lane == 0) {
             if (rc != 1) { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             sc.tasks[ti].state = (uint32_t)(rc == 1 ? 1 : 3);
         }
         cw_wave_sync();
     }
+    poa_flush_prof(sc, 19, acc, lane);
 }
 
 #endif

@@ -95,6 +95,7 @@ def load_library():
     lib.cw_run_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_void_p]
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
     lib.cw_synth_sizes.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -266,6 +267,12 @@ class Engine:
         n = C.c_int()
         _check(self.lib, self.lib.cw_last_timings(self.handle, ms, names, 8, C.byref(n)), "cw_last_timings")
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def profile(self):
+        c = np.zeros(10, np.uint32)
+        p = np.zeros(24, np.uint64)
+        _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
+        return c, p
 
     def win_info(self, n_windows):
         a = np.zeros((n_windows, 16), np.uint32)
