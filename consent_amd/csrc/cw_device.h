@@ -140,14 +140,24 @@ __device__ __forceinline__ int cw_wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-/* inclusive prefix max over the 64 lanes */
-__device__ __forceinline__ int cw_wave_scan_max(int v, int lane) {
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v = max(v, t);
-    }
+/* DPP controls (gfx9 family): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+ * With bound_ctrl = false a lane without a source keeps `old`, which is the identity of the reduction. */
+#define CW_DPP(old, src, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xF, false)
+
+/* inclusive prefix max over the 64 lanes: 4 row shifts + 2 row broadcasts, all VALU (no LDS crossbar) */
+__device__ __forceinline__ int cw_wave_scan_max(int v, int /*lane*/) {
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x111, 0xF));
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x112, 0xF));
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x114, 0xF));
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x118, 0xF));
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x142, 0xA));
+    v = max(v, CW_DPP(CW_NEG * 2, v, 0x143, 0xC));
     return v;
 }
+/* lane l receives v of lane l-1; lane 0 receives `fill` */
+__device__ __forceinline__ int cw_wave_shr1(int v, int fill) { return CW_DPP(fill, v, 0x138, 0xF); }
+/* value of a fixed lane as a wave-uniform scalar */
+__device__ __forceinline__ int cw_lane_value(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int cw_bcast(int v, int src) { return __shfl(v, src); }
 
 #endif

@@ -365,8 +365,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 if ((uint32_t)a + 1u + (uint32_t)(wave * 64) < A) { /* wave-uniform: this wave owns at least one b */
                     if (bb < A) {
                         uint32_t cnt = 0;
+                        const uint16_t* pa_col = P + (uint32_t)a;
+                        const uint16_t* pb_col = P + bb;
+#pragma unroll 8
                         for (uint32_t s = 0; s < N; ++s) {
-                            const uint32_t pa = P[s * Ap + (uint32_t)a], pb = P[s * Ap + bb];
+                            const uint32_t pa = pa_col[s * Ap], pb = pb_col[s * Ap];
                             cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
                         }
                         if ((int)cnt >= sup_min)

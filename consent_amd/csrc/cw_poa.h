@@ -179,9 +179,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     int up0, up1, dg0, dg1;
                     if (prow == i - 1) {
                         up0 = prev0; up1 = prev1;
-                        const int sh0 = __shfl_up(prev0, 1), sh1 = __shfl_up(prev1, 1), last0 = __shfl(prev0, 63);
-                        dg0 = lane ? sh0 : CW_NEG;
-                        dg1 = lane ? sh1 : last0;
+                        dg0 = cw_wave_shr1(prev0, CW_NEG);
+                        dg1 = cw_wave_shr1(prev1, cw_lane_value(prev0, 63));
                     } else {
                         cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
                         const int pr = prow * cols;
@@ -200,7 +199,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 if (two) {
                     int w1 = act1 ? v1 - j1 * G : CW_NEG;
                     w1 = cw_wave_scan_max(w1, lane);
-                    w1 = max(w1, __shfl(w0, 63));
+                    w1 = max(w1, cw_lane_value(w0, 63));
                     prev1 = w1 + j1 * G;
                     if (act1) M.H[i * cols + j1] = (HT)prev1;
                 }
@@ -234,7 +233,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 int wv = act ? v - j * G : CW_NEG;
                 wv = cw_wave_scan_max(wv, lane);
                 wv = max(wv, carry);
-                carry = __shfl(wv, 63);
+                carry = cw_lane_value(wv, 63);
                 if (act) M.H[i * cols + j] = (HT)(wv + j * G);
             }
             cw_wave_sync();

@@ -1,0 +1,78 @@
+"""The C-ABI library loads and exports every symbol include/consent_amd.h declares (no compute, no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "consent_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("cw_create", "cw_destroy", "cw_run", "cw_run_device", "cw_strerror", "cw_version", "cw_pack_sequence"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import consent_amd
+
+    lib = consent_amd.load_library()
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"libconsent_amd.so does not export {s}"
+    assert b"consent_amd" in lib.cw_version()
+    assert lib.cw_strerror(-4).decode().startswith("at least one window")
+
+
+def test_invalid_arguments_are_reported_not_crashed():
+    import consent_amd as ca
+
+    lib = ca.load_library()
+    h = ctypes.c_void_p()
+    assert lib.cw_create(None, 0, ctypes.byref(h)) == -1
+    bad = ca.Params(17, 4, 8, 2, 20)  # k out of range for the in-LDS count table
+    assert lib.cw_create(ctypes.byref(bad), 0, ctypes.byref(h)) == -1
+    bad = ca.Params(9, 0, 8, 2, 20)
+    assert lib.cw_create(ctypes.byref(bad), 0, ctypes.byref(h)) == -1
+
+
+def test_no_device_is_a_loud_error_on_cpu_box():
+    import torch
+
+    import consent_amd as ca
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ca.EngineError):
+        ca.Engine(ca.Params(9, 4, 8, 2, 20))  # no silent CPU fallback
+
+
+def test_pack_roundtrip_and_alphabet():
+    import numpy as np
+
+    import consent_amd as ca
+
+    piles = [["ACGTACGTACGTACGTAC", "TTTT", "ACGNNACG"], ["G" * 33]]
+    hb = ca.pack_piles(piles)
+    assert hb.pile(0) == ["ACGTACGTACGTACGTAC", "TTTT", "ACGTTACG"]  # N -> T (reference utils.cpp:28)
+    assert hb.pile(1) == ["G" * 33]
+    # MSB-first packing: first base in the top two bits
+    assert int(hb.bases[0]) >> 30 == 0 and (int(hb.bases[0]) >> 28) & 3 == 1
+    assert np.all(hb.seq_word_off[1:] > hb.seq_word_off[:-1])
+
+
+def test_product_package_never_imports_the_oracle():
+    import re
+
+    pat = re.compile(r"liboracle|import\s+oracle|from\s+oracle|#include\s+\"[^\"]*oracle/|oracle_lib")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "consent_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(src), f"{f} reaches into oracle/"

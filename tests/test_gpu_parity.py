@@ -1,0 +1,224 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI, against the CPU oracle and the golden vectors.
+Bit-exact: consensus bytes (including case), per-window status, ascending solid k-mer set."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import consent_amd as ca
+import oracle_lib
+from consent_amd.engine import synth_host
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CS = json.load(open(os.path.join(HERE, "golden", "consensus_small.json")))
+
+
+@pytest.fixture(scope="module")
+def engines():
+    cache = {}
+
+    def get(*prm):
+        if prm not in cache:
+            cache[prm] = ca.Engine(ca.Params(*prm))
+        return cache[prm]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def assert_same(got, exp, n, what=""):
+    for w in range(n):
+        assert int(got.status[w]) == int(exp.status[w]), f"{what} window {w}: status {got.status[w]} != {exp.status[w]}"
+        assert got.consensus(w) == exp.consensus(w), f"{what} window {w}: consensus differs"
+        assert np.array_equal(got.solid_kmers(w), exp.solid_kmers(w)), f"{what} window {w}: solid set differs"
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def mutate(rng, s, rate):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < rate * 0.3:
+            continue
+        if x < rate * 0.6:
+            out.append(rng.choice("ACGT"))
+        out.append(rng.choice("ACGT") if x < rate else c)
+    return "".join(out)
+
+
+def test_loaded_library_is_the_hip_engine(engines):
+    e = engines(9, 4, 8, 2, 20)
+    assert b"gfx950" in e.lib.cw_version()
+
+
+@pytest.mark.parametrize("i", range(len(CS["cases"])))
+def test_golden_vectors(engines, i):
+    c = CS["cases"][i]
+    got = engines(*c["params"]).run(ca.pack_piles([c["pile"]]))
+    assert int(got.status[0]) == c["status"]
+    assert got.consensus(0) == c["consensus"]
+    assert [int(x) for x in got.solid_kmers(0)] == c["solid"]
+
+
+@pytest.mark.parametrize("depth,max_msa,n", [(30, 20, 96), (150, 150, 24), (8, 20, 64), (60, 10, 32)])
+def test_synthetic_pacbio_matches_oracle(engines, depth, max_msa, n):
+    prm = (9, 4, 8, 2, max_msa)
+    hb = synth_host(ca.SynthSpec.pacbio(n, depth))
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+    assert_same(got, exp, n, f"pacbio d{depth}")
+
+
+def test_synthetic_ont_profile_matches_oracle(engines):
+    prm = (9, 4, 8, 2, 50)
+    hb = synth_host(ca.SynthSpec.ont(48, 40))
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+    assert_same(got, exp, 48, "ont")
+
+
+@pytest.mark.parametrize("k,solid,common,min_anchors", [(5, 2, 3, 2), (7, 3, 6, 3), (8, 4, 8, 2), (9, 1, 1, 2), (9, 16, 8, 2), (9, 4, 0, 2), (6, 4, 8, 40)])
+def test_other_parameters(engines, k, solid, common, min_anchors):
+    prm = (k, solid, common, min_anchors, 12)
+    hb = synth_host(ca.SynthSpec.pacbio(24, 18, window_len=200))
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+    assert_same(got, exp, 24, f"k={k}")
+
+
+def test_edge_piles(engines):
+    rng = random.Random(11)
+    truth = rand_seq(rng, 300)
+    piles = [
+        [truth[:200]],                                                  # template only
+        [truth[:200]] * 12,                                             # clean, every segment identical
+        [truth[:5]],                                                    # template shorter than k
+        [truth[:200], "ACG", "A", truth[50:58], truth[:9]],             # members shorter than k (kept by the ABI, ignored by k-mers)
+        [rand_seq(rng, 200) for _ in range(10)],                        # unrelated sequences -> template fallback
+        ["A" * 150] * 8,                                                # homopolymer: every k-mer repeated -> no anchors
+        ["AC" * 80] * 5 + ["AC" * 70 + "G" + "AC" * 9] * 2,             # dinucleotide repeat
+        [mutate(rng, truth[:250], 0.02) for _ in range(40)],            # high identity, deep
+        [mutate(rng, truth[:250], 0.25) for _ in range(25)],            # very noisy
+        [truth[:250]] + [mutate(rng, truth[a : a + 60], 0.05) for a in range(0, 190, 7)],   # short tiles only
+        [truth[:180] + truth[60:240]] + [mutate(rng, truth[:180] + truth[60:240], 0.05) for _ in range(14)],  # tandem repeat inside the window
+    ]
+    prm = (9, 4, 8, 2, 20)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb)
+    assert_same(got, exp, len(piles), "edge")
+    assert int(got.status[4]) == ca.WIN_TEMPLATE and got.consensus(4) == piles[4][0]
+
+
+def test_long_and_outlier_segments_exercise_all_tiers(engines):
+    """Few anchors -> segments of hundreds of bases; graphs that outgrow the LDS tiers must give identical results."""
+    rng = random.Random(13)
+    truth = rand_seq(rng, 700)
+    piles = []
+    for depth, rate in ((6, 0.18), (10, 0.22), (16, 0.2)):
+        piles.append([mutate(rng, truth[:600], rate) for _ in range(depth)])
+    # one wildly longer member in the middle of the pile
+    piles.append([mutate(rng, truth[:300], 0.1) for _ in range(6)] + [truth[:150] + rand_seq(rng, 380) + truth[150:300]] + [mutate(rng, truth[:300], 0.1) for _ in range(6)])
+    prm = (9, 4, 8, 2, 30)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb)
+    assert_same(got, exp, len(piles), "tiers")
+
+
+def test_empty_batch_and_capacity_overflow(engines):
+    e = engines(9, 4, 8, 2, 20)
+    lib = e.lib
+    import ctypes as C
+
+    from consent_amd.engine import Batch, Result, _result_struct, alloc_results
+
+    b = Batch(0, 0, 0, None, None, None, None)
+    r = Result(None, None, None, None, None, None, None)
+    assert lib.cw_run(e.handle, C.byref(b), C.byref(r)) == -1  # result arrays are mandatory
+    hb = synth_host(ca.SynthSpec.pacbio(3, 10))
+    res = alloc_results(hb, True, 4, 9)
+    res.cons_off[:] = np.array([0, 10, 2000, 4000], np.uint64)  # window 0 gets 10 bytes only
+    rc = lib.cw_run(e.handle, C.byref(hb.c_struct()), C.byref(_result_struct(res)))
+    assert rc == -4
+    assert int(res.status[0]) == ca.WIN_OVERFLOW and int(res.cons_len[0]) == 0
+    exp, _ = oracle_lib.oracle_run(ca.Params(9, 4, 8, 2, 20), hb)
+    for w in (1, 2):
+        assert res.consensus(w) == exp.consensus(w)
+
+
+def test_results_do_not_depend_on_batch_composition(engines):
+    """Window results are a function of the window only: alone, in a batch, shuffled, or split across two runs."""
+    prm = (9, 4, 8, 2, 20)
+    e = engines(*prm)
+    hb = synth_host(ca.SynthSpec.pacbio(40, 20))
+    full = e.run(hb)
+    piles = [hb.pile(w) for w in range(40)]
+    order = list(range(40))
+    random.Random(3).shuffle(order)
+    shuf = e.run(ca.pack_piles([piles[i] for i in order]))
+    for pos, w in enumerate(order):
+        assert shuf.consensus(pos) == full.consensus(w)
+        assert np.array_equal(shuf.solid_kmers(pos), full.solid_kmers(w))
+    a = e.run(ca.pack_piles(piles[:13]))
+    b = e.run(ca.pack_piles(piles[13:]))
+    for w in range(40):
+        part, idx = (a, w) if w < 13 else (b, w - 13)
+        assert part.consensus(idx) == full.consensus(w)
+    again = e.run(hb)
+    for w in range(40):
+        assert again.consensus(w) == full.consensus(w)
+
+
+def test_mirror_of_the_reference_operator(engines):
+    """computeConsensusReadCorrection-shaped call (reference correctionMSA.h:8)."""
+    hb = synth_host(ca.SynthSpec.pacbio(2, 12))
+    piles = [hb.pile(0), hb.pile(1)]
+    out = ca.compute_consensus_read_correction("read1", piles, (0, 499), 3, 9, 8, 2, 4, 500, 20, "")
+    exp, _ = oracle_lib.oracle_run(ca.Params(9, 4, 8, 2, 20), hb)
+    for w, (cons, solid) in enumerate(out):
+        assert cons == exp.consensus(w) and np.array_equal(solid, exp.solid_kmers(w))
+
+
+def test_full_size_batch_properties(engines):
+    """BASELINE configs[1] at its bench size (16384 windows, depth 30): properties that need no oracle run --
+    every window finishes, consensus is near the truth length, and a checksum over the whole batch is reproducible
+    and equals the checksum of two half-batches; a 256-window sample is compared with the oracle."""
+    import zlib
+
+    prm = (9, 4, 8, 2, 20)
+    e = engines(*prm)
+    n = 16384
+    hb = synth_host(ca.SynthSpec.pacbio(n, 30))
+    r1 = e.run(hb, want_solid=False)
+    assert int((r1.status == ca.WIN_OVERFLOW).sum()) == 0
+    lens = r1.cons_len.astype(np.int64)
+    assert 450 < np.median(lens) < 550
+
+    def digest(res, count):
+        crc = 0
+        for w in range(count):
+            crc = zlib.crc32(res.consensus(w).encode(), crc)
+        return crc
+
+    r2 = e.run(hb, want_solid=False)
+    assert digest(r1, n) == digest(r2, n)
+    ha = synth_host(ca.SynthSpec.pacbio(n // 2, 30))
+    hb2 = synth_host(ca.SynthSpec.pacbio(n // 2, 30, first_window=n // 2))
+    ra, rb = e.run(ha, want_solid=False), e.run(hb2, want_solid=False)
+    crc = 0
+    for res in (ra, rb):
+        for w in range(n // 2):
+            crc = zlib.crc32(res.consensus(w).encode(), crc)
+    assert crc == digest(r1, n)
+    sample = synth_host(ca.SynthSpec.pacbio(256, 30, first_window=9000))
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), sample, threads=os.cpu_count() or 1)
+    for w in range(256):
+        assert r1.consensus(9000 + w) == exp.consensus(w)
