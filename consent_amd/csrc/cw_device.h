@@ -145,13 +145,23 @@ __device__ __forceinline__ int cw_wave_sum(int v) {
 #define CW_DPP(old, src, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xF, false)
 
 /* inclusive prefix max over the 64 lanes: 4 row shifts + 2 row broadcasts, all VALU (no LDS crossbar) */
-__device__ __forceinline__ int cw_wave_scan_max(int v, int /*lane*/) {
+__device__ __forceinline__ int cw_wave_scan_max(int v) {
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x111, 0xF));
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x112, 0xF));
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x114, 0xF));
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x118, 0xF));
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x142, 0xA));
     v = max(v, CW_DPP(CW_NEG * 2, v, 0x143, 0xC));
+    return v;
+}
+/* inclusive prefix sum over the 64 lanes (same DPP ladder, identity 0) */
+__device__ __forceinline__ int cw_wave_scan_add(int v) {
+    v += CW_DPP(0, v, 0x111, 0xF);
+    v += CW_DPP(0, v, 0x112, 0xF);
+    v += CW_DPP(0, v, 0x114, 0xF);
+    v += CW_DPP(0, v, 0x118, 0xF);
+    v += CW_DPP(0, v, 0x142, 0xA);
+    v += CW_DPP(0, v, 0x143, 0xC);
     return v;
 }
 /* lane l receives v of lane l-1; lane 0 receives `fill` */

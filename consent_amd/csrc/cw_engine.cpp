@@ -18,9 +18,7 @@ namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t big_slab_bytes() {
-    size_t b = (size_t)CW_POAB_HC * 4;
-    b += (size_t)CW_POAB_NC * 21 + (size_t)CW_POAB_EC * 6 + 2 * (CW_POAB_NC + 1) + 4 * (CW_POAB_NC + CW_POAB_LC + 2) + (CW_POAB_LC + 1);
-    return align_up(b, 256);
+    return align_up((size_t)CW_POAB_HC * 4 + CW_POA_GRAPH_BYTES(CW_POAB_NC, CW_POAB_EC, CW_POAB_LC), 256);
 }
 
 struct ScratchPlan {

@@ -2,20 +2,25 @@
  * cw_poa.h -- partial-order alignment of one segment pile per wavefront (A4d).
  *
  * One 64-lane wave owns one task from the list the index kernel emitted.  Same code, three memory tiers:
- *   S (cw_poa_kernel)      graph + DP matrix in LDS            small segments (most tasks)
- *   M (cw_poa_mid_kernel)  graph in LDS, matrix in an L2-resident per-wave slab   long segments
- *   G (cw_poa_big_kernel)  everything in a per-wave global slab                   the rare huge graph
+ *   S (cw_poa_kernel)      graph + DP matrix in LDS                                 small segments (most tasks)
+ *   M (cw_poa_mid_kernel)  graph in LDS, matrix in an L2-resident per-wave slab      long segments
+ *   G (cw_poa_big_kernel)  everything in a per-wave global slab                      the rare huge graph
  * A task that outgrows its tier is handed to the next one and redone there from scratch.
  *
- *   DP fill     lanes = sequence positions (columns); rows = graph nodes in rank order; the horizontal
- *               gap recurrence H[i][j] = max(H[i][j], H[i][j-1]+g) is a wave-level inclusive prefix-max
- *               of H[i][j] - j*g (linear gaps), so a row costs one pass regardless of its length.
- *   traceback   wave-uniform walk, preference order of cw_policy.h (diagonal, vertical, horizontal).
- *   graph edit  wave-uniform; rank order maintained by insertion (cw_policy.h "rank order"), the shift of
- *               the rank arrays is done by all lanes.
- *   consensus   column-majority vote, one lane per rank, ordered compaction by ballot.
- * All arithmetic is integer; int16 cells in LDS (|score| <= 8*(nodes+len) < 2^15 under the LDS caps), int32
- * cells in the global slab.
+ * Per member of the pile (policies: include/cw_policy.h):
+ *   row metadata  one lane per rank: base, predecessor rows (first one inline, the rest in a CSR list)
+ *   DP fill       lanes = sequence positions; rows = nodes in rank order; the horizontal gap recurrence
+ *                 H[i][j] = max(H[i][j], H[i][j-1]+g) is a DPP inclusive prefix-max of H[i][j]-j*g (linear gaps);
+ *                 rows of <= 128 columns keep the previous row in registers so a chain of nodes never waits on
+ *                 memory; the next row's metadata is fetched while the current row computes
+ *   traceback     wave-uniform walk (diagonal, then vertical, then horizontal); all three candidate cells and
+ *                 the predecessor's metadata are requested together, one memory round trip per step
+ *   merge         one lane per sequence position: resolve node / sibling / fresh node, assign fresh ids and
+ *                 edge ids by ballot prefix, place fresh nodes in the rank order with one prefix sum
+ *                 (equivalent to the sequential insertions of cw_policy.h "rank order")
+ *   consensus     column-majority vote, one lane per rank, ordered compaction by ballot
+ * All arithmetic is integer; int16 cells in tiers S and M (|score| <= 8*(nodes+len) < 2^15 under their caps),
+ * int32 cells in tier G.
  */
 #ifndef CW_POA_H
 #define CW_POA_H
@@ -27,6 +32,7 @@
 #define CW_POA_EC 448   /* edges            */
 #define CW_POA_LC 255   /* member length    */
 #define CW_POA_HC 4096  /* DP cells (int16) */
+#define CW_POA_WAVES 4
 /* tier M: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2-resident */
 #define CW_POAM_NC 512
 #define CW_POAM_EC 1280
@@ -39,37 +45,36 @@
 #define CW_POAB_LC 1023
 #define CW_POAB_HC ((CW_POAB_NC + 1) * (CW_POAB_LC + 1))
 
-#define CW_POA_WAVES 4
+/* bytes of the graph part of a slab (everything but H) */
+#define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
+#define CW_POAM_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC))
 
 template <typename HT>
 struct PoaMem {
     HT* H;
-    uint8_t* nbase;     /* node -> base code                           */
-    uint16_t* ncov;     /* node -> sequences through it                */
-    uint8_t* nalc;      /* node -> number of aligned nodes (0..3)      */
-    uint16_t* nal;      /* node -> 3 aligned node ids                  */
-    uint16_t* in_head;  /* node -> first in-edge, CW_NONE16 if none    */
+    uint32_t* rmeta;    /* rank -> base | n_pred << 2 | csr offset << 16 (n_pred counts the virtual start as 1) */
+    uint16_t* rpred0;   /* rank -> DP row of its first predecessor (0 = virtual start)                           */
+    uint16_t* plist;    /* predecessor DP rows in in-edge order (CSR); doubles as a u32 histogram during merges  */
+    uint16_t* ncov;     /* node -> sequences through it                                                          */
+    uint16_t* nal;      /* node -> 3 aligned node ids                                                            */
+    uint16_t* in_head;  /* node -> first in-edge, CW_NONE16 if none                                              */
     uint16_t* in_tail;
     uint16_t* indeg;
-    uint8_t* has_out;
-    uint16_t* efrom;    /* edge -> source node                         */
-    uint16_t* enext;    /* edge -> next in-edge of the same target     */
-    uint16_t* r2n;      /* rank -> node                                */
+    uint16_t* efrom;    /* edge -> source node                                                                   */
+    uint16_t* enext;    /* edge -> next in-edge of the same target                                               */
+    uint16_t* r2n;      /* rank -> node                                                                          */
     uint16_t* n2r;
-    uint16_t* poff;     /* rank -> first entry of its predecessor rows */
-    uint16_t* plist;    /* predecessor DP rows (rank+1), in-edge order */
-    uint16_t* pnode;    /* traceback path (reversed)                   */
-    uint16_t* pseq;
-    uint8_t* sq;        /* current member, base codes                  */
+    uint16_t* rtmp;     /* new rank order while fresh nodes are being placed                                     */
+    uint16_t* seqrank;  /* sequence position -> rank of the node it is aligned to, CW_NONE16 for an insertion    */
+    uint16_t* pcur;     /* sequence position -> node it resolves to                                              */
+    uint16_t* pat;      /* sequence position -> rank slot (old order) a fresh node goes in front of              */
+    uint8_t* nbase;     /* node -> base code                                                                     */
+    uint8_t* nalc;      /* node -> number of aligned nodes (0..3)                                                */
+    uint8_t* has_out;
+    uint8_t* sq;        /* current member, base codes                                                            */
     uint32_t n_cap, e_cap, l_cap, h_cap;
 };
-
-template <typename HT>
-__device__ __forceinline__ size_t poa_mem_bytes(uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc) {
-    size_t b = (size_t)hc * sizeof(HT);
-    b += nc * (1 + 2 + 1 + 6 + 2 + 2 + 2 + 1 + 2 + 2) + ec * 6 + 2 * (nc + 1) + 4 * (nc + lc + 2) + (lc + 1);
-    return (b + 15) & ~(size_t)15;
-}
 
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, HT* h_ext = nullptr) {
@@ -77,6 +82,11 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     uint8_t* p = base;
     if (h_ext) M.H = h_ext;
     else { M.H = (HT*)p; p += (size_t)hc * sizeof(HT); }
+    M.rmeta = (uint32_t*)p; p += 4 * nc;
+    M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
+    M.efrom = (uint16_t*)p; p += 2 * ec;
+    M.enext = (uint16_t*)p; p += 2 * ec;
+    M.rpred0 = (uint16_t*)p; p += 2 * nc;
     M.ncov = (uint16_t*)p; p += 2 * nc;
     M.nal = (uint16_t*)p; p += 6 * nc;
     M.in_head = (uint16_t*)p; p += 2 * nc;
@@ -84,12 +94,10 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.indeg = (uint16_t*)p; p += 2 * nc;
     M.r2n = (uint16_t*)p; p += 2 * nc;
     M.n2r = (uint16_t*)p; p += 2 * nc;
-    M.efrom = (uint16_t*)p; p += 2 * ec;
-    M.enext = (uint16_t*)p; p += 2 * ec;
-    M.plist = (uint16_t*)p; p += 2 * ec;
-    M.poff = (uint16_t*)p; p += 2 * (nc + 1);
-    M.pnode = (uint16_t*)p; p += 2 * (nc + lc + 2);
-    M.pseq = (uint16_t*)p; p += 2 * (nc + lc + 2);
+    M.rtmp = (uint16_t*)p; p += 2 * nc;
+    M.seqrank = (uint16_t*)p; p += 2 * (lc + 1);
+    M.pcur = (uint16_t*)p; p += 2 * (lc + 1);
+    M.pat = (uint16_t*)p; p += 2 * (lc + 1);
     M.nbase = p; p += nc;
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
@@ -98,7 +106,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     return M;
 }
 
-/* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded. */
+/* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
 template <typename HT>
 __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
                        unsigned long long (&acc)[6]) {
@@ -106,7 +114,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
 #define POA_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
-    bool csr_ok = false;
+    bool meta_ok = false;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
@@ -127,55 +136,61 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 M.r2n[j] = (uint16_t)j; M.n2r[j] = (uint16_t)j;
                 if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; }
             }
-            n = L; ne = L - 1; tpl_nodes = L; csr_ok = false;
+            n = L; ne = L - 1; tpl_nodes = L; meta_ok = false;
             cw_wave_sync();
             continue;
         }
         const int cols = L + 1;
         if ((uint32_t)((n + 1) * cols) > M.h_cap) return 2;
 
-        /* ---- predecessor rows in CSR form (parallel over ranks) ---- */
-        if (!csr_ok) {
+        /* ---- per-rank metadata (parallel over ranks) ---- */
+        if (!meta_ok) {
             int run = 0;
             for (int r0 = 0; r0 < n; r0 += 64) {
                 const int r = r0 + lane;
                 const int node = r < n ? M.r2n[r] : 0;
                 const int d = r < n ? M.indeg[node] : 0;
-                int inc = d;
-                for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+                const int inc = cw_wave_scan_add(d);
                 const int off = run + inc - d;
                 if (r < n) {
-                    M.poff[r] = (uint16_t)off;
-                    int q = off;
-                    for (uint32_t e = M.in_head[node]; e != CW_NONE16; e = M.enext[e]) M.plist[q++] = (uint16_t)(M.n2r[M.efrom[e]] + 1);
+                    int q = off, first = 0;
+                    for (uint32_t e = M.in_head[node]; e != CW_NONE16; e = M.enext[e]) {
+                        const int pr = M.n2r[M.efrom[e]] + 1;
+                        if (q == off) first = pr;
+                        M.plist[q++] = (uint16_t)pr;
+                    }
+                    M.rpred0[r] = (uint16_t)first;
+                    M.rmeta[r] = (uint32_t)M.nbase[node] | ((uint32_t)(d ? d : 1) << 2) | ((uint32_t)off << 16);
                 }
-                run += __shfl(inc, 63);
+                run += cw_lane_value(inc, 63);
             }
-            if (lane == 0) M.poff[n] = (uint16_t)run;
-            csr_ok = true;
+            meta_ok = true;
             cw_wave_sync();
         }
-
         POA_PROF(0);
+
         /* ---- DP fill ---- */
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
+        for (int j = lane; j < L; j += 64) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
         if (cols <= 128) {
-            /* rows of <= 2 chunks: the previous row stays in registers, so a chain of nodes never waits on memory */
             const bool two = cols > 64;
             const int j0 = lane, j1 = 64 + lane;
             const bool act0 = j0 < cols, act1 = two && j1 < cols;
             const int s0q = (j0 > 0 && act0) ? (int)M.sq[j0 - 1] : -1, s1q = act1 ? (int)M.sq[j1 - 1] : -1;
             int prev0 = j0 * G, prev1 = j1 * G; /* row 0 */
+            uint32_t meta_n = M.rmeta[0];
+            uint32_t pr0_n = M.rpred0[0];
             for (int r = 0; r < n; ++r) {
                 const int i = r + 1;
-                const int base = M.nbase[M.r2n[r]];
-                const int p0 = M.poff[r], p1 = M.poff[r + 1];
+                const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
+                const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
+                if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; } /* in flight while this row computes */
+                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
                 const int sc0 = (s0q == base) ? MS : XS, sc1 = (s1q == base) ? MS : XS;
                 int v0 = CW_NEG, v1 = CW_NEG;
-                const int np = (p0 == p1) ? 1 : p1 - p0;
                 for (int q = 0; q < np; ++q) {
-                    const int prow = (p0 == p1) ? 0 : (int)M.plist[p0 + q];
+                    const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
                     int up0, up1, dg0, dg1;
                     if (prow == i - 1) {
                         up0 = prev0; up1 = prev1;
@@ -193,53 +208,49 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     v1 = max(v1, max(dg1 + sc1, up1 + G));
                 }
                 int w0 = act0 ? v0 - j0 * G : CW_NEG;
-                w0 = cw_wave_scan_max(w0, lane);
+                w0 = cw_wave_scan_max(w0);
                 prev0 = w0 + j0 * G;
                 if (act0) M.H[i * cols + j0] = (HT)prev0;
                 if (two) {
                     int w1 = act1 ? v1 - j1 * G : CW_NEG;
-                    w1 = cw_wave_scan_max(w1, lane);
+                    w1 = cw_wave_scan_max(w1);
                     w1 = max(w1, cw_lane_value(w0, 63));
                     prev1 = w1 + j1 * G;
                     if (act1) M.H[i * cols + j1] = (HT)prev1;
                 }
             }
             cw_wave_sync();
-        } else
-        for (int r = 0; r < n; ++r) {
-            const int i = r + 1;
-            const int base = M.nbase[M.r2n[r]];
-            const int p0 = M.poff[r], p1 = M.poff[r + 1];
-            int carry = CW_NEG;
-            for (int c0 = 0; c0 < cols; c0 += 64) {
-                const int j = c0 + lane;
-                const bool act = j < cols;
-                int v = CW_NEG;
-                if (act) {
-                    const int s = (j > 0 && M.sq[j - 1] == base) ? MS : XS;
-                    if (p0 == p1) {
-                        const int up = M.H[j];
-                        const int dg = j > 0 ? (int)M.H[j - 1] : CW_NEG;
-                        v = max(dg + s, up + G);
-                    } else {
-                        for (int q = p0; q < p1; ++q) {
-                            const int pr = M.plist[q] * cols;
+        } else {
+            for (int r = 0; r < n; ++r) {
+                const int i = r + 1;
+                const uint32_t meta = M.rmeta[r];
+                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+                const int pr0 = M.rpred0[r];
+                int carry = CW_NEG;
+                for (int c0 = 0; c0 < cols; c0 += 64) {
+                    const int j = c0 + lane;
+                    const bool act = j < cols;
+                    int v = CW_NEG;
+                    if (act) {
+                        const int s = (j > 0 && M.sq[j - 1] == base) ? MS : XS;
+                        for (int q = 0; q < np; ++q) {
+                            const int pr = ((np == 1) ? pr0 : (int)M.plist[off + q]) * cols;
                             const int up = M.H[pr + j];
                             const int dg = j > 0 ? (int)M.H[pr + j - 1] : CW_NEG;
                             v = max(v, max(dg + s, up + G));
                         }
                     }
+                    int wv = act ? v - j * G : CW_NEG;
+                    wv = cw_wave_scan_max(wv);
+                    wv = max(wv, carry);
+                    carry = cw_lane_value(wv, 63);
+                    if (act) M.H[i * cols + j] = (HT)(wv + j * G);
                 }
-                int wv = act ? v - j * G : CW_NEG;
-                wv = cw_wave_scan_max(wv, lane);
-                wv = max(wv, carry);
-                carry = cw_lane_value(wv, 63);
-                if (act) M.H[i * cols + j] = (HT)(wv + j * G);
+                cw_wave_sync();
             }
-            cw_wave_sync();
         }
-
         POA_PROF(1);
+
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
         int bi;
         {
@@ -256,104 +267,126 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             bi = br + 1;
         }
 
-        /* ---- traceback (wave-uniform) ---- */
-        int plen = 0;
+        /* ---- traceback (wave-uniform); records seqrank[j] = rank aligned to sequence position j ---- */
         {
             int i = bi, j = L;
-            while (!(i == 0 && j == 0)) {
-                const int h = M.H[i * cols + j];
-                int pi = i, pj = j;
-                bool found = false;
-                int node = 0, p0 = 0, p1 = 0;
-                if (i != 0) { node = M.r2n[i - 1]; p0 = M.poff[i - 1]; p1 = M.poff[i]; }
-                if (i != 0 && j != 0) {
-                    const int s = (M.sq[j - 1] == M.nbase[node]) ? MS : XS;
-                    if (p0 == p1) { if (h == (int)M.H[j - 1] + s) { pi = 0; pj = j - 1; found = true; } }
-                    else for (int q = p0; q < p1 && !found; ++q) {
-                        const int pr = M.plist[q];
-                        if (h == (int)M.H[pr * cols + j - 1] + s) { pi = pr; pj = j - 1; found = true; }
+            int h = M.H[i * cols + j];
+            uint32_t meta = M.rmeta[i - 1];
+            int pr0 = M.rpred0[i - 1];
+            while (i > 0) {
+                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+                if (np == 1) {
+                    /* every candidate cell and the predecessor's metadata in one round trip */
+                    const int a = j > 0 ? (int)M.H[pr0 * cols + j - 1] : 0;
+                    const int bb = (int)M.H[pr0 * cols + j];
+                    const int c = j > 0 ? (int)M.H[i * cols + j - 1] : 0;
+                    const uint32_t metaP = pr0 > 0 ? M.rmeta[pr0 - 1] : 0u;
+                    const int p0P = pr0 > 0 ? (int)M.rpred0[pr0 - 1] : 0;
+                    const int s = (j > 0 && (int)M.sq[j - 1] == base) ? MS : XS;
+                    if (j > 0 && h == a + s) {
+                        if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                        i = pr0; j--; h = a; meta = metaP; pr0 = p0P;
+                    } else if (h == bb + G) {
+                        i = pr0; h = bb; meta = metaP; pr0 = p0P;
+                    } else if (j > 0 && h == c + G) {
+                        j--; h = c;
+                    } else {
+                        return 3; /* cannot happen: the matrix is self-consistent */
                     }
-                }
-                if (!found && i != 0) {
-                    if (p0 == p1) { if (h == (int)M.H[j] + G) { pi = 0; pj = j; found = true; } }
-                    else for (int q = p0; q < p1 && !found; ++q) {
-                        const int pr = M.plist[q];
-                        if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                } else {
+                    int pi = i, pj = j, nh = 0;
+                    bool found = false;
+                    if (j != 0) {
+                        const int s = ((int)M.sq[j - 1] == base) ? MS : XS;
+                        for (int q = 0; q < np && !found; ++q) {
+                            const int pr = M.plist[off + q];
+                            const int x = M.H[pr * cols + j - 1];
+                            if (h == x + s) { pi = pr; pj = j - 1; nh = x; found = true; }
+                        }
                     }
+                    for (int q = 0; q < np && !found; ++q) {
+                        const int pr = M.plist[off + q];
+                        const int x = M.H[pr * cols + j];
+                        if (h == x + G) { pi = pr; pj = j; nh = x; found = true; }
+                    }
+                    if (!found && j != 0) {
+                        const int x = M.H[i * cols + j - 1];
+                        if (h == x + G) { pi = i; pj = j - 1; nh = x; found = true; }
+                    }
+                    if (!found) return 3;
+                    if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                    if (pi != i && pi > 0) { meta = M.rmeta[pi - 1]; pr0 = M.rpred0[pi - 1]; }
+                    i = pi; j = pj; h = nh;
                 }
-                if (!found && j != 0) {
-                    if (h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
-                }
-                if (!found) return 3; /* cannot happen: the matrix is self-consistent */
-                if (lane == 0) {
-                    M.pnode[plen] = (i == pi) ? CW_NONE16 : (uint16_t)node;
-                    M.pseq[plen] = (j == pj) ? CW_NONE16 : (uint16_t)(j - 1);
-                }
-                plen++;
-                i = pi; j = pj;
             }
+            /* i == 0: the remaining sequence positions are insertions, already CW_NONE16 */
         }
         cw_wave_sync();
         POA_PROF(2);
 
-        /* ---- merge the path into the graph (wave-uniform, rank shifts by all lanes) ---- */
+        /* ---- merge the path into the graph: one lane per sequence position ---- */
         {
-            int head = -1;
-            int q_node = -1, q_idx = 0x7FFFFFFF; /* cached look-ahead of the next ranked path node */
-            for (int tix = plen - 1; tix >= 0; --tix) {
-                const uint32_t ps = M.pseq[tix];
-                if (ps == CW_NONE16) continue;
-                const uint32_t pn = M.pnode[tix];
-                const int bcode = M.sq[ps];
-                int cur = -1;
-                bool fresh = false;
-                int at = 0;
-                if (pn == CW_NONE16) {
-                    if (tix <= q_idx || q_idx == 0x7FFFFFFF) {
-                        q_node = -1; q_idx = -1;
-                        for (int u = tix - 1; u >= 0; --u)
-                            if (M.pseq[u] != CW_NONE16 && M.pnode[u] != CW_NONE16) { q_node = M.pnode[u]; q_idx = u; break; }
+            const int n_old = n;
+            const int chunks = (L + 63) >> 6;
+            /* pass A (last chunk first): resolve existing nodes, find the rank slot of fresh ones */
+            int next_rank = -1; /* rank aligned to the nearest later position that has one */
+            for (int c = chunks - 1; c >= 0; --c) {
+                const int j = c * 64 + lane;
+                const bool act = j < L;
+                const uint32_t rk = act ? M.seqrank[j] : CW_NONE16;
+                const unsigned long long has = __ballot(act && rk != CW_NONE16);
+                /* nearest later aligned position: inside this chunk if any, else carried from later chunks */
+                const unsigned long long later = has & ~(lt_mask | (1ull << lane));
+                const int later_rank = (int)(uint32_t)__shfl((int)rk, later ? (__ffsll((long long)later) - 1) : 0);
+                const int qr = later ? later_rank : next_rank;
+                const int first_rank = (int)(uint32_t)__shfl((int)rk, has ? (__ffsll((long long)has) - 1) : 0);
+                uint32_t cur = CW_NONE16, at = CW_NONE16;
+                if (act) {
+                    const int bcode = M.sq[j];
+                    if (rk != CW_NONE16) {
+                        const int pn = M.r2n[rk];
+                        if (M.nbase[pn] == bcode) cur = (uint32_t)pn;
+                        else {
+                            const int ac = M.nalc[pn];
+                            int last = (int)rk;
+                            for (int a = 0; a < ac; ++a) {
+                                const int v = M.nal[pn * 3 + a];
+                                if (M.nbase[v] == bcode) cur = (uint32_t)v;
+                                last = max(last, (int)M.n2r[v]);
+                            }
+                            if (cur == CW_NONE16) at = (uint32_t)(last + 1); /* new member of pn's column */
+                        }
+                    } else if (qr < 0) {
+                        at = (uint32_t)n_old; /* insertion with no aligned position after it: goes last */
+                    } else {
+                        /* insertion: in front of the column of the next position that is aligned to a node */
+                        const int q = M.r2n[qr];
+                        int first = qr;
+                        for (int a = 0; a < M.nalc[q]; ++a) first = min(first, (int)M.n2r[M.nal[q * 3 + a]]);
+                        at = (uint32_t)first;
                     }
-                    if (q_node < 0) at = n;
-                    else {
-                        at = M.n2r[q_node];
-                        for (int a = 0; a < M.nalc[q_node]; ++a) at = min(at, (int)M.n2r[M.nal[q_node * 3 + a]]);
-                    }
-                    fresh = true;
-                } else if (M.nbase[pn] == bcode) {
-                    cur = (int)pn;
-                } else {
-                    const int ac = M.nalc[pn];
-                    for (int a = 0; a < ac; ++a) {
-                        const int v = M.nal[pn * 3 + a];
-                        if (M.nbase[v] == bcode) { cur = v; break; }
-                    }
-                    if (cur < 0) {
-                        at = M.n2r[pn];
-                        for (int a = 0; a < ac; ++a) at = max(at, (int)M.n2r[M.nal[pn * 3 + a]]);
-                        at += 1;
-                        fresh = true;
-                    }
+                    M.pcur[j] = (uint16_t)cur;
+                    M.pat[j] = (uint16_t)at;
                 }
-                if (!fresh) {
-                    if (lane == 0) M.ncov[cur] = (uint16_t)(M.ncov[cur] + 1);
-                } else {
-                    if ((uint32_t)n >= M.n_cap) return 2;
-                    cur = n;
-                    /* shift ranks [at, n) up by one, highest chunk first */
-                    for (int hi = n; hi > at; hi -= 64) {
-                        const int r = hi - 1 - lane;
-                        uint16_t v = 0;
-                        if (r >= at) v = M.r2n[r];
-                        cw_wave_sync();
-                        if (r >= at) { M.r2n[r + 1] = v; M.n2r[v] = (uint16_t)(r + 1); }
-                        cw_wave_sync();
-                    }
-                    if (lane == 0) {
-                        M.r2n[at] = (uint16_t)cur; M.n2r[cur] = (uint16_t)at;
-                        M.nbase[cur] = (uint8_t)bcode; M.ncov[cur] = 1; M.nalc[cur] = 0;
+                if (has) next_rank = first_rank;
+            }
+            cw_wave_sync();
+            /* pass B (first chunk first): ids for fresh nodes, node records, coverage */
+            int fresh_total = 0;
+            for (int c = 0; c < chunks; ++c) {
+                const int j = c * 64 + lane;
+                const bool act = j < L;
+                const bool fresh = act && M.pcur[j] == CW_NONE16;
+                const unsigned long long fb = __ballot(fresh);
+                if (fresh) {
+                    const int cur = n_old + fresh_total + __popcll(fb & lt_mask);
+                    if ((uint32_t)cur < M.n_cap) {
+                        M.pcur[j] = (uint16_t)cur;
+                        M.nbase[cur] = M.sq[j]; M.ncov[cur] = 1; M.nalc[cur] = 0;
                         M.in_head[cur] = CW_NONE16; M.in_tail[cur] = CW_NONE16; M.indeg[cur] = 0; M.has_out[cur] = 0;
-                        if (pn != CW_NONE16) { /* joins pn's column */
+                        const uint32_t rk = M.seqrank[j];
+                        if (rk != CW_NONE16) { /* joins the column of the node it was aligned to */
+                            const int pn = M.r2n[rk];
                             const int ac = M.nalc[pn];
                             for (int a = 0; a < ac; ++a) {
                                 const int v = M.nal[pn * 3 + a];
@@ -364,33 +397,80 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                             M.nal[pn * 3 + ac] = (uint16_t)cur; M.nalc[pn] = (uint8_t)(ac + 1);
                         }
                     }
-                    n++;
-                    csr_ok = false;
-                    cw_wave_sync();
+                } else if (act) {
+                    const int cur = M.pcur[j];
+                    M.ncov[cur] = (uint16_t)(M.ncov[cur] + 1);
                 }
-                if (head >= 0) {
-                    bool exists = false;
-                    for (uint32_t e = M.in_head[cur]; e != CW_NONE16; e = M.enext[e])
-                        if (M.efrom[e] == (uint16_t)head) { exists = true; break; }
-                    if (!exists) {
-                        if ((uint32_t)ne >= M.e_cap) return 2;
-                        if (lane == 0) {
-                            M.efrom[ne] = (uint16_t)head; M.enext[ne] = CW_NONE16;
-                            const uint32_t tl = M.in_tail[cur];
-                            if (tl == CW_NONE16) M.in_head[cur] = (uint16_t)ne; else M.enext[tl] = (uint16_t)ne;
-                            M.in_tail[cur] = (uint16_t)ne;
-                            M.indeg[cur] = (uint16_t)(M.indeg[cur] + 1);
-                            M.has_out[head] = 1;
-                        }
-                        ne++;
-                        csr_ok = false;
-                        cw_wave_sync();
+                fresh_total += __popcll(fb);
+            }
+            if ((uint32_t)(n_old + fresh_total) > M.n_cap) return 2;
+            cw_wave_sync();
+            /* pass C: place the fresh nodes in the rank order (one histogram + one prefix sum) */
+            if (fresh_total > 0) {
+                uint32_t* hist = (uint32_t*)M.plist; /* n_old + 1 counters */
+                for (int r = lane; r <= n_old; r += 64) hist[r] = 0;
+                cw_wave_sync();
+                for (int c = 0; c < chunks; ++c) {
+                    const int j = c * 64 + lane;
+                    if (j < L && M.pat[j] != CW_NONE16) atomicAdd(&hist[M.pat[j]], 1u);
+                }
+                cw_wave_sync();
+                int run = 0;
+                for (int r0 = 0; r0 < n_old; r0 += 64) {
+                    const int r = r0 + lane;
+                    const int hcount = r < n_old ? (int)hist[r] : 0;
+                    const int inc = cw_wave_scan_add(hcount);
+                    if (r < n_old) {
+                        const int nr = r + run + inc; /* shifted by every fresh node placed at a slot <= r */
+                        const int v = M.r2n[r];
+                        M.rtmp[nr] = (uint16_t)v;
+                        M.n2r[v] = (uint16_t)nr;
+                    }
+                    run += cw_lane_value(inc, 63);
+                }
+                for (int c = 0; c < chunks; ++c) {
+                    const int j = c * 64 + lane;
+                    if (j < L && M.pat[j] != CW_NONE16) {
+                        const int cur = M.pcur[j];
+                        const int nr = (int)M.pat[j] + (cur - n_old); /* slot + fresh nodes before it on the path */
+                        M.rtmp[nr] = (uint16_t)cur;
+                        M.n2r[cur] = (uint16_t)nr;
                     }
                 }
-                head = cur;
+                cw_wave_sync();
+                n = n_old + fresh_total;
+                for (int r = lane; r < n; r += 64) M.r2n[r] = M.rtmp[r];
+                meta_ok = false;
+                cw_wave_sync();
             }
+            /* pass D: edges between consecutive sequence positions */
+            for (int c = 0; c < chunks; ++c) {
+                const int j = c * 64 + lane;
+                const bool act = j < L && j > 0;
+                int head = 0, cur = 0;
+                bool add = false;
+                if (act) {
+                    head = M.pcur[j - 1]; cur = M.pcur[j];
+                    add = true;
+                    for (uint32_t e = M.in_head[cur]; e != CW_NONE16; e = M.enext[e])
+                        if (M.efrom[e] == (uint16_t)head) { add = false; break; }
+                }
+                const unsigned long long ab = __ballot(add);
+                const int total = __popcll(ab);
+                if ((uint32_t)(ne + total) > M.e_cap) return 2;
+                if (add) {
+                    const int e = ne + __popcll(ab & lt_mask);
+                    M.efrom[e] = (uint16_t)head; M.enext[e] = CW_NONE16;
+                    const uint32_t tl = M.in_tail[cur];
+                    if (tl == CW_NONE16) M.in_head[cur] = (uint16_t)e; else M.enext[tl] = (uint16_t)e;
+                    M.in_tail[cur] = (uint16_t)e;
+                    M.indeg[cur] = (uint16_t)(M.indeg[cur] + 1);
+                    M.has_out[head] = 1;
+                }
+                if (total) { ne += total; meta_ok = false; }
+            }
+            cw_wave_sync();
         }
-        cw_wave_sync();
         POA_PROF(3);
     }
 
@@ -405,28 +485,30 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             bool first = true;
             for (int a = 0; a < ac; ++a) if (M.n2r[M.nal[v * 3 + a]] < r) first = false;
             if (first) {
-                int cnt[4] = {0, 0, 0, 0};
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
                 int tpl_code = -1;
                 for (int c = 0; c <= ac; ++c) {
                     const int u = M.r2n[r + c];
                     const int code = M.nbase[u];
-                    cnt[code] += M.ncov[u];
+                    const int cv = M.ncov[u];
+                    c0 += code == 0 ? cv : 0; c1 += code == 1 ? cv : 0; c2 += code == 2 ? cv : 0; c3 += code == 3 ? cv : 0;
                     if (u < tpl_nodes) tpl_code = code;
                 }
-                const int gaps = nseq - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
-                int top = 0;
-                for (int c = 1; c < 4; ++c) if (cnt[c] > cnt[top]) top = c;
-                if (!(gaps > cnt[top])) {
-                    if (tpl_code != -1 && cnt[tpl_code] == cnt[top]) top = tpl_code;
+                const int gaps = nseq - (c0 + c1 + c2 + c3);
+                int top = 0, tc = c0;
+                if (c1 > tc) { top = 1; tc = c1; }
+                if (c2 > tc) { top = 2; tc = c2; }
+                if (c3 > tc) { top = 3; tc = c3; }
+                if (!(gaps > tc)) {
+                    const int tplc = tpl_code == 0 ? c0 : tpl_code == 1 ? c1 : tpl_code == 2 ? c2 : tpl_code == 3 ? c3 : -1;
+                    if (tplc == tc) top = tpl_code;
                     emit = top;
                 }
             }
         }
         const unsigned long long bal = __ballot(emit >= 0);
-        const uint32_t idx = out_len + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (emit >= 0) {
-            if (idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
-        }
+        const uint32_t idx = out_len + (uint32_t)__popcll(bal & lt_mask);
+        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
         out_len += (uint32_t)__popcll(bal);
     }
     if (out_len > t.out_cap) return 3;
@@ -435,11 +517,6 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
 #undef POA_PROF
     return 1;
 }
-
-/* ---- tier S: one task per wave, graph + DP matrix in LDS, work-stealing over the task list -------- */
-#define CW_POA_GRAPH_BYTES(NC, EC, LC) ((NC) * 21 + (EC) * 6 + 2 * ((NC) + 1) + 4 * ((NC) + (LC) + 2) + ((LC) + 1))
-#define CW_POA_SLAB_BYTES ((CW_POA_HC * 2 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + 15) / 16 * 16)
-#define CW_POAM_SLAB_BYTES ((CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC) + 15) / 16 * 16)
 
 __device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, const unsigned long long (&acc)[6], int lane) {
     if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[base + q], acc[q]);
