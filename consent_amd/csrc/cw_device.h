@@ -68,6 +68,8 @@ struct BatchCounters {
     uint32_t any_overflow;
     uint32_t n_mid;        /* tasks for tier M */
     uint32_t next_mid;
+    uint32_t n_large;      /* tasks for tier L */
+    uint32_t next_large;
     unsigned long long prof[24]; /* cycle totals per phase (wall_clock64), see cw_debug_profile */
 };
 
@@ -92,11 +94,15 @@ struct DevScratch {
     uint32_t member_cap;
     uint32_t* big_list; /* indices of tasks for tier G */
     uint32_t* mid_list; /* indices of tasks for tier M */
+    uint32_t* large_list; /* indices of tasks for tier L */
     uint32_t big_cap;   /* capacity of both lists */
     BatchCounters* ctr;
     uint8_t* mid_scratch; /* per-wave DP slabs of tier M */
     uint64_t mid_slab_bytes;
     uint32_t mid_slots;
+    uint8_t* large_scratch; /* per-wave DP slabs of tier L */
+    uint64_t large_slab_bytes;
+    uint32_t large_slots;
     uint8_t* big_scratch; /* per-wave slabs of tier G */
     uint64_t big_slab_bytes;
     uint32_t big_slots;
@@ -163,6 +169,22 @@ __device__ __forceinline__ int cw_wave_scan_add(int v) {
     v += CW_DPP(0, v, 0x142, 0xA);
     v += CW_DPP(0, v, 0x143, 0xC);
     return v;
+}
+/* wave-wide max of a 64-bit key, returned as a wave-uniform value (two 32-bit DPP ladders with a lexicographic select) */
+__device__ __forceinline__ unsigned long long cw_wave_max_u64(unsigned long long v) {
+    unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+#define CW_MAX64_STEP(ctrl, mask)                                                        \
+    do {                                                                                 \
+        const unsigned ohi = (unsigned)CW_DPP(0, (int)hi, ctrl, mask);                   \
+        const unsigned olo = (unsigned)CW_DPP(0, (int)lo, ctrl, mask);                   \
+        const bool take = ohi > hi || (ohi == hi && olo > lo);                           \
+        hi = take ? ohi : hi; lo = take ? olo : lo;                                      \
+    } while (0)
+    CW_MAX64_STEP(0x111, 0xF); CW_MAX64_STEP(0x112, 0xF); CW_MAX64_STEP(0x114, 0xF); CW_MAX64_STEP(0x118, 0xF);
+    CW_MAX64_STEP(0x142, 0xA); CW_MAX64_STEP(0x143, 0xC);
+#undef CW_MAX64_STEP
+    const unsigned rh = (unsigned)__builtin_amdgcn_readlane((int)hi, 63), rl = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    return ((unsigned long long)rh << 32) | rl;
 }
 /* lane l receives v of lane l-1; lane 0 receives `fill` */
 __device__ __forceinline__ int cw_wave_shr1(int v, int fill) { return CW_DPP(fill, v, 0x138, 0xF); }

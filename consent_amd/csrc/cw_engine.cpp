@@ -22,14 +22,15 @@ size_t big_slab_bytes() {
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, mid_list, ctr, big, mid, total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, mid_list, large_list, ctr, big, mid, large, total;
     uint64_t solid_cap, seg_cap, arena_cap;
-    uint32_t task_cap, member_cap, big_slots, mid_slots;
+    uint32_t task_cap, member_cap, big_slots, mid_slots, large_slots;
 };
 
 size_t mid_slab_bytes() { return align_up((size_t)CW_POAM_HC * 2, 256); }
+size_t large_slab_bytes() { return align_up((size_t)CW_POAL_HC * 2, 256); }
 
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots, uint32_t mid_slots) {
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots, uint32_t mid_slots, uint32_t large_slots) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
@@ -40,6 +41,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
     p.big_slots = big_slots;
     p.mid_slots = mid_slots;
+    p.large_slots = large_slots;
     size_t o = 0;
     auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
     put(p.win, (size_t)n_windows * sizeof(WinInfo));
@@ -52,9 +54,11 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
     put(p.big_list, (size_t)p.task_cap * 4);
     put(p.mid_list, (size_t)p.task_cap * 4);
+    put(p.large_list, (size_t)p.task_cap * 4);
     put(p.ctr, sizeof(BatchCounters));
     put(p.big, (size_t)big_slots * big_slab_bytes());
     put(p.mid, (size_t)mid_slots * mid_slab_bytes());
+    put(p.large, (size_t)large_slots * large_slab_bytes());
     p.total = o;
     return p;
 }
@@ -121,7 +125,8 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAL_SLAB_BYTES * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
         return CW_E_NO_DEVICE;
@@ -155,8 +160,9 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const uint32_t mid_blocks_per_cu = 3;
     const uint32_t mid_slots = (uint32_t)cus * mid_blocks_per_cu * CW_POAM_WAVES;
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots, mid_slots);
-    e->last_mid_slots = mid_slots;
+    const uint32_t large_slots = (uint32_t)cus * 2 * CW_POAL_WAVES;
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots, mid_slots, large_slots);
+    e->last_mid_slots = mid_slots; e->last_large_slots = large_slots;
     e->last_windows = batch->n_windows; e->last_words = batch->n_words; e->last_big_slots = big_slots;
     int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
     if (rc) return rc;
@@ -175,6 +181,8 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.big_list = (uint32_t*)(base + p.big_list); sc.big_cap = p.task_cap;
     sc.mid_list = (uint32_t*)(base + p.mid_list);
     sc.mid_scratch = base + p.mid; sc.mid_slab_bytes = mid_slab_bytes(); sc.mid_slots = p.mid_slots;
+    sc.large_list = (uint32_t*)(base + p.large_list);
+    sc.large_scratch = base + p.large; sc.large_slab_bytes = large_slab_bytes(); sc.large_slots = p.large_slots;
     sc.ctr = (BatchCounters*)(base + p.ctr);
     sc.big_scratch = base + p.big; sc.big_slab_bytes = big_slab_bytes(); sc.big_slots = p.big_slots;
     FinOut fo;
@@ -194,8 +202,10 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     mark(e, st, "index");
     cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
     mark(e, st, "poa");
-    cw_poa_mid_kernel<<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
+    cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_WAVES, 1><<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
     mark(e, st, "poa_mid");
+    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 2><<<p.large_slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POAL_SLAB_BYTES * CW_POAL_WAVES, st>>>(db, sc);
+    mark(e, st, "poa_large");
     cw_poa_big_kernel<<<p.big_slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     mark(e, st, "poa_big");
     {
@@ -238,10 +248,10 @@ int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
 int cw_debug_profile(cw_engine* e, uint32_t* counters8, unsigned long long* prof24) {
     if (!e || !e->scratch || !counters8 || !prof24) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
-    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, e->last_big_slots, e->last_mid_slots);
+    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, e->last_big_slots, e->last_mid_slots, e->last_large_slots);
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(counters8, &c, 40);
+    memcpy(counters8, &c, 48);
     memcpy(prof24, c.prof, sizeof(c.prof));
     return CW_OK;
 }

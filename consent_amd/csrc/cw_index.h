@@ -333,12 +333,15 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (ok) { tcand[tid] = (int16_t)off; cand_tp[off] = (uint16_t)tid; }
         }
         __syncthreads();
-        const uint32_t Ap = A | 1u; /* P is sequence-major: P[s * Ap + a]; odd stride spreads the banks */
-        if ((uint64_t)Ap * N > p_cap) {
+        /* P is anchor-major, P[a * Np + s]; Np is even with Np/2 odd so that rows read as u32 pairs by consecutive
+           lanes fall on distinct banks */
+        uint32_t Np = (N + 1u) & ~1u;
+        if (((Np >> 1) & 1u) == 0u) Np += 2u;
+        if ((uint64_t)A * Np > p_cap) {
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             continue;
         }
-        for (uint32_t i = tid; i < Ap * N; i += CW_IDX_THREADS) P[i] = CW_NONE16;
+        for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) P[i] = CW_NONE16;
         __syncthreads();
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
             const uint32_t len = b.seq_len[s0 + s];
@@ -348,52 +351,61 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const int e = cw_tpl_lookup(th, tkey, cw_kmer_at(words, p, k));
                 if (e < 0) continue;
                 const int a = tcand[e];
-                if (a >= 0) P[s * Ap + (uint32_t)a] = (uint16_t)p;
+                if (a >= 0) P[(uint32_t)a * Np + s] = (uint16_t)p;
             }
         }
         __syncthreads();
 
         CW_PROF(sc.ctr, 4, tid == 0);
         /* ================= phase C: chain ================= */
-        /* best(a) for a = A-1 .. 0: every thread scores one successor b > a against all N sequences, then a
-           block-wide lexicographic max (length, summed score, smallest b) picks the link (cw_policy.h). */
-        {
-            unsigned long long* red = (unsigned long long*)(misc + 16); /* 16 x u64 */
+        /* best(a) for a = A-1 .. 0 by one wave: lanes score 64 successors b > a at a time against all N sequences,
+           nearest successors first; smax[b] = max length from b onwards lets the scan stop as soon as no later
+           successor can tie or beat the best link found (exact; cw_policy.h "chaining"). */
+        if (wave == 0) {
+            int16_t* smax = bnext; /* A + 1 entries */
+            if (lane == 0) smax[A] = -1;
+            cw_wave_sync();
             for (int a = (int)A - 1; a >= 0; --a) {
-                const uint32_t bb = (uint32_t)a + 1u + (uint32_t)tid;
-                unsigned long long key = 0ull;
-                if ((uint32_t)a + 1u + (uint32_t)(wave * 64) < A) { /* wave-uniform: this wave owns at least one b */
+                unsigned long long best = 0ull;
+                const uint32_t* pa_row = (const uint32_t*)(P + (uint32_t)a * Np);
+                const uint32_t half = Np >> 1; /* pairs of sequences; padding entries are CW_NONE16 and never count */
+                for (uint32_t b0 = (uint32_t)a + 1u; b0 < A; b0 += 64) {
+                    const uint32_t bb = b0 + (uint32_t)lane;
+                    unsigned long long key = 0ull;
                     if (bb < A) {
                         uint32_t cnt = 0;
-                        const uint16_t* pa_col = P + (uint32_t)a;
-                        const uint16_t* pb_col = P + bb;
+                        const uint32_t* pb_row = (const uint32_t*)(P + bb * Np);
 #pragma unroll 8
-                        for (uint32_t s = 0; s < N; ++s) {
-                            const uint32_t pa = pa_col[s * Ap], pb = pb_col[s * Ap];
-                            cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                        for (uint32_t s = 0; s < half; ++s) {
+                            const uint32_t va = pa_row[s], vb = pb_row[s];
+                            const uint32_t a0 = va & 0xFFFFu, a1 = va >> 16, b0_ = vb & 0xFFFFu, b1_ = vb >> 16;
+                            cnt += (a0 < b0_ && b0_ != CW_NONE16) ? 1u : 0u;
+                            cnt += (a1 < b1_ && b1_ != CW_NONE16) ? 1u : 0u;
                         }
                         if ((int)cnt >= sup_min)
                             key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
                                   (unsigned long long)(0xFFFFu - bb);
                     }
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const unsigned long long ok = __shfl_xor(key, o);
-                        key = ok > key ? ok : key;
+                    key = cw_wave_max_u64(key);
+                    best = key > best ? key : best;
+                    if (best != 0ull && b0 + 64 < A) {
+                        const int blen = (int)(best >> 48) - 1;
+                        if ((int)smax[b0 + 64] < blen) break;
                     }
                 }
-                if (lane == 0) red[wave] = key;
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned long long best = 0ull;
-                    for (int q = 0; q < CW_IDX_WAVES; ++q) best = red[q] > best ? red[q] : best;
+                if (lane == 0) {
+                    int la = 0;
                     if (best == 0ull) { clen[a] = 0; csc[a] = 0; cnxt[a] = -1; }
                     else {
-                        clen[a] = (int16_t)(best >> 48); /* stored length+1 of b == length of a */
+                        la = (int)(best >> 48); /* stored length+1 of b == length of a */
+                        clen[a] = (int16_t)la;
                         csc[a] = (int32_t)((best >> 16) & 0xFFFFFFFFull);
                         cnxt[a] = (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
                     }
+                    const int sm = smax[a + 1];
+                    smax[a] = (int16_t)(la > sm ? la : sm);
                 }
-                __syncthreads();
+                cw_wave_sync();
             }
         }
         if (wave == 0) {
@@ -442,8 +454,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[s * Ap + (uint32_t)ca] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[s * Ap + (uint32_t)cb] : 0u;
+                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
+                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
@@ -496,8 +508,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[s * Ap + (uint32_t)ca] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[s * Ap + (uint32_t)cb] : 0u;
+                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
+                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }

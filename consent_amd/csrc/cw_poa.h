@@ -39,6 +39,12 @@
 #define CW_POAM_LC 511
 #define CW_POAM_HC ((CW_POAM_NC + 1) * (CW_POAM_LC + 1))
 #define CW_POAM_WAVES 2
+/* tier L: as M with room for the long tail (one wave per work-group, ~76 KiB of LDS) */
+#define CW_POAL_NC 1536
+#define CW_POAL_EC 4096
+#define CW_POAL_LC 1023
+#define CW_POAL_HC ((CW_POAL_NC + 1) * (CW_POAL_LC + 1))
+#define CW_POAL_WAVES 1
 /* tier G: everything in a per-wave global slab (int32 cells) */
 #define CW_POAB_NC 2048
 #define CW_POAB_EC 8192
@@ -49,6 +55,7 @@
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 #define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
 #define CW_POAM_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC))
+#define CW_POAL_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC))
 
 template <typename HT>
 struct PoaMem {
@@ -104,6 +111,78 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.sq = p; p += lc + 1;
     M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc;
     return M;
+}
+
+/*
+ * DP fill with the previous row resident in registers: NCH chunks of 64 columns per row (cols <= 64*NCH).
+ * A row whose predecessor is the row just computed needs no memory read at all; other predecessor rows are
+ * fetched for all chunks at once (one round trip per row).  The next row's metadata is requested while the
+ * current row computes.
+ */
+template <typename HT, int NCH>
+__device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane) {
+    const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
+    int sq_[NCH], prev[NCH];
+    bool act[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = c * 64 + lane;
+        act[c] = j < cols;
+        sq_[c] = (j > 0 && act[c]) ? (int)M.sq[j - 1] : -1;
+        prev[c] = j * G; /* row 0 */
+    }
+    uint32_t meta_n = M.rmeta[0];
+    uint32_t pr0_n = M.rpred0[0];
+    for (int r = 0; r < n; ++r) {
+        const int i = r + 1;
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
+        const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
+        if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
+        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+        int v[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = CW_NEG;
+        for (int q = 0; q < np; ++q) {
+            const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
+            if (prow == i - 1) {
+                int carry_in = CW_NEG;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int dg = cw_wave_shr1(prev[c], carry_in);
+                    carry_in = cw_lane_value(prev[c], 63);
+                    const int s = (sq_[c] == base) ? MS : XS;
+                    v[c] = max(v[c], max(dg + s, prev[c] + G));
+                }
+            } else {
+                cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
+                const int pr = prow * cols;
+                int up[NCH], dg[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int j = c * 64 + lane;
+                    up[c] = act[c] ? (int)M.H[pr + j] : CW_NEG;
+                    dg[c] = (act[c] && j > 0) ? (int)M.H[pr + j - 1] : CW_NEG;
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int s = (sq_[c] == base) ? MS : XS;
+                    v[c] = max(v[c], max(dg[c] + s, up[c] + G));
+                }
+            }
+        }
+        int carry = CW_NEG;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = c * 64 + lane;
+            int w = act[c] ? v[c] - j * G : CW_NEG;
+            w = cw_wave_scan_max(w);
+            w = max(w, carry);
+            carry = cw_lane_value(w, 63);
+            prev[c] = w + j * G;
+            if (act[c]) M.H[i * cols + j] = (HT)prev[c];
+        }
+    }
+    cw_wave_sync();
 }
 
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
@@ -173,82 +252,11 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         for (int j = lane; j < L; j += 64) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
-        if (cols <= 128) {
-            const bool two = cols > 64;
-            const int j0 = lane, j1 = 64 + lane;
-            const bool act0 = j0 < cols, act1 = two && j1 < cols;
-            const int s0q = (j0 > 0 && act0) ? (int)M.sq[j0 - 1] : -1, s1q = act1 ? (int)M.sq[j1 - 1] : -1;
-            int prev0 = j0 * G, prev1 = j1 * G; /* row 0 */
-            uint32_t meta_n = M.rmeta[0];
-            uint32_t pr0_n = M.rpred0[0];
-            for (int r = 0; r < n; ++r) {
-                const int i = r + 1;
-                const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
-                const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
-                if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; } /* in flight while this row computes */
-                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                const int sc0 = (s0q == base) ? MS : XS, sc1 = (s1q == base) ? MS : XS;
-                int v0 = CW_NEG, v1 = CW_NEG;
-                for (int q = 0; q < np; ++q) {
-                    const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
-                    int up0, up1, dg0, dg1;
-                    if (prow == i - 1) {
-                        up0 = prev0; up1 = prev1;
-                        dg0 = cw_wave_shr1(prev0, CW_NEG);
-                        dg1 = cw_wave_shr1(prev1, cw_lane_value(prev0, 63));
-                    } else {
-                        cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
-                        const int pr = prow * cols;
-                        up0 = act0 ? (int)M.H[pr + j0] : CW_NEG;
-                        dg0 = (act0 && j0 > 0) ? (int)M.H[pr + j0 - 1] : CW_NEG;
-                        up1 = act1 ? (int)M.H[pr + j1] : CW_NEG;
-                        dg1 = act1 ? (int)M.H[pr + j1 - 1] : CW_NEG;
-                    }
-                    v0 = max(v0, max(dg0 + sc0, up0 + G));
-                    v1 = max(v1, max(dg1 + sc1, up1 + G));
-                }
-                int w0 = act0 ? v0 - j0 * G : CW_NEG;
-                w0 = cw_wave_scan_max(w0);
-                prev0 = w0 + j0 * G;
-                if (act0) M.H[i * cols + j0] = (HT)prev0;
-                if (two) {
-                    int w1 = act1 ? v1 - j1 * G : CW_NEG;
-                    w1 = cw_wave_scan_max(w1);
-                    w1 = max(w1, cw_lane_value(w0, 63));
-                    prev1 = w1 + j1 * G;
-                    if (act1) M.H[i * cols + j1] = (HT)prev1;
-                }
-            }
-            cw_wave_sync();
-        } else {
-            for (int r = 0; r < n; ++r) {
-                const int i = r + 1;
-                const uint32_t meta = M.rmeta[r];
-                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                const int pr0 = M.rpred0[r];
-                int carry = CW_NEG;
-                for (int c0 = 0; c0 < cols; c0 += 64) {
-                    const int j = c0 + lane;
-                    const bool act = j < cols;
-                    int v = CW_NEG;
-                    if (act) {
-                        const int s = (j > 0 && M.sq[j - 1] == base) ? MS : XS;
-                        for (int q = 0; q < np; ++q) {
-                            const int pr = ((np == 1) ? pr0 : (int)M.plist[off + q]) * cols;
-                            const int up = M.H[pr + j];
-                            const int dg = j > 0 ? (int)M.H[pr + j - 1] : CW_NEG;
-                            v = max(v, max(dg + s, up + G));
-                        }
-                    }
-                    int wv = act ? v - j * G : CW_NEG;
-                    wv = cw_wave_scan_max(wv);
-                    wv = max(wv, carry);
-                    carry = cw_lane_value(wv, 63);
-                    if (act) M.H[i * cols + j] = (HT)(wv + j * G);
-                }
-                cw_wave_sync();
-            }
-        }
+        if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane);
+        else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane);
+        else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane);
+        else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane);
+        else poa_fill<HT, 16>(M, n, cols, lane);
         POA_PROF(1);
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
@@ -551,28 +559,38 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
     poa_flush_prof(sc, 8, acc, lane);
 }
 
-/* ---- tier M: graph in LDS, DP matrix in this wave's global slab --------------------------------- */
-__global__ void __launch_bounds__(64 * CW_POAM_WAVES) cw_poa_mid_kernel(DevBatch b, DevScratch sc) {
+/* ---- tiers M and L: graph in LDS, DP matrix in this wave's global slab ----------------------------- */
+template <int NC, int EC, int LC, int WAVES, int TIER>
+__global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t gw = blockIdx.x * CW_POAM_WAVES + wave;
-    if (gw >= sc.mid_slots) return;
-    int16_t* hslab = (int16_t*)(sc.mid_scratch + (size_t)gw * sc.mid_slab_bytes);
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POAM_SLAB_BYTES, CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_HC, hslab);
-    const uint32_t n_mid = min(sc.ctr->n_mid, sc.big_cap);
+    const uint32_t gw = blockIdx.x * WAVES + wave;
+    const uint32_t slots = TIER == 1 ? sc.mid_slots : sc.large_slots;
+    if (gw >= slots) return;
+    uint8_t* slab_base = TIER == 1 ? sc.mid_scratch : sc.large_scratch;
+    const uint64_t slab_bytes = TIER == 1 ? sc.mid_slab_bytes : sc.large_slab_bytes;
+    int16_t* hslab = (int16_t*)(slab_base + (size_t)gw * slab_bytes);
+    constexpr uint32_t graph_bytes = CW_POA_GRAPH_BYTES(NC, EC, LC);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * graph_bytes, NC, EC, LC, (NC + 1) * (LC + 1), hslab);
+    const uint32_t* list = TIER == 1 ? sc.mid_list : sc.large_list;
+    uint32_t* n_in = TIER == 1 ? &sc.ctr->n_mid : &sc.ctr->n_large;
+    uint32_t* next_in = TIER == 1 ? &sc.ctr->next_mid : &sc.ctr->next_large;
+    uint32_t* out_list = TIER == 1 ? sc.large_list : sc.big_list;
+    uint32_t* n_out = TIER == 1 ? &sc.ctr->n_large : &sc.ctr->n_big;
+    const uint32_t n_work = min(*n_in, sc.big_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t mi = 0;
-        if (lane == 0) mi = atomicAdd(&sc.ctr->next_mid, 1u);
+        if (lane == 0) mi = atomicAdd(next_in, 1u);
         mi = (uint32_t)__shfl((int)mi, 0);
-        if (mi >= n_mid) break;
-        const uint32_t ti = sc.mid_list[mi];
+        if (mi >= n_work) break;
+        const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
         if (lane == 0) {
             if (rc == 2) {
-                const uint32_t bi = atomicAdd(&sc.ctr->n_big, 1u);
-                if (bi < sc.big_cap) sc.big_list[bi] = ti;
+                const uint32_t bi = atomicAdd(n_out, 1u);
+                if (bi < sc.big_cap) out_list[bi] = ti;
                 else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             } else if (rc == 3) {
                 sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
@@ -581,7 +599,7 @@ __global__ void __launch_bounds__(64 * CW_POAM_WAVES) cw_poa_mid_kernel(DevBatch
         }
         cw_wave_sync();
     }
-    poa_flush_prof(sc, 14, acc, lane);
+    if (TIER == 1) poa_flush_prof(sc, 14, acc, lane);
 }
 
 /* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
