@@ -125,8 +125,8 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAL_SLAB_BYTES * CW_POAL_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_DC, CW_POAM_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, 0, CW_POAL_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAL_SLAB_BYTES * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
         return CW_E_NO_DEVICE;
@@ -202,9 +202,9 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     mark(e, st, "index");
     cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
     mark(e, st, "poa");
-    cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_WAVES, 1><<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
+    cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_DC, CW_POAM_WAVES, 1><<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
     mark(e, st, "poa_mid");
-    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 2><<<p.large_slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POAL_SLAB_BYTES * CW_POAL_WAVES, st>>>(db, sc);
+    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, 0, CW_POAL_WAVES, 2><<<p.large_slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POAL_SLAB_BYTES * CW_POAL_WAVES, st>>>(db, sc);
     mark(e, st, "poa_large");
     cw_poa_big_kernel<<<p.big_slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     mark(e, st, "poa_big");

@@ -32,12 +32,14 @@
 #define CW_POA_EC 448   /* edges            */
 #define CW_POA_LC 255   /* member length    */
 #define CW_POA_HC 4096  /* DP cells (int16) */
+#define CW_POA_DC 160   /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
 #define CW_POA_WAVES 4
 /* tier M: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2-resident */
 #define CW_POAM_NC 512
 #define CW_POAM_EC 1280
 #define CW_POAM_LC 511
 #define CW_POAM_HC ((CW_POAM_NC + 1) * (CW_POAM_LC + 1))
+#define CW_POAM_DC 0   /* direction words cost tier M more occupancy than they save (measured) */
 #define CW_POAM_WAVES 2
 /* tier L: as M with room for the long tail (one wave per work-group, ~76 KiB of LDS) */
 #define CW_POAL_NC 1536
@@ -53,13 +55,15 @@
 
 /* bytes of the graph part of a slab (everything but H) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
-#define CW_POAM_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC))
+#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
+#define CW_POAM_SLAB_BYTES (CW_POAM_DC * 16 + CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC))
 #define CW_POAL_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC))
 
 template <typename HT>
 struct PoaMem {
     HT* H;
+    unsigned long long* dirs; /* traceback codes, 2 bits per cell as two ballots per (row, chunk): 0 diagonal and
+                                 1 vertical through the first predecessor, 2 horizontal, 3 = compare cell values */
     uint32_t* rmeta;    /* rank -> base | n_pred << 2 | csr offset << 16 (n_pred counts the virtual start as 1) */
     uint16_t* rpred0;   /* rank -> DP row of its first predecessor (0 = virtual start)                           */
     uint16_t* plist;    /* predecessor DP rows in in-edge order (CSR); doubles as a u32 histogram during merges  */
@@ -80,15 +84,17 @@ struct PoaMem {
     uint8_t* nalc;      /* node -> number of aligned nodes (0..3)                                                */
     uint8_t* has_out;
     uint8_t* sq;        /* current member, base codes                                                            */
-    uint32_t n_cap, e_cap, l_cap, h_cap;
+    uint32_t n_cap, e_cap, l_cap, h_cap, d_cap;
 };
 
 template <typename HT>
-__device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, HT* h_ext = nullptr) {
+__device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
+                                                HT* h_ext = nullptr) {
     PoaMem<HT> M;
     uint8_t* p = base;
     if (h_ext) M.H = h_ext;
     else { M.H = (HT*)p; p += (size_t)hc * sizeof(HT); }
+    M.dirs = (unsigned long long*)p; p += (size_t)dc * 16;
     M.rmeta = (uint32_t*)p; p += 4 * nc;
     M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
     M.efrom = (uint16_t*)p; p += 2 * ec;
@@ -109,7 +115,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
     M.sq = p; p += lc + 1;
-    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc;
+    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc;
     return M;
 }
 
@@ -120,7 +126,8 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
  * current row computes.
  */
 template <typename HT, int NCH>
-__device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane) {
+__device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs) {
+    const int nch = (cols + 63) >> 6;
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     int sq_[NCH], prev[NCH];
     bool act[NCH];
@@ -139,9 +146,9 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
         if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-        int v[NCH];
+        int v[NCH], dgv[NCH], upv[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) v[c] = CW_NEG;
+        for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
             if (prow == i - 1) {
@@ -151,7 +158,8 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
                     const int dg = cw_wave_shr1(prev[c], carry_in);
                     carry_in = cw_lane_value(prev[c], 63);
                     const int s = (sq_[c] == base) ? MS : XS;
-                    v[c] = max(v[c], max(dg + s, prev[c] + G));
+                    dgv[c] = dg + s; upv[c] = prev[c] + G;
+                    v[c] = max(v[c], max(dgv[c], upv[c]));
                 }
             } else {
                 cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
@@ -166,7 +174,8 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int s = (sq_[c] == base) ? MS : XS;
-                    v[c] = max(v[c], max(dg[c] + s, up[c] + G));
+                    dgv[c] = dg[c] + s; upv[c] = up[c] + G;
+                    v[c] = max(v[c], max(dgv[c], upv[c]));
                 }
             }
         }
@@ -180,6 +189,13 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             carry = cw_lane_value(w, 63);
             prev[c] = w + j * G;
             if (act[c]) M.H[i * cols + j] = (HT)prev[c];
+            if (use_dirs && c < nch) {
+                /* single-predecessor row: the code the traceback would derive (diagonal, then vertical, then horizontal) */
+                int code = 3;
+                if (np == 1) code = (j > 0 && prev[c] == dgv[c]) ? 0 : (prev[c] == upv[c]) ? 1 : 2;
+                const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code >> 1);
+                if (lane == 0) { M.dirs[(r * nch + c) * 2] = b0; M.dirs[(r * nch + c) * 2 + 1] = b1; }
+            }
         }
     }
     cw_wave_sync();
@@ -252,11 +268,13 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         for (int j = lane; j < L; j += 64) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
-        if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane);
-        else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane);
-        else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane);
-        else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane);
-        else poa_fill<HT, 16>(M, n, cols, lane);
+        const int nch = (cols + 63) >> 6;
+        const bool use_dirs = (uint32_t)(n * nch) <= M.d_cap;
+        if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+        else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
+        else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
+        else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
+        else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
         POA_PROF(1);
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
@@ -278,6 +296,45 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         /* ---- traceback (wave-uniform); records seqrank[j] = rank aligned to sequence position j ---- */
         {
             int i = bi, j = L;
+            if (use_dirs) {
+                /* one LDS round trip per step: the row's direction words and its first predecessor together */
+                while (i > 0) {
+                    const int c = j >> 6;
+                    const unsigned long long d0 = M.dirs[((i - 1) * nch + c) * 2], d1 = M.dirs[((i - 1) * nch + c) * 2 + 1];
+                    const int pr0 = M.rpred0[i - 1];
+                    const int code = (int)((d0 >> (j & 63)) & 1ull) | ((int)((d1 >> (j & 63)) & 1ull) << 1);
+                    if (code == 0) {
+                        if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                        i = pr0; j--;
+                    } else if (code == 1) {
+                        i = pr0;
+                    } else if (code == 2) {
+                        j--;
+                    } else {
+                        /* several predecessors: decide from the cell values (same order of preference) */
+                        const uint32_t meta = M.rmeta[i - 1];
+                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+                        const int h = M.H[i * cols + j];
+                        int pi = i, pj = j;
+                        bool found = false;
+                        if (j != 0) {
+                            const int s = ((int)M.sq[j - 1] == base) ? MS : XS;
+                            for (int q = 0; q < np && !found; ++q) {
+                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                                if (h == (int)M.H[pr * cols + j - 1] + s) { pi = pr; pj = j - 1; found = true; }
+                            }
+                        }
+                        for (int q = 0; q < np && !found; ++q) {
+                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                        }
+                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found) return 3;
+                        if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                        i = pi; j = pj;
+                    }
+                }
+            } else {
             int h = M.H[i * cols + j];
             uint32_t meta = M.rmeta[i - 1];
             int pr0 = M.rpred0[i - 1];
@@ -326,6 +383,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     if (pi != i && pi > 0) { meta = M.rmeta[pi - 1]; pr0 = M.rpred0[pi - 1]; }
                     i = pi; j = pj; h = nh;
                 }
+            }
             }
             /* i == 0: the remaining sequence positions are insertions, already CW_NONE16 */
         }
@@ -533,7 +591,7 @@ __device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, c
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC, CW_POA_DC);
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
@@ -560,7 +618,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
 }
 
 /* ---- tiers M and L: graph in LDS, DP matrix in this wave's global slab ----------------------------- */
-template <int NC, int EC, int LC, int WAVES, int TIER>
+template <int NC, int EC, int LC, int DC, int WAVES, int TIER>
 __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,8 +628,8 @@ __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, Dev
     uint8_t* slab_base = TIER == 1 ? sc.mid_scratch : sc.large_scratch;
     const uint64_t slab_bytes = TIER == 1 ? sc.mid_slab_bytes : sc.large_slab_bytes;
     int16_t* hslab = (int16_t*)(slab_base + (size_t)gw * slab_bytes);
-    constexpr uint32_t graph_bytes = CW_POA_GRAPH_BYTES(NC, EC, LC);
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * graph_bytes, NC, EC, LC, (NC + 1) * (LC + 1), hslab);
+    constexpr uint32_t slab = DC * 16 + CW_POA_GRAPH_BYTES(NC, EC, LC);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), DC, hslab);
     const uint32_t* list = TIER == 1 ? sc.mid_list : sc.large_list;
     uint32_t* n_in = TIER == 1 ? &sc.ctr->n_mid : &sc.ctr->n_large;
     uint32_t* next_in = TIER == 1 ? &sc.ctr->next_mid : &sc.ctr->next_large;
@@ -607,7 +665,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch 
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * CW_POA_WAVES + (threadIdx.x >> 6);
     if (gw >= sc.big_slots) return;
-    const PoaMem<int32_t> M = poa_carve<int32_t>(sc.big_scratch + (size_t)gw * sc.big_slab_bytes, CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC);
+    const PoaMem<int32_t> M = poa_carve<int32_t>(sc.big_scratch + (size_t)gw * sc.big_slab_bytes, CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC, 0);
     const uint32_t n_big = min(sc.ctr->n_big, sc.big_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
