@@ -148,6 +148,19 @@ def main():
         },
         "stage_ms": stage_avg,
     }
+    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_mid": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536",
+                    "poa_big": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
+    if dom and os.path.exists(prof):
+        try:  # HBM-side bytes of the dominant kernel from the separate --pmc passes of the same command (tools/profile_round.sh)
+            pj = json.load(open(prof))
+            if pj.get("windows_per_step") == n_win:
+                for name, k in pj["kernels"].items():
+                    if stage_kernel.get(dom, "?") in name and "traffic_bytes_per_launch" in k:
+                        traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(prof, ROOT)
+        except Exception:
+            pass
     if dom:
         # dominant kernel: algorithmic bytes of the whole path per launch / its own launch time (HIP events)
         ach = alg_bytes / (stage_avg[dom] * 1e-3) / 1e9
@@ -158,7 +171,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_window": alg_bytes / n_win,
             "launch_ms": stage_avg[dom],
         }
