@@ -148,7 +148,7 @@ def main():
         },
         "stage_ms": stage_avg,
     }
-    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_mid": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536",
+    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536",
                     "poa_big": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
     traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
@@ -205,7 +205,9 @@ def main():
         }
     if rank == 0 and os.environ.get("CW_PROFILE"):
         ctr, prof = eng.profile()
-        names = ["idx.count", "idx.exact", "idx.export", "idx.support", "idx.cand+P", "idx.chain", "idx.segments", "-", "poa.csr", "poa.fill", "poa.trace", "poa.merge", "poa.cons", "-", "mid.csr", "mid.fill", "mid.trace", "mid.merge", "mid.cons", "big.csr", "big.fill", "big.trace", "big.merge", "big.cons"]
+        names = ["idx.count", "idx.exact", "idx.export", "idx.support", "idx.cand+P", "idx.chain", "idx.segments", "-"]
+        for tname in ("S", "M1", "M2", "L", "G"):
+            names += [f"{tname}.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
         print("counters", ctr.tolist(), file=sys.stderr)
         print("phase Mcycles", {n: round(float(v) / 1e6, 2) for n, v in zip(names, prof) if n != "-"}, file=sys.stderr)
     if rank == 0:

@@ -56,21 +56,19 @@ struct PoaMember {
     uint16_t len;
 };
 
+#define CW_TIERS 5 /* POA memory tiers: 0 = S (LDS), 1 = M1, 2 = M2, 3 = L (graph in LDS, matrix in a slab), 4 = G (all global) */
+
 /* Batch-wide counters (one struct in scratch, zeroed before every run). */
 struct BatchCounters {
     uint32_t n_tasks;
     uint32_t n_members;
-    uint32_t next_task;    /* work-stealing cursor of the LDS POA kernel */
-    uint32_t n_big;        /* tasks deferred to tier G */
-    uint32_t next_big;
+    uint32_t next_task;    /* work-stealing cursor of the tier-S kernel */
     uint32_t next_window;  /* work-stealing cursor of the index kernel */
     uint32_t next_finish;  /* work-stealing cursor of the finish kernel */
     uint32_t any_overflow;
-    uint32_t n_mid;        /* tasks for tier M */
-    uint32_t next_mid;
-    uint32_t n_large;      /* tasks for tier L */
-    uint32_t next_large;
-    unsigned long long prof[24]; /* cycle totals per phase (wall_clock64), see cw_debug_profile */
+    uint32_t n_tier[CW_TIERS];    /* tasks handed to tier t (t >= 1) */
+    uint32_t next_tier[CW_TIERS]; /* work-stealing cursors */
+    unsigned long long prof[32];  /* cycle totals per phase, see cw_debug_profile */
 };
 
 struct DevBatch {
@@ -92,20 +90,12 @@ struct DevScratch {
     uint32_t task_cap;
     PoaMember* members;
     uint32_t member_cap;
-    uint32_t* big_list; /* indices of tasks for tier G */
-    uint32_t* mid_list; /* indices of tasks for tier M */
-    uint32_t* large_list; /* indices of tasks for tier L */
-    uint32_t big_cap;   /* capacity of both lists */
     BatchCounters* ctr;
-    uint8_t* mid_scratch; /* per-wave DP slabs of tier M */
-    uint64_t mid_slab_bytes;
-    uint32_t mid_slots;
-    uint8_t* large_scratch; /* per-wave DP slabs of tier L */
-    uint64_t large_slab_bytes;
-    uint32_t large_slots;
-    uint8_t* big_scratch; /* per-wave slabs of tier G */
-    uint64_t big_slab_bytes;
-    uint32_t big_slots;
+    uint32_t* tier_list[CW_TIERS]; /* task indices handed to tier t */
+    uint32_t list_cap;
+    uint8_t* slab[CW_TIERS];       /* per-wave slabs of tier t (DP matrix; for tier G also the graph) */
+    uint64_t slab_bytes[CW_TIERS];
+    uint32_t slots[CW_TIERS];      /* resident waves of tier t */
 };
 
 /* ---- packed-sequence access ------------------------------------------------------------------- */

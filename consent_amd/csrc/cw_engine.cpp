@@ -17,20 +17,28 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+struct TierCfg { uint32_t slots; size_t slab_bytes; };
+
 size_t big_slab_bytes() {
     return align_up((size_t)CW_POAB_HC * 4 + CW_POA_GRAPH_BYTES(CW_POAB_NC, CW_POAB_EC, CW_POAB_LC), 256);
 }
 
+void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
+    t[0] = {0, 0};
+    t[1] = {(uint32_t)cus * 3 * CW_POAM1_WAVES, CW_POA_HSLAB_BYTES(CW_POAM1_NC, CW_POAM1_LC)};
+    t[2] = {(uint32_t)cus * 3 * CW_POAM2_WAVES, CW_POA_HSLAB_BYTES(CW_POAM2_NC, CW_POAM2_LC)};
+    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_HSLAB_BYTES(CW_POAL_NC, CW_POAL_LC)};
+    t[4] = {big_slots, big_slab_bytes()};
+}
+
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, big_list, mid_list, large_list, ctr, big, mid, large, total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], slab[CW_TIERS], total;
     uint64_t solid_cap, seg_cap, arena_cap;
-    uint32_t task_cap, member_cap, big_slots, mid_slots, large_slots;
+    uint32_t task_cap, member_cap;
+    TierCfg tier[CW_TIERS];
 };
 
-size_t mid_slab_bytes() { return align_up((size_t)CW_POAM_HC * 2, 256); }
-size_t large_slab_bytes() { return align_up((size_t)CW_POAL_HC * 2, 256); }
-
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, uint32_t big_slots, uint32_t mid_slots, uint32_t large_slots) {
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, int cus, uint32_t big_slots) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
@@ -39,9 +47,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     uint64_t tc = 64ull * n_windows + 1024, mc = 2048ull * n_windows + 4096;
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
-    p.big_slots = big_slots;
-    p.mid_slots = mid_slots;
-    p.large_slots = large_slots;
+    tier_config(cus, big_slots, p.tier);
     size_t o = 0;
     auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
     put(p.win, (size_t)n_windows * sizeof(WinInfo));
@@ -52,13 +58,9 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     put(p.arena, p.arena_cap);
     put(p.tasks, (size_t)p.task_cap * sizeof(PoaTask));
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
-    put(p.big_list, (size_t)p.task_cap * 4);
-    put(p.mid_list, (size_t)p.task_cap * 4);
-    put(p.large_list, (size_t)p.task_cap * 4);
     put(p.ctr, sizeof(BatchCounters));
-    put(p.big, (size_t)big_slots * big_slab_bytes());
-    put(p.mid, (size_t)mid_slots * mid_slab_bytes());
-    put(p.large, (size_t)large_slots * large_slab_bytes());
+    for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
+    for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
     p.total = o;
     return p;
 }
@@ -125,8 +127,12 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_DC, CW_POAM_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAM_SLAB_BYTES * CW_POAM_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, 0, CW_POAL_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAL_SLAB_BYTES * CW_POAL_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
         return CW_E_NO_DEVICE;
@@ -158,11 +164,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     uint32_t big_slots = 256;
     if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const uint32_t mid_blocks_per_cu = 3;
-    const uint32_t mid_slots = (uint32_t)cus * mid_blocks_per_cu * CW_POAM_WAVES;
-    const uint32_t large_slots = (uint32_t)cus * 2 * CW_POAL_WAVES;
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, big_slots, mid_slots, large_slots);
-    e->last_mid_slots = mid_slots; e->last_large_slots = large_slots;
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, cus, big_slots);
     e->last_windows = batch->n_windows; e->last_words = batch->n_words; e->last_big_slots = big_slots;
     int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
     if (rc) return rc;
@@ -172,19 +174,19 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     db.n_windows = batch->n_windows;
     db.win_first_seq = batch->win_first_seq; db.seq_len = batch->seq_len; db.seq_word_off = batch->seq_word_off; db.bases = batch->bases;
     DevScratch sc;
+    memset(&sc, 0, sizeof(sc));
     sc.win = (WinInfo*)(base + p.win);
     sc.solid_key = (uint32_t*)(base + p.solid_key); sc.solid_cnt = (uint32_t*)(base + p.solid_cnt);
     sc.seg_off = (uint32_t*)(base + p.seg_off); sc.seg_len = (uint32_t*)(base + p.seg_len);
     sc.arena = base + p.arena;
     sc.tasks = (PoaTask*)(base + p.tasks); sc.task_cap = p.task_cap;
     sc.members = (PoaMember*)(base + p.members); sc.member_cap = p.member_cap;
-    sc.big_list = (uint32_t*)(base + p.big_list); sc.big_cap = p.task_cap;
-    sc.mid_list = (uint32_t*)(base + p.mid_list);
-    sc.mid_scratch = base + p.mid; sc.mid_slab_bytes = mid_slab_bytes(); sc.mid_slots = p.mid_slots;
-    sc.large_list = (uint32_t*)(base + p.large_list);
-    sc.large_scratch = base + p.large; sc.large_slab_bytes = large_slab_bytes(); sc.large_slots = p.large_slots;
     sc.ctr = (BatchCounters*)(base + p.ctr);
-    sc.big_scratch = base + p.big; sc.big_slab_bytes = big_slab_bytes(); sc.big_slots = p.big_slots;
+    sc.list_cap = p.task_cap;
+    for (int t = 1; t < CW_TIERS; ++t) {
+        sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
+        sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
+    }
     FinOut fo;
     fo.cons = res->cons; fo.cons_off = res->cons_off; fo.cons_len = res->cons_len; fo.win_status = res->win_status;
     fo.solid = res->solid; fo.solid_off = res->solid_off; fo.solid_len = res->solid_len;
@@ -202,11 +204,16 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     mark(e, st, "index");
     cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
     mark(e, st, "poa");
-    cw_poa_slab_kernel<CW_POAM_NC, CW_POAM_EC, CW_POAM_LC, CW_POAM_DC, CW_POAM_WAVES, 1><<<p.mid_slots / CW_POAM_WAVES, 64 * CW_POAM_WAVES, CW_POAM_SLAB_BYTES * CW_POAM_WAVES, st>>>(db, sc);
-    mark(e, st, "poa_mid");
-    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, 0, CW_POAL_WAVES, 2><<<p.large_slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POAL_SLAB_BYTES * CW_POAL_WAVES, st>>>(db, sc);
+    cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1>
+        <<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES, st>>>(db, sc);
+    mark(e, st, "poa_m1");
+    cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2>
+        <<<p.tier[2].slots / CW_POAM2_WAVES, 64 * CW_POAM2_WAVES, CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES, st>>>(db, sc);
+    mark(e, st, "poa_m2");
+    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3>
+        <<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES, st>>>(db, sc);
     mark(e, st, "poa_large");
-    cw_poa_big_kernel<<<p.big_slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
+    cw_poa_big_kernel<<<p.tier[4].slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     mark(e, st, "poa_big");
     {
         uint32_t grid = (batch->n_windows + CW_FIN_WAVES - 1) / CW_FIN_WAVES;
@@ -244,15 +251,16 @@ int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
     return CW_OK;
 }
 
-/* Debug/inspection: the 10 batch counters (u32) and 24 per-phase cycle totals (u64) of the last run. */
-int cw_debug_profile(cw_engine* e, uint32_t* counters8, unsigned long long* prof24) {
-    if (!e || !e->scratch || !counters8 || !prof24) return CW_E_INVALID;
+/* Debug/inspection: 16 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
+int cw_debug_profile(cw_engine* e, uint32_t* counters16, unsigned long long* prof32) {
+    if (!e || !e->scratch || !counters16 || !prof32) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
-    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, e->last_big_slots, e->last_mid_slots, e->last_large_slots);
+    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, cus, e->last_big_slots);
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(counters8, &c, 48);
-    memcpy(prof24, c.prof, sizeof(c.prof));
+    memcpy(counters16, &c, 64);
+    memcpy(prof32, c.prof, sizeof(c.prof));
     return CW_OK;
 }
 

@@ -528,12 +528,12 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 t.window = w; t.seg_slot = slot; t.member_off = m_off; t.n_members = n_mem; t.max_len = mx;
                 t.out_off = abs_off; t.out_cap = need;
                 /* the graph has at least max_len nodes once its longest member is in: (max_len+1)^2 cells */
-                const bool to_mid = (mx + 1) * (mx + 1) > 4096u || mx > 255u;
-                t.state = to_mid ? 2u : 0u;
+                const uint32_t tier = ((mx + 1) * (mx + 1) <= 4096u) ? 0u : (mx <= 255u) ? 1u : (mx <= 511u) ? 2u : 3u;
+                t.state = tier ? 2u : 0u;
                 sc.tasks[t_idx] = t;
-                if (to_mid) {
-                    const uint32_t bi = atomicAdd(&sc.ctr->n_mid, 1u);
-                    if (bi < sc.big_cap) sc.mid_list[bi] = t_idx; else misc[2] = 1;
+                if (tier) {
+                    const uint32_t bi = atomicAdd(&sc.ctr->n_tier[tier], 1u);
+                    if (bi < sc.list_cap) sc.tier_list[tier][bi] = t_idx; else misc[2] = 1;
                 }
                 sc.seg_off[slot] = abs_off; sc.seg_len[slot] = 0;
             }

@@ -7,7 +7,7 @@
 
 #include "../../include/consent_amd.h"
 
-#define CW_MAX_STAGES 10
+#define CW_MAX_STAGES 12
 
 struct cw_engine {
     cw_params prm;
@@ -28,7 +28,7 @@ struct cw_engine {
     const char* stage_name[CW_MAX_STAGES];
     float stage_ms[CW_MAX_STAGES];
     bool timings_valid;
-    uint32_t last_windows, last_big_slots, last_mid_slots, last_large_slots;
+    uint32_t last_windows, last_big_slots;
     uint64_t last_words;
 };
 

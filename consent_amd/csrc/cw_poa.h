@@ -2,9 +2,9 @@
  * cw_poa.h -- partial-order alignment of one segment pile per wavefront (A4d).
  *
  * One 64-lane wave owns one task from the list the index kernel emitted.  Same code, three memory tiers:
- *   S (cw_poa_kernel)      graph + DP matrix in LDS                                 small segments (most tasks)
- *   M (cw_poa_mid_kernel)  graph in LDS, matrix in an L2-resident per-wave slab      long segments
- *   G (cw_poa_big_kernel)  everything in a per-wave global slab                      the rare huge graph
+ *   S        (cw_poa_kernel)        graph + DP matrix in LDS                              small segments (most tasks)
+ *   M1/M2/L  (cw_poa_slab_kernel)   graph in LDS, matrix in an L2-resident per-wave slab   long segments, 3 size classes
+ *   G        (cw_poa_big_kernel)    everything in a per-wave global slab                   the rare huge graph
  * A task that outgrows its tier is handed to the next one and redone there from scratch.
  *
  * Per member of the pile (policies: include/cw_policy.h):
@@ -34,18 +34,19 @@
 #define CW_POA_HC 4096  /* DP cells (int16) */
 #define CW_POA_DC 160   /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
 #define CW_POA_WAVES 4
-/* tier M: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2-resident */
-#define CW_POAM_NC 512
-#define CW_POAM_EC 1280
-#define CW_POAM_LC 511
-#define CW_POAM_HC ((CW_POAM_NC + 1) * (CW_POAM_LC + 1))
-#define CW_POAM_DC 0   /* direction words cost tier M more occupancy than they save (measured) */
-#define CW_POAM_WAVES 2
-/* tier L: as M with room for the long tail (one wave per work-group, ~76 KiB of LDS) */
+/* tiers M1 / M2 / L: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2 / Infinity-Cache
+   resident.  Direction words are off there: they cost more occupancy than they save (measured). */
+#define CW_POAM1_NC 256
+#define CW_POAM1_EC 640
+#define CW_POAM1_LC 255
+#define CW_POAM1_WAVES 4
+#define CW_POAM2_NC 512
+#define CW_POAM2_EC 1280
+#define CW_POAM2_LC 511
+#define CW_POAM2_WAVES 2
 #define CW_POAL_NC 1536
 #define CW_POAL_EC 4096
 #define CW_POAL_LC 1023
-#define CW_POAL_HC ((CW_POAL_NC + 1) * (CW_POAL_LC + 1))
 #define CW_POAL_WAVES 1
 /* tier G: everything in a per-wave global slab (int32 cells) */
 #define CW_POAB_NC 2048
@@ -56,8 +57,7 @@
 /* bytes of the graph part of a slab (everything but H) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 #define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
-#define CW_POAM_SLAB_BYTES (CW_POAM_DC * 16 + CW_POA_GRAPH_BYTES(CW_POAM_NC, CW_POAM_EC, CW_POAM_LC))
-#define CW_POAL_SLAB_BYTES (CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC))
+#define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 
 template <typename HT>
 struct PoaMem {
@@ -588,6 +588,19 @@ __device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, c
     if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[base + q], acc[q]);
 }
 
+__device__ __forceinline__ void poa_hand_over(const DevScratch& sc, const PoaTask& t, uint32_t ti, int rc, int next_tier) {
+    /* lane 0 only: rc 2 = this tier's capacity was exceeded -> next tier; rc 3 = output capacity / internal -> window overflow */
+    if (rc == 2 && next_tier < CW_TIERS) {
+        const uint32_t bi = atomicAdd(&sc.ctr->n_tier[next_tier], 1u);
+        if (bi < sc.list_cap) sc.tier_list[next_tier][bi] = ti;
+        else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+    } else if (rc != 1) {
+        sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
+    }
+    sc.tasks[ti].state = (uint32_t)rc;
+}
+
+/* ---- tier S: one task per wave, graph + DP matrix in LDS, work-stealing over the task list -------- */
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -602,87 +615,59 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         const PoaTask t = sc.tasks[ti];
         if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
         const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
-        if (lane == 0) {
-            if (rc == 2) {
-                const uint32_t bi = atomicAdd(&sc.ctr->n_mid, 1u);
-                if (bi < sc.big_cap) sc.mid_list[bi] = ti;
-                else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
-            } else if (rc == 3) {
-                sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
-            }
-            sc.tasks[ti].state = (uint32_t)rc;
-        }
+        if (lane == 0) poa_hand_over(sc, t, ti, rc, 1);
         cw_wave_sync();
     }
     poa_flush_prof(sc, 8, acc, lane);
 }
 
-/* ---- tiers M and L: graph in LDS, DP matrix in this wave's global slab ----------------------------- */
-template <int NC, int EC, int LC, int DC, int WAVES, int TIER>
+/* ---- tiers M1 / M2 / L: graph in LDS, DP matrix in this wave's global slab ------------------------ */
+template <int NC, int EC, int LC, int WAVES, int TIER>
 __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = blockIdx.x * WAVES + wave;
-    const uint32_t slots = TIER == 1 ? sc.mid_slots : sc.large_slots;
-    if (gw >= slots) return;
-    uint8_t* slab_base = TIER == 1 ? sc.mid_scratch : sc.large_scratch;
-    const uint64_t slab_bytes = TIER == 1 ? sc.mid_slab_bytes : sc.large_slab_bytes;
-    int16_t* hslab = (int16_t*)(slab_base + (size_t)gw * slab_bytes);
-    constexpr uint32_t slab = DC * 16 + CW_POA_GRAPH_BYTES(NC, EC, LC);
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), DC, hslab);
-    const uint32_t* list = TIER == 1 ? sc.mid_list : sc.large_list;
-    uint32_t* n_in = TIER == 1 ? &sc.ctr->n_mid : &sc.ctr->n_large;
-    uint32_t* next_in = TIER == 1 ? &sc.ctr->next_mid : &sc.ctr->next_large;
-    uint32_t* out_list = TIER == 1 ? sc.large_list : sc.big_list;
-    uint32_t* n_out = TIER == 1 ? &sc.ctr->n_large : &sc.ctr->n_big;
-    const uint32_t n_work = min(*n_in, sc.big_cap);
+    if (gw >= sc.slots[TIER]) return;
+    int16_t* hslab = (int16_t*)(sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER]);
+    constexpr uint32_t slab = CW_POA_GRAPH_BYTES(NC, EC, LC);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), 0, hslab);
+    const uint32_t* list = sc.tier_list[TIER];
+    const uint32_t n_work = min(sc.ctr->n_tier[TIER], sc.list_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t mi = 0;
-        if (lane == 0) mi = atomicAdd(next_in, 1u);
+        if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER], 1u);
         mi = (uint32_t)__shfl((int)mi, 0);
         if (mi >= n_work) break;
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
-        if (lane == 0) {
-            if (rc == 2) {
-                const uint32_t bi = atomicAdd(n_out, 1u);
-                if (bi < sc.big_cap) out_list[bi] = ti;
-                else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
-            } else if (rc == 3) {
-                sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
-            }
-            sc.tasks[ti].state = (uint32_t)rc;
-        }
+        if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER + 1);
         cw_wave_sync();
     }
-    if (TIER == 1) poa_flush_prof(sc, 14, acc, lane);
+    poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
 }
 
 /* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch b, DevScratch sc) {
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * CW_POA_WAVES + (threadIdx.x >> 6);
-    if (gw >= sc.big_slots) return;
-    const PoaMem<int32_t> M = poa_carve<int32_t>(sc.big_scratch + (size_t)gw * sc.big_slab_bytes, CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC, 0);
-    const uint32_t n_big = min(sc.ctr->n_big, sc.big_cap);
+    if (gw >= sc.slots[4]) return;
+    const PoaMem<int32_t> M = poa_carve<int32_t>(sc.slab[4] + (size_t)gw * sc.slab_bytes[4], CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC, 0);
+    const uint32_t n_big = min(sc.ctr->n_tier[4], sc.list_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t bi = 0;
-        if (lane == 0) bi = atomicAdd(&sc.ctr->next_big, 1u);
+        if (lane == 0) bi = atomicAdd(&sc.ctr->next_tier[4], 1u);
         bi = (uint32_t)__shfl((int)bi, 0);
         if (bi >= n_big) break;
-        const uint32_t ti = sc.big_list[bi];
+        const uint32_t ti = sc.tier_list[4][bi];
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int32_t>(M, t, b, sc, lane, acc);
-        if (lane == 0) {
-            if (rc != 1) { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
-            sc.tasks[ti].state = (uint32_t)(rc == 1 ? 1 : 3);
-        }
+        if (lane == 0) poa_hand_over(sc, t, ti, rc, CW_TIERS);
         cw_wave_sync();
     }
-    poa_flush_prof(sc, 19, acc, lane);
+    poa_flush_prof(sc, 8 + 5 * 4, acc, lane);
 }
 
 #endif

@@ -262,15 +262,15 @@ class Engine:
         _check(self.lib, self.lib.cw_run_device(self.handle, C.byref(batch_struct), C.byref(result_struct), stream), "cw_run_device")
 
     def timings(self):
-        ms = (C.c_float * 12)()
-        names = (C.c_char_p * 12)()
+        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 16)()
         n = C.c_int()
-        _check(self.lib, self.lib.cw_last_timings(self.handle, ms, names, 12, C.byref(n)), "cw_last_timings")
+        _check(self.lib, self.lib.cw_last_timings(self.handle, ms, names, 16, C.byref(n)), "cw_last_timings")
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
     def profile(self):
-        c = np.zeros(12, np.uint32)
-        p = np.zeros(24, np.uint64)
+        c = np.zeros(16, np.uint32)
+        p = np.zeros(32, np.uint64)
         _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
         return c, p
 
