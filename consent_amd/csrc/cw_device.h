@@ -66,8 +66,10 @@ struct BatchCounters {
     uint32_t next_window;  /* work-stealing cursor of the index kernel */
     uint32_t next_finish;  /* work-stealing cursor of the finish kernel */
     uint32_t any_overflow;
-    uint32_t n_tier[CW_TIERS];    /* tasks handed to tier t (t >= 1) */
+    uint32_t n_tier[CW_TIERS];    /* tasks routed to tier t (t >= 1) by the index kernel */
     uint32_t next_tier[CW_TIERS]; /* work-stealing cursors */
+    uint32_t n_over[CW_TIERS];    /* tasks that outgrew tier t-1 (second pass) */
+    uint32_t next_over[CW_TIERS];
     unsigned long long prof[32];  /* cycle totals per phase, see cw_debug_profile */
 };
 
@@ -91,7 +93,8 @@ struct DevScratch {
     PoaMember* members;
     uint32_t member_cap;
     BatchCounters* ctr;
-    uint32_t* tier_list[CW_TIERS]; /* task indices handed to tier t */
+    uint32_t* tier_list[CW_TIERS]; /* task indices routed to tier t by the index kernel */
+    uint32_t* over_list[CW_TIERS]; /* task indices that outgrew tier t-1 */
     uint32_t list_cap;
     uint8_t* slab[CW_TIERS];       /* per-wave slabs of tier t (DP matrix; for tier G also the graph) */
     uint64_t slab_bytes[CW_TIERS];

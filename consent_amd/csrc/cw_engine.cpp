@@ -25,14 +25,14 @@ size_t big_slab_bytes() {
 
 void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
     t[0] = {0, 0};
-    t[1] = {(uint32_t)cus * 3 * CW_POAM1_WAVES, CW_POA_HSLAB_BYTES(CW_POAM1_NC, CW_POAM1_LC)};
-    t[2] = {(uint32_t)cus * 3 * CW_POAM2_WAVES, CW_POA_HSLAB_BYTES(CW_POAM2_NC, CW_POAM2_LC)};
-    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_HSLAB_BYTES(CW_POAL_NC, CW_POAL_LC)};
+    t[1] = {(uint32_t)cus * 3 * CW_POAM1_WAVES, CW_POA_SLAB_TOTAL(CW_POAM1_NC, CW_POAM1_LC)};
+    t[2] = {(uint32_t)cus * 3 * CW_POAM2_WAVES, CW_POA_SLAB_TOTAL(CW_POAM2_NC, CW_POAM2_LC)};
+    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_SLAB_TOTAL(CW_POAL_NC, CW_POAL_LC)};
     t[4] = {big_slots, big_slab_bytes()};
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], slab[CW_TIERS], total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], total;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap;
     TierCfg tier[CW_TIERS];
@@ -60,6 +60,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
     put(p.ctr, sizeof(BatchCounters));
     for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
+    for (int t = 1; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
     p.total = o;
     return p;
@@ -80,13 +81,13 @@ int check_params(const cw_params* p) {
     return CW_OK;
 }
 
-void mark(cw_engine* e, hipStream_t st, const char* name) {
-    if (e->n_stages < CW_MAX_STAGES) {
-        e->stage_name[e->n_stages] = name;
-        e->n_stages++;
-        (void)hipEventRecord(e->ev[e->n_stages], st);
-    }
+int stage_begin(cw_engine* e, hipStream_t st, const char* name) {
+    const int i = e->n_stages < CW_MAX_STAGES ? e->n_stages++ : CW_MAX_STAGES - 1;
+    e->stage_name[i] = name;
+    (void)hipEventRecord(e->ev0[i], st);
+    return i;
 }
+void stage_end(cw_engine* e, hipStream_t st, int i) { (void)hipEventRecord(e->ev1[i], st); }
 
 } // namespace
 
@@ -123,15 +124,23 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         delete e;
         return CW_E_NO_DEVICE;
     }
-    for (int i = 0; i <= CW_MAX_STAGES; ++i)
-        if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return CW_E_NO_DEVICE; }
+    bool ok = hipEventCreate(&e->ev_fork) == hipSuccess && hipEventCreate(&e->ev_begin) == hipSuccess && hipEventCreate(&e->ev_end) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < CW_MAX_STAGES && ok; ++i) ok = hipEventCreate(&e->ev0[i]) == hipSuccess && hipEventCreate(&e->ev1[i]) == hipSuccess;
+    if (!ok) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
@@ -148,7 +157,11 @@ void cw_destroy(cw_engine* e) {
     if (e->scratch) (void)hipFree(e->scratch);
     if (e->dev_in) (void)hipFree(e->dev_in);
     if (e->dev_out) (void)hipFree(e->dev_out);
-    for (int i = 0; i <= CW_MAX_STAGES; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
+    for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
+    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -185,6 +198,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.list_cap = p.task_cap;
     for (int t = 1; t < CW_TIERS; ++t) {
         sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
+        sc.over_list[t] = (uint32_t*)(base + p.over[t]);
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
     }
     FinOut fo;
@@ -193,34 +207,57 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
 
     e->n_stages = 0;
     e->timings_valid = false;
-    CW_HIP(hipEventRecord(e->ev[0], st));
+#define M1_ARGS CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1
+#define M2_ARGS CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2
+#define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
+    const size_t lds_m1 = CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
+    const size_t lds_m2 = CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
+    const size_t lds_l = CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
+    int sid;
+    CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
+    sid = stage_begin(e, st, "setup");
     cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
-    mark(e, st, "setup");
+    stage_end(e, st, sid);
+    sid = stage_begin(e, st, "index");
     {
         const uint32_t grid = batch->n_windows < (uint32_t)cus ? batch->n_windows : (uint32_t)cus;
         cw_index_kernel<<<grid, CW_IDX_THREADS, CW_IDX_LDS_BYTES, st>>>(db, sc, e->prm);
     }
-    mark(e, st, "index");
+    stage_end(e, st, sid);
+    /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
+       dispatched first so that their tail overlaps the bulk of the small tasks */
+    CW_HIP(hipEventRecord(e->ev_fork, st));
+    for (int i = 0; i < 3; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
+    sid = stage_begin(e, e->side[2], "poa_large");
+    cw_poa_slab_kernel<L_ARGS, 0><<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
+    stage_end(e, e->side[2], sid);
+    sid = stage_begin(e, e->side[1], "poa_m2");
+    cw_poa_slab_kernel<M2_ARGS, 0><<<p.tier[2].slots / CW_POAM2_WAVES, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
+    stage_end(e, e->side[1], sid);
+    sid = stage_begin(e, e->side[0], "poa_m1");
+    cw_poa_slab_kernel<M1_ARGS, 0><<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
+    stage_end(e, e->side[0], sid);
+    sid = stage_begin(e, st, "poa");
     cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
-    mark(e, st, "poa");
-    cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1>
-        <<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES, st>>>(db, sc);
-    mark(e, st, "poa_m1");
-    cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2>
-        <<<p.tier[2].slots / CW_POAM2_WAVES, 64 * CW_POAM2_WAVES, CW_POA_GRAPH_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES, st>>>(db, sc);
-    mark(e, st, "poa_m2");
-    cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3>
-        <<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, CW_POA_GRAPH_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES, st>>>(db, sc);
-    mark(e, st, "poa_large");
+    stage_end(e, st, sid);
+    for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
+    /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
+    sid = stage_begin(e, st, "poa_overflow");
+    cw_poa_slab_kernel<L_ARGS, 1><<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
     cw_poa_big_kernel<<<p.tier[4].slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
-    mark(e, st, "poa_big");
+    stage_end(e, st, sid);
+    sid = stage_begin(e, st, "finish");
     {
         uint32_t grid = (batch->n_windows + CW_FIN_WAVES - 1) / CW_FIN_WAVES;
         if (grid > (uint32_t)cus * 2) grid = (uint32_t)cus * 2;
         cw_finish_kernel<<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
     }
-    mark(e, st, "finish");
+    stage_end(e, st, sid);
+    CW_HIP(hipEventRecord(e->ev_end, st));
+#undef M1_ARGS
+#undef M2_ARGS
+#undef L_ARGS
     CW_HIP(hipGetLastError());
     e->timings_valid = true;
     return CW_OK;
@@ -231,15 +268,23 @@ int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n
     *n_stages = 0;
     if (!e->timings_valid) return CW_OK;
     CW_HIP(hipSetDevice(e->device));
-    CW_HIP(hipEventSynchronize(e->ev[e->n_stages]));
-    for (int i = 0; i < e->n_stages && i < cap; ++i) {
+    CW_HIP(hipEventSynchronize(e->ev_end));
+    int k = 0;
+    for (int i = 0; i < e->n_stages && k < cap; ++i, ++k) {
         float t = 0.f;
-        CW_HIP(hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]));
+        CW_HIP(hipEventElapsedTime(&t, e->ev0[i], e->ev1[i]));
         e->stage_ms[i] = t;
-        if (ms) ms[i] = t;
-        if (names) names[i] = e->stage_name[i];
-        *n_stages = i + 1;
+        if (ms) ms[k] = t;
+        if (names) names[k] = e->stage_name[i];
     }
+    if (k < cap) { /* wall time of the whole run on the launch stream (tiers overlap, so this is not the sum) */
+        float t = 0.f;
+        CW_HIP(hipEventElapsedTime(&t, e->ev_begin, e->ev_end));
+        if (ms) ms[k] = t;
+        if (names) names[k] = "total";
+        ++k;
+    }
+    *n_stages = k;
     return CW_OK;
 }
 
@@ -251,15 +296,15 @@ int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
     return CW_OK;
 }
 
-/* Debug/inspection: 16 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
-int cw_debug_profile(cw_engine* e, uint32_t* counters16, unsigned long long* prof32) {
-    if (!e || !e->scratch || !counters16 || !prof32) return CW_E_INVALID;
+/* Debug/inspection: 26 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
+int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* prof32) {
+    if (!e || !e->scratch || !counters26 || !prof32) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, cus, e->last_big_slots);
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(counters16, &c, 64);
+    memcpy(counters26, &c, 26 * 4);
     memcpy(prof32, c.prof, sizeof(c.prof));
     return CW_OK;
 }

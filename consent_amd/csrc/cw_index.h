@@ -527,8 +527,13 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 PoaTask t;
                 t.window = w; t.seg_slot = slot; t.member_off = m_off; t.n_members = n_mem; t.max_len = mx;
                 t.out_off = abs_off; t.out_cap = need;
-                /* the graph has at least max_len nodes once its longest member is in: (max_len+1)^2 cells */
-                const uint32_t tier = ((mx + 1) * (mx + 1) <= 4096u) ? 0u : (mx <= 255u) ? 1u : (mx <= 511u) ? 2u : 3u;
+                /* route by the expected graph size: the graph has at least max_len nodes once its longest member is in
+                   and typically ends at 1.4-1.6x that; a task that still outgrows its tier is redone in the next one */
+                const uint32_t est = (mx * 17u + 9u) / 10u;
+                const uint32_t tier = ((est + 1) * (mx + 1) <= 4096u && est <= 160u) ? 0u
+                                      : (est <= 256u && mx <= 255u)                 ? 1u
+                                      : (est <= 512u && mx <= 511u)                 ? 2u
+                                                                                    : 3u;
                 t.state = tier ? 2u : 0u;
                 sc.tasks[t_idx] = t;
                 if (tier) {

@@ -7,7 +7,7 @@
 
 #include "../../include/consent_amd.h"
 
-#define CW_MAX_STAGES 12
+#define CW_MAX_STAGES 14
 
 struct cw_engine {
     cw_params prm;
@@ -23,7 +23,10 @@ struct cw_engine {
     void* dev_out;
     size_t dev_out_bytes;
     /* per-stage timing of the last run */
-    hipEvent_t ev[CW_MAX_STAGES + 1];
+    hipStream_t side[3];          /* POA tiers run concurrently on their own streams */
+    hipEvent_t ev_fork, ev_join[3];
+    hipEvent_t ev0[CW_MAX_STAGES], ev1[CW_MAX_STAGES]; /* start/stop per stage, recorded on the stage's stream */
+    hipEvent_t ev_begin, ev_end;
     int n_stages;
     const char* stage_name[CW_MAX_STAGES];
     float stage_ms[CW_MAX_STAGES];

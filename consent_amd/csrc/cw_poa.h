@@ -58,6 +58,8 @@
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 #define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
+#define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
+#define CW_POA_SLAB_TOTAL(NC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + (CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
 
 template <typename HT>
 struct PoaMem {
@@ -85,16 +87,18 @@ struct PoaMem {
     uint8_t* has_out;
     uint8_t* sq;        /* current member, base codes                                                            */
     uint32_t n_cap, e_cap, l_cap, h_cap, d_cap;
+    bool runs;          /* consume runs of equal moves per round trip (pays when paths have long straight stretches) */
 };
 
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
-                                                HT* h_ext = nullptr) {
+                                                HT* h_ext = nullptr, unsigned long long* d_ext = nullptr) {
     PoaMem<HT> M;
     uint8_t* p = base;
     if (h_ext) M.H = h_ext;
     else { M.H = (HT*)p; p += (size_t)hc * sizeof(HT); }
-    M.dirs = (unsigned long long*)p; p += (size_t)dc * 16;
+    if (d_ext) M.dirs = d_ext;
+    else { M.dirs = (unsigned long long*)p; p += (size_t)dc * 16; }
     M.rmeta = (uint32_t*)p; p += 4 * nc;
     M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
     M.efrom = (uint16_t*)p; p += 2 * ec;
@@ -115,7 +119,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
     M.sq = p; p += lc + 1;
-    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc;
+    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false;
     return M;
 }
 
@@ -296,8 +300,79 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         /* ---- traceback (wave-uniform); records seqrank[j] = rank aligned to sequence position j ---- */
         {
             int i = bi, j = L;
-            if (use_dirs) {
-                /* one LDS round trip per step: the row's direction words and its first predecessor together */
+            if (use_dirs && M.runs) {
+                /* Direction words: every lane looks at the cell it would reach if the path kept going the way it starts
+                   (diagonal: (i-t, j-t); vertical: (i-t, j); horizontal: (i, j-t)) along a linear stretch of the graph
+                   (first predecessor == previous rank), so one round trip consumes a whole run of equal moves. */
+                while (i > 0) {
+                    const int t = lane;
+                    const int row = i - t;
+                    const bool rvalid = row >= 1;
+                    const int prow = rvalid ? (int)M.rpred0[row - 1] : -1;
+                    const bool linear = rvalid && prow == row - 1;
+                    int cD = 3, cV = 3, cH = 3;
+                    if (rvalid) {
+                        const int w = ((row - 1) * nch + (j >> 6)) * 2;
+                        const unsigned long long d0 = M.dirs[w], d1 = M.dirs[w + 1];
+                        cV = (int)((d0 >> (j & 63)) & 1ull) | ((int)((d1 >> (j & 63)) & 1ull) << 1);
+                        if (j - t >= 1) {
+                            const int cc = j - t;
+                            const int w2 = ((row - 1) * nch + (cc >> 6)) * 2;
+                            const unsigned long long e0 = M.dirs[w2], e1 = M.dirs[w2 + 1];
+                            cD = (int)((e0 >> (cc & 63)) & 1ull) | ((int)((e1 >> (cc & 63)) & 1ull) << 1);
+                        }
+                    }
+                    if (j - t >= 1) {
+                        const int cc = j - t;
+                        const int w3 = ((i - 1) * nch + (cc >> 6)) * 2;
+                        const unsigned long long f0 = M.dirs[w3], f1 = M.dirs[w3 + 1];
+                        cH = (int)((f0 >> (cc & 63)) & 1ull) | ((int)((f1 >> (cc & 63)) & 1ull) << 1);
+                    }
+                    const int code0 = __builtin_amdgcn_readlane(cV, 0);
+                    const int pr0 = __builtin_amdgcn_readlane(prow, 0);
+                    if (code0 == 2) {
+                        const unsigned long long bad = ~__ballot(cH == 2);
+                        const int run = bad ? (__ffsll((long long)bad) - 1) : 64;
+                        j -= run;
+                    } else if (code0 == 3) {
+                        /* several predecessors: decide from the cell values (same order of preference) */
+                        const uint32_t meta = M.rmeta[i - 1];
+                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+                        const int h = M.H[i * cols + j];
+                        int pi = i, pj = j;
+                        bool found = false;
+                        if (j != 0) {
+                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
+                            for (int q = 0; q < np && !found; ++q) {
+                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+                            }
+                        }
+                        for (int q = 0; q < np && !found; ++q) {
+                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                        }
+                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found) return 3;
+                        if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                        i = pi; j = pj;
+                    } else if (pr0 != i - 1) {
+                        /* the predecessor is not the previous rank: a single step */
+                        if (code0 == 0) { if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1); j--; }
+                        i = pr0;
+                    } else if (code0 == 0) {
+                        const unsigned long long bad = ~__ballot(cD == 0 && linear);
+                        const int run = bad ? (__ffsll((long long)bad) - 1) : 64;
+                        if (t < run) M.seqrank[j - 1 - t] = (uint16_t)(i - 1 - t);
+                        i -= run; j -= run;
+                    } else {
+                        const unsigned long long bad = ~__ballot(cV == 1 && linear);
+                        const int run = bad ? (__ffsll((long long)bad) - 1) : 64;
+                        i -= run;
+                    }
+                }
+            } else if (use_dirs) {
+                /* direction words, one step per LDS round trip: the row's words and its first predecessor together */
                 while (i > 0) {
                     const int c = j >> 6;
                     const unsigned long long d0 = M.dirs[((i - 1) * nch + c) * 2], d1 = M.dirs[((i - 1) * nch + c) * 2 + 1];
@@ -311,17 +386,16 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     } else if (code == 2) {
                         j--;
                     } else {
-                        /* several predecessors: decide from the cell values (same order of preference) */
                         const uint32_t meta = M.rmeta[i - 1];
                         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
                         const int h = M.H[i * cols + j];
                         int pi = i, pj = j;
                         bool found = false;
                         if (j != 0) {
-                            const int s = ((int)M.sq[j - 1] == base) ? MS : XS;
+                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
                             for (int q = 0; q < np && !found; ++q) {
                                 const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * cols + j - 1] + s) { pi = pr; pj = j - 1; found = true; }
+                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
                             }
                         }
                         for (int q = 0; q < np && !found; ++q) {
@@ -335,55 +409,80 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     }
                 }
             } else {
-            int h = M.H[i * cols + j];
-            uint32_t meta = M.rmeta[i - 1];
-            int pr0 = M.rpred0[i - 1];
-            while (i > 0) {
-                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                if (np == 1) {
-                    /* every candidate cell and the predecessor's metadata in one round trip */
-                    const int a = j > 0 ? (int)M.H[pr0 * cols + j - 1] : 0;
-                    const int bb = (int)M.H[pr0 * cols + j];
-                    const int c = j > 0 ? (int)M.H[i * cols + j - 1] : 0;
-                    const uint32_t metaP = pr0 > 0 ? M.rmeta[pr0 - 1] : 0u;
-                    const int p0P = pr0 > 0 ? (int)M.rpred0[pr0 - 1] : 0;
-                    const int s = (j > 0 && (int)M.sq[j - 1] == base) ? MS : XS;
-                    if (j > 0 && h == a + s) {
-                        if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
-                        i = pr0; j--; h = a; meta = metaP; pr0 = p0P;
-                    } else if (h == bb + G) {
-                        i = pr0; h = bb; meta = metaP; pr0 = p0P;
-                    } else if (j > 0 && h == c + G) {
-                        j--; h = c;
-                    } else {
-                        return 3; /* cannot happen: the matrix is self-consistent */
-                    }
-                } else {
-                    int pi = i, pj = j, nh = 0;
-                    bool found = false;
-                    if (j != 0) {
-                        const int s = ((int)M.sq[j - 1] == base) ? MS : XS;
-                        for (int q = 0; q < np && !found; ++q) {
-                            const int pr = M.plist[off + q];
-                            const int x = M.H[pr * cols + j - 1];
-                            if (h == x + s) { pi = pr; pj = j - 1; nh = x; found = true; }
+                /* no direction words (matrix lives in the slab): walk 8x8 tiles of the matrix held one cell per lane, so
+                   that up to 8 steps cost one memory round trip.  The tile's rows are the first-predecessor chain
+                   i, p(i), p(p(i)), ...; lane (tr,tc) = (lane>>3, lane&7) holds H[chain[tr]][j-tc]; lanes with tc == 0 also
+                   hold the row's metadata, lanes with tr == 0 the sequence base of the column. */
+                const int tr = lane >> 3, tc = lane & 7;
+                while (i > 0) {
+                    int ch[8];
+                    ch[0] = i;
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) ch[q] = ch[q - 1] > 0 ? (int)M.rpred0[ch[q - 1] - 1] : -1;
+                    int row = ch[0];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) row = (tr == q) ? ch[q] : row;
+                    const int col = j - tc;
+                    const bool valid = row >= 0 && col >= 0;
+                    const int hv = valid ? (int)M.H[row * cols + col] : 0;
+                    const int meta_l = (tc == 0 && row >= 1) ? (int)M.rmeta[row - 1] : 0;
+                    const int sq_l = (tr == 0 && col >= 1) ? (int)M.sq[col - 1] : 255;
+                    int ti = 0, tj = 0, ci = i;
+                    bool slow = false;
+                    for (;;) {
+                        const int cj = j - tj;
+                        if (ci == 0) break;
+                        if (ti == 7 || (tj == 7 && cj > 0)) break; /* neighbours outside the tile: fetch the next one */
+                        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(meta_l, ti * 8);
+                        const int np = (int)((meta >> 2) & 0x3FFFu), base = (int)(meta & 3u);
+                        const int up = __builtin_amdgcn_readlane(row, (ti + 1) * 8); /* first predecessor's row */
+                        const int h = __builtin_amdgcn_readlane(hv, ti * 8 + tj);
+                        const int bv = __builtin_amdgcn_readlane(hv, (ti + 1) * 8 + tj);
+                        bool moved = false;
+                        if (cj > 0) {
+                            const int sx = (__builtin_amdgcn_readlane(sq_l, tj) == base) ? MS : XS;
+                            const int av = __builtin_amdgcn_readlane(hv, (ti + 1) * 8 + tj + 1);
+                            if (h == av + sx) { /* diagonal through the first predecessor: first in the order of preference */
+                                if (lane == 0) M.seqrank[cj - 1] = (uint16_t)(ci - 1);
+                                ti++; tj++; ci = up; moved = true;
+                            }
+                        }
+                        if (!moved) {
+                            if (np != 1) { slow = true; break; } /* other predecessors come before the vertical move */
+                            if (h == bv + G) { ti++; ci = up; }
+                            else if (cj > 0 && h == __builtin_amdgcn_readlane(hv, ti * 8 + tj + 1) + G) { tj++; }
+                            else return 3;
                         }
                     }
-                    for (int q = 0; q < np && !found; ++q) {
-                        const int pr = M.plist[off + q];
-                        const int x = M.H[pr * cols + j];
-                        if (h == x + G) { pi = pr; pj = j; nh = x; found = true; }
+                    i = ci;
+                    (void)ti;
+                    j -= tj;
+                    if (slow && i > 0) {
+                        /* a node with several predecessors, or one whose predecessor is not the previous rank: one step
+                           decided from direct reads (same order of preference) */
+                        const uint32_t meta = M.rmeta[i - 1];
+                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+                        const int pr0 = M.rpred0[i - 1];
+                        const int h = M.H[i * cols + j];
+                        int pi = i, pj = j;
+                        bool found = false;
+                        if (j != 0) {
+                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
+                            for (int q = 0; q < np && !found; ++q) {
+                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+                            }
+                        }
+                        for (int q = 0; q < np && !found; ++q) {
+                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
+                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                        }
+                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found) return 3;
+                        if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
+                        i = pi; j = pj;
                     }
-                    if (!found && j != 0) {
-                        const int x = M.H[i * cols + j - 1];
-                        if (h == x + G) { pi = i; pj = j - 1; nh = x; found = true; }
-                    }
-                    if (!found) return 3;
-                    if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
-                    if (pi != i && pi > 0) { meta = M.rmeta[pi - 1]; pr0 = M.rpred0[pi - 1]; }
-                    i = pi; j = pj; h = nh;
                 }
-            }
             }
             /* i == 0: the remaining sequence positions are insertions, already CW_NONE16 */
         }
@@ -591,8 +690,8 @@ __device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, c
 __device__ __forceinline__ void poa_hand_over(const DevScratch& sc, const PoaTask& t, uint32_t ti, int rc, int next_tier) {
     /* lane 0 only: rc 2 = this tier's capacity was exceeded -> next tier; rc 3 = output capacity / internal -> window overflow */
     if (rc == 2 && next_tier < CW_TIERS) {
-        const uint32_t bi = atomicAdd(&sc.ctr->n_tier[next_tier], 1u);
-        if (bi < sc.list_cap) sc.tier_list[next_tier][bi] = ti;
+        const uint32_t bi = atomicAdd(&sc.ctr->n_over[next_tier], 1u);
+        if (bi < sc.list_cap) sc.over_list[next_tier][bi] = ti;
         else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
     } else if (rc != 1) {
         sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
@@ -615,34 +714,40 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         const PoaTask t = sc.tasks[ti];
         if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
         const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
-        if (lane == 0) poa_hand_over(sc, t, ti, rc, 1);
+        if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
         cw_wave_sync();
     }
     poa_flush_prof(sc, 8, acc, lane);
 }
 
 /* ---- tiers M1 / M2 / L: graph in LDS, DP matrix in this wave's global slab ------------------------ */
-template <int NC, int EC, int LC, int WAVES, int TIER>
+/* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
+   streams); PASS 1, after those have finished, through the tasks that outgrew the tier below. */
+template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
 __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = blockIdx.x * WAVES + wave;
     if (gw >= sc.slots[TIER]) return;
-    int16_t* hslab = (int16_t*)(sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER]);
+    uint8_t* my_slab = sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER];
+    int16_t* hslab = (int16_t*)my_slab;
+    unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     constexpr uint32_t slab = CW_POA_GRAPH_BYTES(NC, EC, LC);
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), 0, hslab);
-    const uint32_t* list = sc.tier_list[TIER];
-    const uint32_t n_work = min(sc.ctr->n_tier[TIER], sc.list_cap);
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab);
+    M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
+    const uint32_t* list = PASS ? sc.over_list[TIER] : sc.tier_list[TIER];
+    const uint32_t n_work = min(PASS ? sc.ctr->n_over[TIER] : sc.ctr->n_tier[TIER], sc.list_cap);
+    uint32_t* cursor = PASS ? &sc.ctr->next_over[TIER] : &sc.ctr->next_tier[TIER];
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t mi = 0;
-        if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER], 1u);
+        if (lane == 0) mi = atomicAdd(cursor, 1u);
         mi = (uint32_t)__shfl((int)mi, 0);
         if (mi >= n_work) break;
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
-        if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER + 1);
+        if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
     }
     poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
@@ -654,14 +759,14 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch 
     const uint32_t gw = blockIdx.x * CW_POA_WAVES + (threadIdx.x >> 6);
     if (gw >= sc.slots[4]) return;
     const PoaMem<int32_t> M = poa_carve<int32_t>(sc.slab[4] + (size_t)gw * sc.slab_bytes[4], CW_POAB_NC, CW_POAB_EC, CW_POAB_LC, CW_POAB_HC, 0);
-    const uint32_t n_big = min(sc.ctr->n_tier[4], sc.list_cap);
+    const uint32_t n_big = min(sc.ctr->n_over[4], sc.list_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t bi = 0;
-        if (lane == 0) bi = atomicAdd(&sc.ctr->next_tier[4], 1u);
+        if (lane == 0) bi = atomicAdd(&sc.ctr->next_over[4], 1u);
         bi = (uint32_t)__shfl((int)bi, 0);
         if (bi >= n_big) break;
-        const uint32_t ti = sc.tier_list[4][bi];
+        const uint32_t ti = sc.over_list[4][bi];
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int32_t>(M, t, b, sc, lane, acc);
         if (lane == 0) poa_hand_over(sc, t, ti, rc, CW_TIERS);

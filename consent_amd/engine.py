@@ -269,7 +269,7 @@ class Engine:
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
     def profile(self):
-        c = np.zeros(16, np.uint32)
+        c = np.zeros(26, np.uint32)
         p = np.zeros(32, np.uint64)
         _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
         return c, p

@@ -112,10 +112,10 @@ int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n
  * arena_base, arena_cap, arena_used, 3 reserved. */
 int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16);
 
-/* Inspection aid: 16 batch counters (uint32: tasks, members, next_task, next_window, next_finish, any_overflow,
- * n_tier[5], next_tier[5]) and 32 per-phase GPU cycle totals of the last run (index kernel 0-6; POA tier t at 8+5t..12+5t:
+/* Inspection aid: 26 batch counters (uint32: tasks, members, next_task, next_window, next_finish, any_overflow,
+ * n_tier[5], next_tier[5], n_over[5], next_over[5]) and 32 per-phase GPU cycle totals of the last run (index kernel 0-6; POA tier t at 8+5t..12+5t:
  * metadata, fill, traceback, merge, consensus). */
-int cw_debug_profile(cw_engine* e, uint32_t* counters16, unsigned long long* prof32);
+int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* prof32);
 
 /* Pack one ASCII window pile (n strings, lens[i] bytes each, not NUL-terminated) at the tail of host
  * arrays laid out as cw_batch.  words_cap counts 32-bit words available at bases_out.  Returns the
