@@ -214,54 +214,69 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             continue;
         }
-        /* export the solid set in ascending key order */
+        /* export the solid set in ascending key order.  Thread t owns the contiguous words [t*wpt, (t+1)*wpt) (so thread
+           order = key order) but visits them rotated by t, which spreads a wave's reads over all LDS banks; the few
+           solid keys it finds are kept in registers, ranked locally, and written after one block-wide prefix sum. */
         {
-            const uint32_t wpt = (nib_words + CW_IDX_THREADS - 1) / CW_IDX_THREADS;
-            const uint32_t w_beg = min(nib_words, tid * wpt), w_end = min(nib_words, w_beg + wpt);
             const uint32_t keys_per_word = n_keys >= 8 ? 8 : n_keys;
+            const uint32_t wpt = (nib_words + CW_IDX_THREADS - 1) / CW_IDX_THREADS;
+            const uint32_t w_beg = min(nib_words, (uint32_t)tid * wpt), w_cnt = min(nib_words, w_beg + wpt) - w_beg;
+            uint32_t lk[8], lc[8];
             uint32_t mine = 0;
-            for (uint32_t wd = w_beg; wd < w_end; ++wd) {
+            for (uint32_t i = 0; i < w_cnt; ++i) {
+                uint32_t r = i + (uint32_t)tid;
+                r = r >= w_cnt ? r % w_cnt : r;
+                const uint32_t wd = w_beg + r;
                 const uint32_t v = tab[wd];
-                for (uint32_t i = 0; i < keys_per_word; ++i) {
-                    const uint32_t nib = (v >> (4 * i)) & 15u;
-                    if (nib == 15u || nib >= prm.solid) mine++; /* nib==15: exact count checked below */
-                }
-            }
-            /* keys with nib==15 have count >= 15; they are solid iff exact >= solid; cheap to resolve now */
-            if (prm.solid > 15) {
-                mine = 0;
-                for (uint32_t wd = w_beg; wd < w_end; ++wd) {
-                    const uint32_t v = tab[wd];
-                    for (uint32_t i = 0; i < keys_per_word; ++i) {
-                        if (((v >> (4 * i)) & 15u) != 15u) continue;
-                        const uint32_t key = wd * 8 + i;
+                if (v == 0) continue;
+                for (uint32_t q = 0; q < keys_per_word; ++q) {
+                    const uint32_t nib = (v >> (4 * q)) & 15u;
+                    if (!nib) continue;
+                    const uint32_t key = wd * 8 + q;
+                    uint32_t c = nib;
+                    if (nib == 15u) {
                         uint32_t slot = cw_hash32(key) >> (32 - 11);
                         while ((uint32_t)(ex[slot] >> 32) != key + 1) slot = (slot + 1) & (CW_EX_SLOTS - 1);
-                        if ((uint32_t)ex[slot] >= prm.solid) mine++;
+                        c = (uint32_t)ex[slot];
                     }
+                    if (c < prm.solid) continue;
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) if ((uint32_t)z == mine) { lk[z] = key; lc[z] = c; }
+                    mine++;
                 }
             }
+            if (mine > 8) flags[1] = 1; /* more than the register slots hold: the whole block re-walks in key order */
             uint32_t total;
             const uint32_t off = cw_block_exscan(mine, scan_tmp, &total);
             const bool fits = total <= wi->solid_cap;
-            if (fits) {
+            if (fits && flags[1]) {
                 uint32_t o = wi->solid_base + off;
-                for (uint32_t wd = w_beg; wd < w_end; ++wd) {
+                for (uint32_t i = 0; i < w_cnt && mine; ++i) {
+                    const uint32_t wd = w_beg + i;
                     const uint32_t v = tab[wd];
-                    for (uint32_t i = 0; i < keys_per_word; ++i) {
-                        const uint32_t nib = (v >> (4 * i)) & 15u;
-                        if (nib < 15u && nib < prm.solid) continue;
-                        const uint32_t key = wd * 8 + i;
-                        uint32_t cnt = nib;
+                    if (v == 0) continue;
+                    for (uint32_t q = 0; q < keys_per_word; ++q) {
+                        const uint32_t nib = (v >> (4 * q)) & 15u;
+                        if (!nib) continue;
+                        const uint32_t key = wd * 8 + q;
+                        uint32_t c = nib;
                         if (nib == 15u) {
                             uint32_t slot = cw_hash32(key) >> (32 - 11);
                             while ((uint32_t)(ex[slot] >> 32) != key + 1) slot = (slot + 1) & (CW_EX_SLOTS - 1);
-                            cnt = (uint32_t)ex[slot];
+                            c = (uint32_t)ex[slot];
                         }
-                        if (cnt < prm.solid) continue;
-                        sc.solid_key[o] = key;
-                        sc.solid_cnt[o] = cnt;
-                        o++;
+                        if (c >= prm.solid) { sc.solid_key[o] = key; sc.solid_cnt[o] = c; o++; }
+                    }
+                }
+            } else if (fits && mine) {
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    if ((uint32_t)z < mine) {
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) rank += ((uint32_t)y < mine && lk[y] < lk[z]) ? 1u : 0u;
+                        sc.solid_key[wi->solid_base + off + rank] = lk[z];
+                        sc.solid_cnt[wi->solid_base + off + rank] = lc[z];
                     }
                 }
             }
@@ -356,6 +371,58 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         }
         __syncthreads();
 
+        /* A sequence whose anchor positions increase with the anchor index ("clean") satisfies pos(a) < pos(b) for every
+           pair a < b it holds, so its contribution to score(a,b) is one bit of presence(a) & presence(b); only the few
+           sequences with an out-of-order (spurious) anchor hit need their positions compared.  Exact, and ~20x cheaper
+           than comparing positions for all N sequences. */
+        const uint32_t Nw = (N + 63u) >> 6;
+        uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available) */
+        unsigned long long* pres = (unsigned long long*)(P + (((size_t)A * Np + 3u) & ~(size_t)3u)); /* A x Nw, 8-byte aligned */
+        uint16_t* dirty = (uint16_t*)(pres + (size_t)A * Nw);          /* up to N ids */
+        const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_LDS_BYTES);
+        if (use_bits) {
+            for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
+                int run = -1;
+                bool bad = false;
+                for (uint32_t a0 = 0; a0 < A; a0 += 64) {
+                    const uint32_t a = a0 + lane;
+                    const uint32_t pv = a < A ? (uint32_t)P[a * Np + s] : (uint32_t)CW_NONE16;
+                    const int v = pv != CW_NONE16 ? (int)pv : -1;
+                    const int inc = cw_wave_scan_max(v);
+                    int before = cw_wave_shr1(inc, -1);
+                    before = max(before, run);
+                    bad = bad || (__ballot(v >= 0 && v <= before) != 0ull);
+                    run = max(run, cw_lane_value(inc, 63));
+                }
+                if (lane == 0) clean[s] = bad ? 0 : 1;
+            }
+            if (tid == 0) misc[3] = 0;
+            __syncthreads();
+            for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
+                for (uint32_t w = 0; w < Nw; ++w) {
+                    const uint32_t s = w * 64 + lane;
+                    const bool on = s < N && P[a * Np + s] != CW_NONE16 && clean[s];
+                    const unsigned long long bal = __ballot(on);
+                    if (lane == 0) pres[(size_t)a * Nw + w] = bal;
+                }
+            }
+            for (uint32_t s = tid; s < N; s += CW_IDX_THREADS)
+                if (!clean[s]) dirty[atomicAdd(&misc[3], 1u)] = (uint16_t)s;
+            __syncthreads();
+            /* the dirty list must not depend on thread timing: sort the few ids (insertion sort by one thread) */
+            if (tid == 0) {
+                const uint32_t nd = misc[3];
+                for (uint32_t x = 1; x < nd; ++x) {
+                    const uint16_t v = dirty[x];
+                    uint32_t y = x;
+                    while (y > 0 && dirty[y - 1] > v) { dirty[y] = dirty[y - 1]; --y; }
+                    dirty[y] = v;
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t n_dirty = use_bits ? misc[3] : 0u;
+
         CW_PROF(sc.ctr, 4, tid == 0);
         /* ================= phase C: chain ================= */
         /* best(a) for a = A-1 .. 0 by one wave: lanes score 64 successors b > a at a time against all N sequences,
@@ -374,13 +441,22 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     unsigned long long key = 0ull;
                     if (bb < A) {
                         uint32_t cnt = 0;
-                        const uint32_t* pb_row = (const uint32_t*)(P + bb * Np);
+                        if (use_bits) {
+                            for (uint32_t w = 0; w < Nw; ++w) cnt += (uint32_t)__popcll(pres[(size_t)a * Nw + w] & pres[(size_t)bb * Nw + w]);
+                            for (uint32_t d = 0; d < n_dirty; ++d) {
+                                const uint32_t sd = dirty[d];
+                                const uint32_t pa = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                            }
+                        } else {
+                            const uint32_t* pb_row = (const uint32_t*)(P + bb * Np);
 #pragma unroll 8
-                        for (uint32_t s = 0; s < half; ++s) {
-                            const uint32_t va = pa_row[s], vb = pb_row[s];
-                            const uint32_t a0 = va & 0xFFFFu, a1 = va >> 16, b0_ = vb & 0xFFFFu, b1_ = vb >> 16;
-                            cnt += (a0 < b0_ && b0_ != CW_NONE16) ? 1u : 0u;
-                            cnt += (a1 < b1_ && b1_ != CW_NONE16) ? 1u : 0u;
+                            for (uint32_t s = 0; s < half; ++s) {
+                                const uint32_t va = pa_row[s], vb = pb_row[s];
+                                const uint32_t a0 = va & 0xFFFFu, a1 = va >> 16, b0_ = vb & 0xFFFFu, b1_ = vb >> 16;
+                                cnt += (a0 < b0_ && b0_ != CW_NONE16) ? 1u : 0u;
+                                cnt += (a1 < b1_ && b1_ != CW_NONE16) ? 1u : 0u;
+                            }
                         }
                         if ((int)cnt >= sup_min)
                             key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
