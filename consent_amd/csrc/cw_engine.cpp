@@ -7,11 +7,13 @@
 #include "cw_index.h"
 #include "cw_poa.h"
 #include "cw_finish.h"
+#include "cw_extract.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -157,6 +159,7 @@ void cw_destroy(cw_engine* e) {
     if (e->scratch) (void)hipFree(e->scratch);
     if (e->dev_in) (void)hipFree(e->dev_in);
     if (e->dev_out) (void)hipFree(e->dev_out);
+    if (e->xscratch) (void)hipFree(e->xscratch);
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
     for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -306,6 +309,53 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
     memcpy(counters26, &c, 26 * 4);
     memcpy(prof32, c.prof, sizeof(c.prof));
+    return CW_OK;
+}
+
+int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps,
+                            const cw_window_job* jobs, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len,
+                            uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
+                            uint64_t* n_words, void* hip_stream) {
+    if (!e || !reads || !jobs || !n_seqs || !n_words || (n_overlaps && !overlaps) || k < 1) return CW_E_INVALID;
+    *n_seqs = 0; *n_words = 0;
+    if (n_jobs == 0) return CW_OK;
+    CW_HIP(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    /* per-window descriptor offsets need the jobs' overlap counts: take them from the device once */
+    std::vector<cw_window_job> hj;
+    try { hj.resize(n_jobs); } catch (...) { return CW_E_NOMEM; }
+    CW_HIP(hipMemcpyAsync(hj.data(), jobs, (size_t)n_jobs * sizeof(cw_window_job), hipMemcpyDeviceToHost, st));
+    CW_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> doff(n_jobs + 1, 0);
+    for (uint32_t w = 0; w < n_jobs; ++w) {
+        if ((uint64_t)hj[w].ovl_first + hj[w].ovl_count > n_overlaps || hj[w].tpl_read >= reads->n_reads || hj[w].q_end < hj[w].q_beg) return CW_E_INVALID;
+        doff[w + 1] = doff[w] + hj[w].ovl_count;
+    }
+    size_t o = 0;
+    auto put = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t o_desc = put((size_t)doff[n_jobs] * sizeof(ExtractDesc) + 16), o_doff = put((size_t)(n_jobs + 1) * 8),
+                 o_ws = put((size_t)(n_jobs + 1) * 4), o_ww = put((size_t)(n_jobs + 1) * 8), o_st = put(16);
+    int rc = ensure(&e->xscratch, &e->xscratch_bytes, o);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)e->xscratch;
+    CW_HIP(hipMemcpyAsync(base + o_doff, doff.data(), (size_t)(n_jobs + 1) * 8, hipMemcpyHostToDevice, st));
+    CW_HIP(hipMemsetAsync(base + o_st, 0, 16, st));
+    ExtractArgs a;
+    a.reads = *reads; a.ovl = overlaps; a.jobs = jobs; a.n_jobs = n_jobs; a.k = k;
+    a.desc = (ExtractDesc*)(base + o_desc); a.desc_off = (const uint64_t*)(base + o_doff);
+    a.win_seqs = (uint32_t*)(base + o_ws); a.win_words = (uint64_t*)(base + o_ww);
+    a.win_first_seq = win_first_seq; a.seq_len = seq_len; a.seq_word_off = seq_word_off; a.bases = bases;
+    a.seq_cap = seq_cap; a.word_cap = word_cap; a.status = (uint32_t*)(base + o_st);
+    cw_extract_count_kernel<<<(n_jobs + 3) / 4, 256, 0, st>>>(a);
+    cw_extract_scan_kernel<<<1, 1024, 0, st>>>(a);
+    uint32_t tot_s = 0; uint64_t tot_w = 0;
+    CW_HIP(hipMemcpyAsync(&tot_s, a.win_seqs + n_jobs, 4, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipMemcpyAsync(&tot_w, a.win_words + n_jobs, 8, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipStreamSynchronize(st));
+    *n_seqs = tot_s; *n_words = tot_w;
+    if (tot_s > seq_cap || tot_w > word_cap || !win_first_seq || !seq_len || !seq_word_off || !bases) return CW_E_CAPACITY;
+    cw_extract_fill_kernel<<<(n_jobs + 1 + 3) / 4, 256, 0, st>>>(a);
+    CW_HIP(hipGetLastError());
     return CW_OK;
 }
 

@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
         int len = 0;
         M.s = buf0; M.alt = buf1;
 
-        if (status == CW_WIN_TEMPLATE) { /* correctionMSA.cpp:34-36: the raw template */
+        if (status == CW_WIN_TEMPLATE && wi.n_seqs == 0) {
+            len = 0; /* a window beyond its template has an empty pile (alignmentWindows.cpp:95-97) */
+        } else if (status == CW_WIN_TEMPLATE) { /* correctionMSA.cpp:34-36: the raw template */
             const uint32_t* words = b.bases + b.seq_word_off[s0];
             if (wi.tpl_len > o_cap) status = CW_WIN_OVERFLOW;
             else {

@@ -46,6 +46,10 @@ class Result(C.Structure):
     ]
 
 
+class ReadSet(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("read_len", C.c_void_p), ("read_word_off", C.c_void_p), ("bases", C.c_void_p)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64),
@@ -81,6 +85,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    try:  # PyTorch-ROCm ships its own HIP runtime: let it initialise first so both sides share one runtime and one context
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     p = lib_path()
     if not os.path.exists(p):
         raise EngineError(f"{p} is missing: build it with `python -m consent_amd._build` (hipcc --offload-arch=gfx950)")
@@ -96,6 +107,8 @@ def load_library():
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cw_extract_piles_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
     lib.cw_synth_sizes.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -260,6 +273,37 @@ class Engine:
 
     def run_device(self, batch_struct, result_struct, stream=None):
         _check(self.lib, self.lib.cw_run_device(self.handle, C.byref(batch_struct), C.byref(result_struct), stream), "cw_run_device")
+
+    def extract_piles(self, reads, overlaps, jobs, k):
+        """Device-side getAlignmentWindowsSequences (cw_extract_piles_device).  `reads` is a HostBatch-like packing of the read
+        set (one "window" holding every read), `overlaps` an (n,6) uint32 array (q_start, q_end, t_read, t_start, t_end, strand;
+        ends inclusive), `jobs` an (m,5) uint32 array (tpl_read, q_beg, q_end, ovl_first, ovl_count).  Returns a HostBatch."""
+        import torch
+
+        dev = torch.device("cuda", 0)
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+
+        t_len, t_off, t_bases = up(reads.seq_len, np.int32), up(reads.seq_word_off, np.int64), up(np.concatenate([reads.bases, np.zeros(1, np.uint32)]), np.int32)
+        ov = np.ascontiguousarray(overlaps, np.uint32).reshape(-1, 6)
+        jb = np.ascontiguousarray(jobs, np.uint32).reshape(-1, 5)
+        t_ov = up(ov if len(ov) else np.zeros((1, 6), np.uint32), np.int32)
+        t_jb = up(jb, np.int32)
+        rs = ReadSet(len(reads.seq_len), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr())
+        ns, nw = C.c_uint32(), C.c_uint64()
+        rc = self.lib.cw_extract_piles_device(self.handle, C.byref(rs), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), len(jb), k, None, None, None, None, 0, 0, C.byref(ns), C.byref(nw), None)
+        if rc not in (0, -4):
+            _check(self.lib, rc, "cw_extract_piles_device(size)")
+        o_wfs = torch.zeros(len(jb) + 1, dtype=torch.int32, device=dev)
+        o_len = torch.zeros(max(ns.value, 1), dtype=torch.int32, device=dev)
+        o_off = torch.zeros(max(ns.value, 1), dtype=torch.int64, device=dev)
+        o_bases = torch.zeros(max(nw.value, 1) + 1, dtype=torch.int32, device=dev)
+        _check(self.lib, self.lib.cw_extract_piles_device(self.handle, C.byref(rs), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), len(jb), k, o_wfs.data_ptr(), o_len.data_ptr(),
+                                                          o_off.data_ptr(), o_bases.data_ptr(), ns.value, nw.value, C.byref(ns), C.byref(nw), None), "cw_extract_piles_device")
+        torch.cuda.synchronize()
+        return HostBatch(o_wfs.cpu().numpy().view(np.uint32), o_len.cpu().numpy().view(np.uint32)[: ns.value], o_off.cpu().numpy().view(np.uint64)[: ns.value],
+                         o_bases.cpu().numpy().view(np.uint32)[: max(nw.value, 1)])
 
     def timings(self):
         ms = (C.c_float * 16)()

@@ -9,7 +9,8 @@
  *                               i.e. MSABMAAC (call sites correctionMSA.cpp:32,54) + weightConsensus
  *                               (correctionMSA.cpp:6-27) + polishCorrection (correctionDBG.h:11)
  *                               -- batched over windows, because one window per call cannot feed a GPU.
- *   cw_pack_window           <- the vector<string> pile handed to those operators
+ *   cw_extract_piles_device  <- getAlignmentWindowsSequences (alignmentWindows.cpp:87-149) evaluated on the device
+ *   cw_pack_sequence         <- the vector<string> pile handed to those operators
  *                               (CONSENT-correction.cpp:35-37, CONSENT-polishing.cpp:46-49): 2-bit packing
  *                               with the reference's own alphabet (utils.cpp:21-32: A=00 C=01 G=10 else=11).
  *
@@ -121,6 +122,39 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
  * arrays laid out as cw_batch.  words_cap counts 32-bit words available at bases_out.  Returns the
  * number of words written, or a negative cw_status.  Non-ACGT bytes pack as T (utils.cpp:28). */
 int64_t cw_pack_sequence(const char* seq, uint32_t len, uint32_t* bases_out, uint64_t words_cap);
+
+/* ---- device-side pile extraction ------------------------------------------------------------------
+ * Stands in for getAlignmentWindowsSequences (src/alignmentWindows.cpp:87-149) + the read decoding of getSequencesMap
+ * (src/alignmentPiles.cpp:5-20): piles are cut on the GPU from the 2-bit read set and the overlap tuples. */
+typedef struct cw_read_set {      /* the indexed reads (utils.cpp:166-205), 2-bit packed like cw_batch.bases */
+    uint32_t n_reads;
+    const uint32_t* read_len;      /* [n_reads] */
+    const uint64_t* read_word_off; /* [n_reads] */
+    const uint32_t* bases;
+} cw_read_set;
+
+typedef struct cw_overlap {        /* one PAF record after Overlap(std::string) (src/Overlap.h:26-58): ends INCLUSIVE */
+    uint32_t q_start, q_end;
+    uint32_t t_read;               /* index of the target read in the read set (its length is tLength)             */
+    uint32_t t_start, t_end;
+    uint32_t strand;               /* 0 '+', 1 '-' */
+} cw_overlap;
+
+typedef struct cw_window_job {     /* one window of one template (pilesPos[i], CONSENT-correction.cpp:35)            */
+    uint32_t tpl_read;
+    uint32_t q_beg, q_end;         /* inclusive */
+    uint32_t ovl_first, ovl_count; /* the template's pile in `overlaps`, in getNextReadPile order                    */
+} cw_window_job;
+
+/* All pointers are DEVICE pointers (read set, overlaps, jobs, and the four output arrays laid out as cw_batch:
+ * win_first_seq[n_jobs+1], seq_len[seq_cap], seq_word_off[seq_cap], bases[word_cap]).  On return *n_seqs / *n_words hold
+ * the totals (the call synchronises once to read them); CW_E_CAPACITY if they exceed the capacities -- call again with
+ * larger arrays (capacities 0 just size the batch).  A window beyond its template (alignmentWindows.cpp:95-97) or a
+ * piece shorter than k (:141) yields no member, as in the reference. */
+int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps,
+                            const cw_window_job* jobs, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len,
+                            uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
+                            uint64_t* n_words, void* hip_stream);
 
 /* ---- synthetic PacBio/ONT-profile piles (bench + tests; SURVEY 8d generator) --------------------- */
 typedef struct cw_synth_spec {
