@@ -205,8 +205,132 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
     cw_wave_sync();
 }
 
+/* ---- packed int16 arithmetic: two DP columns per lane (VOP3P v_pk_add/sub/max_i16) ------------------------------ */
+typedef short cw_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (cw_s2)(__builtin_bit_cast(cw_s2, a) + __builtin_bit_cast(cw_s2, b))); }
+__device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (cw_s2)(__builtin_bit_cast(cw_s2, a) - __builtin_bit_cast(cw_s2, b))); }
+__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_s2, a), __builtin_bit_cast(cw_s2, b))); }
+__device__ __forceinline__ int pk_make(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
+#define CW_NEG16 (-30000)
+#define CW_NEGPK ((int)0x8AD08AD0) /* (CW_NEG16, CW_NEG16) */
+
+/* inclusive prefix max over lanes of a packed pair (both halves scanned independently) */
+__device__ __forceinline__ int pk_wave_scan_max(int v) {
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x111, 0xF));
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x112, 0xF));
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x114, 0xF));
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x118, 0xF));
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x142, 0xA));
+    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x143, 0xC));
+    return v;
+}
+
+/* direction-word addressing: unpacked rows hold 2 words per 64 columns; packed rows 4 words per 128 columns
+   (even columns, odd columns) x (low bit, high bit), bit = lane that owns the column pair */
+__device__ __forceinline__ int poa_dir_code(const unsigned long long* dirs, int r, int c, int nch, bool packed) {
+    if (!packed) {
+        const int w = (r * nch + (c >> 6)) * 2;
+        return (int)((dirs[w] >> (c & 63)) & 1ull) | ((int)((dirs[w + 1] >> (c & 63)) & 1ull) << 1);
+    }
+    const int w = (r * nch + (c >> 7)) * 4 + (c & 1) * 2, bit = (c & 127) >> 1;
+    return (int)((dirs[w] >> bit) & 1ull) | ((int)((dirs[w + 1] >> bit) & 1ull) << 1);
+}
+
+/*
+ * Packed DP fill for rows of more than 64 columns in the int16 tiers: NCH2 chunks of 128 columns, lane l of chunk c owns
+ * columns 128c+2l (low half) and 128c+2l+1 (high half).  The diagonal operand is one v_alignbit of the row above with
+ * its wave_shr:1 copy; the horizontal recurrence is an in-lane step plus a packed DPP prefix max.  Row stride hs is even
+ * so that a lane's pair is one aligned 32-bit access.  |values| stay far from the int16 range (CW_NEG16 headroom).
+ */
+template <int NCH2>
+__device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int n, const int cols, const int hs, const int lane,
+                                            const bool use_dirs) {
+    const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
+    const int GPK = pk_make(G, G);
+    const int nch = (cols + 127) >> 7;
+    int prev[NCH2], jg[NCH2], amask[NCH2], sc_[NCH2][4];
+    int* Hw = (int*)M.H;
+#pragma unroll
+    for (int c = 0; c < NCH2; ++c) {
+        const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
+        jg[c] = pk_make(j0 * G, j1 * G);
+        prev[c] = jg[c]; /* row 0 */
+        amask[c] = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
+        const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) sc_[c][bb] = pk_make(q0 == bb ? MS : XS, q1 == bb ? MS : XS);
+    }
+    uint32_t meta_n = M.rmeta[0];
+    uint32_t pr0_n = M.rpred0[0];
+    for (int r = 0; r < n; ++r) {
+        const int i = r + 1;
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
+        const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
+        if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
+        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+        int v[NCH2], dgv[NCH2], upv[NCH2];
+#pragma unroll
+        for (int c = 0; c < NCH2; ++c) { v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK; }
+        for (int q = 0; q < np; ++q) {
+            const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
+            int up[NCH2];
+            if (prow == i - 1) {
+#pragma unroll
+                for (int c = 0; c < NCH2; ++c) up[c] = prev[c];
+            } else {
+                cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
+#pragma unroll
+                for (int c = 0; c < NCH2; ++c) {
+                    const int j0 = c * 128 + 2 * lane;
+                    up[c] = (j0 < cols) ? Hw[(prow * hs + j0) >> 1] : CW_NEGPK;
+                }
+            }
+            int carry_in = CW_NEGPK;
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) {
+                const int sh = CW_DPP(carry_in, up[c], 0x138, 0xF);       /* lane l-1's pair; lane 0: last pair of the chunk before */
+                carry_in = cw_lane_value(up[c], 63);
+                const int dg = __builtin_amdgcn_alignbit(up[c], sh, 16);   /* (col 2l-1, col 2l) of the row above */
+                const int s = base == 0 ? sc_[c][0] : base == 1 ? sc_[c][1] : base == 2 ? sc_[c][2] : sc_[c][3];
+                dgv[c] = pk_add(dg, s); upv[c] = pk_add(up[c], GPK);
+                v[c] = pk_max(v[c], pk_max(dgv[c], upv[c]));
+            }
+        }
+        int carry = CW_NEGPK;
+#pragma unroll
+        for (int c = 0; c < NCH2; ++c) {
+            int w = pk_sub(v[c], jg[c]);
+            w = (w & amask[c]) | (CW_NEGPK & ~amask[c]);
+            w = pk_max(w, (w << 16) | 0x8AD0);                                   /* odd column sees the even one of its lane */
+            const int tot = __builtin_amdgcn_perm(w, w, 0x07060706);             /* (hi, hi): the lane's running max */
+            const int inc = pk_wave_scan_max(tot);
+            int ex = CW_DPP(carry, inc, 0x138, 0xF);                              /* exclusive: lanes before this one (+ chunks before) */
+            ex = pk_max(ex, carry);
+            w = pk_max(w, ex);
+            carry = cw_lane_value(pk_max(inc, carry), 63);
+            prev[c] = pk_add(w, jg[c]);
+            const int j0 = c * 128 + 2 * lane;
+            if (j0 < cols) Hw[(i * hs + j0) >> 1] = prev[c];
+            if (use_dirs && c < nch) {
+                int ce = 3, co = 3;
+                if (np == 1) {
+                    const int xd = prev[c] ^ dgv[c], xu = prev[c] ^ upv[c];
+                    ce = (j0 > 0 && (xd & 0xFFFF) == 0) ? 0 : ((xu & 0xFFFF) == 0) ? 1 : 2;
+                    co = (((unsigned)xd >> 16) == 0u) ? 0 : (((unsigned)xu >> 16) == 0u) ? 1 : 2;
+                }
+                const unsigned long long e0 = __ballot(ce & 1), e1 = __ballot(ce >> 1), o0 = __ballot(co & 1), o1 = __ballot(co >> 1);
+                if (lane == 0) {
+                    unsigned long long* d = M.dirs + (size_t)(r * nch + c) * 4;
+                    d[0] = e0; d[1] = e1; d[2] = o0; d[3] = o1;
+                }
+            }
+        }
+    }
+    cw_wave_sync();
+}
+
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
-template <typename HT>
+template <typename HT, bool PK>
 __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
                        unsigned long long (&acc)[6]) {
     unsigned long long _pt = __builtin_readcyclecounter();
@@ -240,7 +364,9 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             continue;
         }
         const int cols = L + 1;
-        if ((uint32_t)((n + 1) * cols) > M.h_cap) return 2;
+        const bool packed = PK && cols > 64;                 /* two columns per lane (int16 tiers, wide rows) */
+        const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
+        if ((uint32_t)((n + 1) * hs) > M.h_cap) return 2;
 
         /* ---- per-rank metadata (parallel over ranks) ---- */
         if (!meta_ok) {
@@ -272,13 +398,20 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         for (int j = lane; j < L; j += 64) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
-        const int nch = (cols + 63) >> 6;
-        const bool use_dirs = (uint32_t)(n * nch) <= M.d_cap;
-        if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
-        else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
-        else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
-        else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
-        else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
+        const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
+        const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
+        if constexpr (PK) {
+            if (!packed) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+            else if (cols <= 128) poa_fill_pk<1>(M, n, cols, hs, lane, use_dirs);
+            else if (cols <= 256) poa_fill_pk<2>(M, n, cols, hs, lane, use_dirs);
+            else poa_fill_pk<4>(M, n, cols, hs, lane, use_dirs);
+        } else {
+            if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+            else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
+            else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
+            else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
+            else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
+        }
         POA_PROF(1);
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
@@ -287,7 +420,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             int bs = CW_NEG * 2, br = 0x7FFFFFFF;
             for (int r = lane; r < n; r += 64) {
                 if (M.has_out[M.r2n[r]]) continue;
-                const int h = M.H[(r + 1) * cols + L];
+                const int h = M.H[(r + 1) * hs + L];
                 if (h > bs) { bs = h; br = r; } /* ranks ascend within a lane */
             }
             for (int o = 32; o > 0; o >>= 1) {
@@ -312,22 +445,10 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     const bool linear = rvalid && prow == row - 1;
                     int cD = 3, cV = 3, cH = 3;
                     if (rvalid) {
-                        const int w = ((row - 1) * nch + (j >> 6)) * 2;
-                        const unsigned long long d0 = M.dirs[w], d1 = M.dirs[w + 1];
-                        cV = (int)((d0 >> (j & 63)) & 1ull) | ((int)((d1 >> (j & 63)) & 1ull) << 1);
-                        if (j - t >= 1) {
-                            const int cc = j - t;
-                            const int w2 = ((row - 1) * nch + (cc >> 6)) * 2;
-                            const unsigned long long e0 = M.dirs[w2], e1 = M.dirs[w2 + 1];
-                            cD = (int)((e0 >> (cc & 63)) & 1ull) | ((int)((e1 >> (cc & 63)) & 1ull) << 1);
-                        }
+                        cV = poa_dir_code(M.dirs, row - 1, j, nch, packed);
+                        if (j - t >= 1) cD = poa_dir_code(M.dirs, row - 1, j - t, nch, packed);
                     }
-                    if (j - t >= 1) {
-                        const int cc = j - t;
-                        const int w3 = ((i - 1) * nch + (cc >> 6)) * 2;
-                        const unsigned long long f0 = M.dirs[w3], f1 = M.dirs[w3 + 1];
-                        cH = (int)((f0 >> (cc & 63)) & 1ull) | ((int)((f1 >> (cc & 63)) & 1ull) << 1);
-                    }
+                    if (j - t >= 1) cH = poa_dir_code(M.dirs, i - 1, j - t, nch, packed);
                     const int code0 = __builtin_amdgcn_readlane(cV, 0);
                     const int pr0 = __builtin_amdgcn_readlane(prow, 0);
                     if (code0 == 2) {
@@ -338,21 +459,21 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                         /* several predecessors: decide from the cell values (same order of preference) */
                         const uint32_t meta = M.rmeta[i - 1];
                         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                        const int h = M.H[i * cols + j];
+                        const int h = M.H[i * hs + j];
                         int pi = i, pj = j;
                         bool found = false;
                         if (j != 0) {
                             const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
                             for (int q = 0; q < np && !found; ++q) {
                                 const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
                             }
                         }
                         for (int q = 0; q < np && !found; ++q) {
                             const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
                         }
-                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
                         if (!found) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
@@ -374,10 +495,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             } else if (use_dirs) {
                 /* direction words, one step per LDS round trip: the row's words and its first predecessor together */
                 while (i > 0) {
-                    const int c = j >> 6;
-                    const unsigned long long d0 = M.dirs[((i - 1) * nch + c) * 2], d1 = M.dirs[((i - 1) * nch + c) * 2 + 1];
+                    const int code = poa_dir_code(M.dirs, i - 1, j, nch, packed);
                     const int pr0 = M.rpred0[i - 1];
-                    const int code = (int)((d0 >> (j & 63)) & 1ull) | ((int)((d1 >> (j & 63)) & 1ull) << 1);
                     if (code == 0) {
                         if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pr0; j--;
@@ -388,21 +507,21 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     } else {
                         const uint32_t meta = M.rmeta[i - 1];
                         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                        const int h = M.H[i * cols + j];
+                        const int h = M.H[i * hs + j];
                         int pi = i, pj = j;
                         bool found = false;
                         if (j != 0) {
                             const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
                             for (int q = 0; q < np && !found; ++q) {
                                 const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
                             }
                         }
                         for (int q = 0; q < np && !found; ++q) {
                             const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
                         }
-                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
                         if (!found) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
@@ -424,7 +543,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     for (int q = 1; q < 8; ++q) row = (tr == q) ? ch[q] : row;
                     const int col = j - tc;
                     const bool valid = row >= 0 && col >= 0;
-                    const int hv = valid ? (int)M.H[row * cols + col] : 0;
+                    const int hv = valid ? (int)M.H[row * hs + col] : 0;
                     const int meta_l = (tc == 0 && row >= 1) ? (int)M.rmeta[row - 1] : 0;
                     const int sq_l = (tr == 0 && col >= 1) ? (int)M.sq[col - 1] : 255;
                     int ti = 0, tj = 0, ci = i;
@@ -463,21 +582,21 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                         const uint32_t meta = M.rmeta[i - 1];
                         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
                         const int pr0 = M.rpred0[i - 1];
-                        const int h = M.H[i * cols + j];
+                        const int h = M.H[i * hs + j];
                         int pi = i, pj = j;
                         bool found = false;
                         if (j != 0) {
                             const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
                             for (int q = 0; q < np && !found; ++q) {
                                 const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * cols + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
                             }
                         }
                         for (int q = 0; q < np && !found; ++q) {
                             const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * cols + j] + G) { pi = pr; pj = j; found = true; }
+                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
                         }
-                        if (!found && j != 0 && h == (int)M.H[i * cols + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
                         if (!found) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
@@ -713,7 +832,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         if (ti >= n_tasks) break;
         const PoaTask t = sc.tasks[ti];
         if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
-        const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int16_t, true>(M, t, b, sc, lane, acc);
         if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
         cw_wave_sync();
     }
@@ -746,7 +865,7 @@ __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, Dev
         if (mi >= n_work) break;
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int16_t>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int16_t, (TIER < 3)>(M, t, b, sc, lane, acc); /* packed columns where n+len stays in int16 headroom */
         if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
     }
@@ -768,7 +887,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch 
         if (bi >= n_big) break;
         const uint32_t ti = sc.over_list[4][bi];
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int32_t>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int32_t, false>(M, t, b, sc, lane, acc);
         if (lane == 0) poa_hand_over(sc, t, ti, rc, CW_TIERS);
         cw_wave_sync();
     }
