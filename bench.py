@@ -49,10 +49,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if os.environ.get("CW_BENCH_SINGLE_DEVICE"):  # test aid: several ranks on one GPU (gloo only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CW_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; only a barrier and one max-reduce use it
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as exc:  # keep the run alive on a box where RCCL cannot initialise: the data path has no collective
+            print(f"[bench] {backend} init failed ({exc}); falling back to gloo for the barrier", file=sys.stderr)
+            backend = "gloo"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        backend = None
 
     import consent_amd as ca
     from consent_amd.engine import Batch, Result, synth_host
@@ -110,7 +123,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -149,7 +162,7 @@ def main():
         },
         "stage_ms": stage_avg,
     }
-    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536",
+    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0>",
                     "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
     traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
