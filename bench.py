@@ -31,6 +31,24 @@ def algorithmic_bytes(seq_len, n_windows, cons_len, solid_len):
     return int(np.sum((seq_len.astype(np.int64) + 3) // 4) + 4 * len(seq_len) + 16 * n_windows + int(np.sum(cons_len)) + 4 * int(np.sum(solid_len)) + 8 * n_windows)
 
 
+def effective_cores():
+    """CPU parallelism this process can actually use: affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pd = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pd))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,8 +217,8 @@ def main():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
         import oracle_lib
 
-        cores = os.cpu_count() or 1
-        n_s = args.cpu_sample if args.cpu_sample > 0 else max(cores * (4 if depth > 60 else 16), 64)
+        cores = effective_cores()
+        n_s = args.cpu_sample if args.cpu_sample > 0 else max(cores * (256 if depth > 60 else 1024), 64)
         n_s = min(n_s, n_win)
         hb = synth_host(ca.SynthSpec.pacbio(n_s, depth))
         # one worker PROCESS per core, each running the scalar oracle on a contiguous slice (threads of one process
@@ -239,7 +257,7 @@ def main():
             "unit": "windows/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"first {n_s} windows of the same workload, oracle/liboracle.so, {len(procs)} single-thread worker processes, consensus stage only",
+            "sample": f"first {n_s} windows of the same workload, oracle/liboracle.so, {len(procs)} single-thread worker processes (= usable cores: affinity capped by the cgroup CPU quota; the box shows {os.cpu_count()} logical CPUs), consensus stage only",
             "gpu_identical_on_sample": bool(same),
         }
     if rank == 0 and os.environ.get("CW_PROFILE"):
