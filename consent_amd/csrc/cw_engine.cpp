@@ -78,7 +78,7 @@ int ensure(void** ptr, size_t* have, size_t need) {
 
 int check_params(const cw_params* p) {
     if (!p) return CW_E_INVALID;
-    if (p->k < 2 || p->k > 9) return CW_E_INVALID; /* direct-addressed count table: 4^k nibbles in LDS */
+    if (p->k < 2 || p->k > 16) return CW_E_INVALID; /* k-mers are 32-bit keys; k <= 9 counts in a direct LDS table, larger k in a hashed one */
     if (p->solid < 1 || p->max_msa < 1) return CW_E_INVALID;
     return CW_OK;
 }

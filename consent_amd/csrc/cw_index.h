@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t k = prm.k;
-    const uint32_t n_keys = 1u << (2 * k);
-    const uint32_t nib_words = n_keys >= 8 ? n_keys / 8 : 1;
+    const bool direct = k <= 9;                             /* 4^k nibbles fit the LDS table */
+    const uint32_t n_keys = direct ? 1u << (2 * k) : 0u;
+    const uint32_t nib_words = direct ? (n_keys >= 8 ? n_keys / 8 : 1) : 0u;
 
     /* phase A carve */
     uint32_t* tab = (uint32_t*)lds;                                           /* nib_words                */
@@ -161,6 +162,93 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 
         CW_PROF_T0();
         /* ================= phase A: counts ================= */
+        if (!direct) {
+            /* ---- k > 9: the key space no longer fits a direct table.  Exact counts in an LDS hash table (key<<32 | count),
+               the pile scanned P times, pass p owning the keys whose hash falls in partition p (P chosen so that even an
+               all-distinct pile stays under half load); after each pass the solid entries are appended to the window's
+               slice; at the end the slice is bitonic-sorted by key in LDS. ---- */
+            unsigned long long* hs_tab = (unsigned long long*)lds; /* 16384 slots = 128 KiB */
+            const uint32_t HS = 16384u;
+            const uint32_t P_ = (wi->n_kmers + HS / 2 - 1) / (HS / 2) ? (wi->n_kmers + HS / 2 - 1) / (HS / 2) : 1u;
+            uint32_t written = 0;
+            bool fits = true;
+            if (tid < 8) flags[tid] = 0;
+            for (uint32_t pass = 0; pass < P_; ++pass) {
+                for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) hs_tab[i] = 0ull;
+                __syncthreads();
+                for (uint32_t sp = 0; sp < N; sp += 2) {
+                    const uint32_t s = sp + (tid >> 9);
+                    if (s < N) {
+                        const uint32_t len = b.seq_len[s0 + s];
+                        const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
+                        const uint32_t nk = len >= k ? len - k + 1 : 0;
+                        for (uint32_t p = tid & 511; p < nk; p += 512) {
+                            const uint32_t key = cw_kmer_at(words, p, k);
+                            const uint32_t h = cw_hash32(key ^ 0x9E3779B9u);
+                            if ((uint32_t)(((unsigned long long)h * P_) >> 32) != pass) continue;
+                            uint32_t slot = cw_hash32(key) >> (32 - 14);
+                            const unsigned long long fresh = ((unsigned long long)key << 32) | 1ull;
+                            for (uint32_t probe = 0;; ++probe) {
+                                if (probe >= HS) { flags[0] = 1; break; }
+                                const unsigned long long cur = atomicCAS(&hs_tab[slot], 0ull, fresh);
+                                if (cur == 0ull) break;
+                                if ((uint32_t)(cur >> 32) == key) { atomicAdd(&hs_tab[slot], 1ull); break; }
+                                slot = (slot + 1) & (HS - 1);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t mine = 0;
+                for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) mine += ((uint32_t)hs_tab[i] >= prm.solid) ? 1u : 0u;
+                uint32_t total;
+                const uint32_t off = cw_block_exscan(mine, scan_tmp, &total);
+                if (written + total > wi->solid_cap || flags[0]) fits = false;
+                if (fits && mine) {
+                    uint32_t o = wi->solid_base + written + off;
+                    for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) {
+                        const unsigned long long e = hs_tab[i];
+                        if ((uint32_t)e >= prm.solid) { sc.solid_key[o] = (uint32_t)(e >> 32); sc.solid_cnt[o] = (uint32_t)e; o++; }
+                    }
+                }
+                written += total;
+                __syncthreads();
+                if (!fits) break;
+            }
+            uint32_t np2 = 2;
+            while (np2 < written) np2 <<= 1;
+            if (fits && np2 > HS) fits = false;
+            if (tid == 0) {
+                wi->n_solid = fits ? written : 0;
+                if (!fits) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (!fits) continue;
+            if (written > 1) {
+                for (uint32_t x = tid; x < np2; x += CW_IDX_THREADS)
+                    hs_tab[x] = x < written ? (((unsigned long long)sc.solid_key[wi->solid_base + x] << 32) | sc.solid_cnt[wi->solid_base + x]) : ~0ull;
+                __syncthreads();
+                for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+                    for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                        for (uint32_t x = tid; x < np2; x += CW_IDX_THREADS) {
+                            const uint32_t y = x ^ j2;
+                            if (y > x) {
+                                const unsigned long long ax = hs_tab[x], ay = hs_tab[y];
+                                const bool up = (x & k2) == 0;
+                                if ((ax > ay) == up) { hs_tab[x] = ay; hs_tab[y] = ax; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (uint32_t x = tid; x < written; x += CW_IDX_THREADS) {
+                    sc.solid_key[wi->solid_base + x] = (uint32_t)(hs_tab[x] >> 32);
+                    sc.solid_cnt[wi->solid_base + x] = (uint32_t)hs_tab[x];
+                }
+                __syncthreads();
+            }
+        } else {
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
@@ -287,6 +375,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             __syncthreads();
             if (!fits) continue;
         }
+
+        } /* direct table */
 
         CW_PROF(sc.ctr, 2, tid == 0);
         /* ================= phase B: anchor candidates ================= */

@@ -76,6 +76,15 @@ def test_synthetic_pacbio_matches_oracle(engines, depth, max_msa, n):
     assert_same(got, exp, n, f"pacbio d{depth}")
 
 
+def test_large_k_on_deep_piles_uses_the_hashed_count_path(engines):
+    """k > 9: exact counts in the partitioned LDS hash table (several passes at depth 150)."""
+    prm = (12, 4, 8, 2, 150)
+    hb = synth_host(ca.SynthSpec.pacbio(12, 150))
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+    assert_same(got, exp, 12, "k=12 d150")
+
+
 def test_synthetic_ont_profile_matches_oracle(engines):
     prm = (9, 4, 8, 2, 50)
     hb = synth_host(ca.SynthSpec.ont(48, 40))
@@ -84,7 +93,8 @@ def test_synthetic_ont_profile_matches_oracle(engines):
     assert_same(got, exp, 48, "ont")
 
 
-@pytest.mark.parametrize("k,solid,common,min_anchors", [(5, 2, 3, 2), (7, 3, 6, 3), (8, 4, 8, 2), (9, 1, 1, 2), (9, 16, 8, 2), (9, 4, 0, 2), (6, 4, 8, 40)])
+@pytest.mark.parametrize("k,solid,common,min_anchors", [(5, 2, 3, 2), (7, 3, 6, 3), (8, 4, 8, 2), (9, 1, 1, 2), (9, 16, 8, 2), (9, 4, 0, 2), (6, 4, 8, 40),
+                                                        (10, 4, 8, 2), (11, 3, 6, 2), (13, 2, 4, 2), (16, 2, 3, 2)])
 def test_other_parameters(engines, k, solid, common, min_anchors):
     prm = (k, solid, common, min_anchors, 12)
     hb = synth_host(ca.SynthSpec.pacbio(24, 18, window_len=200))
