@@ -76,3 +76,20 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(src), f"{f} reaches into oracle/"
+
+
+def test_cpp_adapter_compiles_and_links_against_the_c_abi(tmp_path):
+    """The C++ host side (include/consent_amd_adapter.hpp) builds with plain g++ against the C-ABI library."""
+    import subprocess
+
+    exe = tmp_path / "operator_demo"
+    cmd = ["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "operator_demo.cpp"),
+           "-L", os.path.join(ROOT, "consent_amd"), "-lconsent_amd", "-Wl,-rpath," + os.path.join(ROOT, "consent_amd"), "-o", str(exe)]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    import torch
+
+    if torch.cuda.is_available():
+        assert out.returncode == 0 and "status: consensus" in out.stdout, out.stdout + out.stderr
+    else:
+        assert out.returncode == 2 and "engine unavailable" in out.stdout  # loud, no CPU fallback

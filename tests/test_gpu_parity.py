@@ -232,3 +232,15 @@ def test_full_size_batch_properties(engines):
     exp, _ = oracle_lib.oracle_run(ca.Params(*prm), sample, threads=os.cpu_count() or 1)
     for w in range(256):
         assert r1.consensus(9000 + w) == exp.consensus(w)
+
+
+def test_cpp_adapter_runs_on_the_gpu(tmp_path):
+    """examples/operator_demo.cpp through include/consent_amd_adapter.hpp: the C++ host side of the boundary."""
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    exe = tmp_path / "operator_demo"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "operator_demo.cpp"), "-L", os.path.join(root, "consent_amd"),
+                           "-lconsent_amd", "-Wl,-rpath," + os.path.join(root, "consent_amd"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "status: consensus" in out.stdout, out.stdout + out.stderr
