@@ -68,8 +68,10 @@ struct BatchCounters {
     uint32_t any_overflow;
     uint32_t n_tier[CW_TIERS];    /* tasks routed to tier t (t >= 1) by the index kernel */
     uint32_t next_tier[CW_TIERS]; /* work-stealing cursors */
-    uint32_t n_over[CW_TIERS];    /* tasks that outgrew tier t-1 (second pass) */
+    uint32_t n_over[CW_TIERS];    /* tasks that outgrew a tier and were handed to tier t */
     uint32_t next_over[CW_TIERS];
+    uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
+    uint32_t pad_;
     unsigned long long prof[32];  /* cycle totals per phase, see cw_debug_profile */
 };
 
@@ -99,6 +101,8 @@ struct DevScratch {
     uint8_t* slab[CW_TIERS];       /* per-wave slabs of tier t (DP matrix; for tier G also the graph) */
     uint64_t slab_bytes[CW_TIERS];
     uint32_t slots[CW_TIERS];      /* resident waves of tier t */
+    uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
+    uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */
 };
 
 /* ---- packed-sequence access ------------------------------------------------------------------- */

@@ -199,6 +199,18 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.members = (PoaMember*)(base + p.members); sc.member_cap = p.member_cap;
     sc.ctr = (BatchCounters*)(base + p.ctr);
     sc.list_cap = p.task_cap;
+    /* how many tier-L work-groups stay on the live overflow queue: about half of what the previous batch handed over
+       (few when nothing overflows, since a lingering work-group holds LDS the other tiers could use) */
+    if (e->timings_valid && e->scratch && hipEventQuery(e->ev_end) == hipSuccess) {
+        BatchCounters c;
+        if (hipMemcpy(&c, base + p.ctr, sizeof(uint32_t) * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint32_t want = c.n_over[3] / 2;
+            e->linger_wgs = want < 16 ? 16 : want > 256 ? 256 : want;
+        }
+    }
+    sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
+    if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
+    sc.producer_wgs = (uint32_t)cus * 2 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
     for (int t = 1; t < CW_TIERS; ++t) {
         sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
         sc.over_list[t] = (uint32_t*)(base + p.over[t]);
@@ -219,6 +231,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
+    CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
     stage_end(e, st, sid);
@@ -232,8 +245,11 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
        dispatched first so that their tail overlaps the bulk of the small tasks */
     CW_HIP(hipEventRecord(e->ev_fork, st));
     for (int i = 0; i < 3; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
+    /* tier L also consumes the live overflow queue; only sc.linger_wgs of its work-groups stay for that (far fewer than
+       CUs, so they can never keep the producers they wait for off the machine) */
+    const uint32_t grid_l = p.tier[3].slots / CW_POAL_WAVES;
     sid = stage_begin(e, e->side[2], "poa_large");
-    cw_poa_slab_kernel<L_ARGS, 0><<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
+    cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
     stage_end(e, e->side[2], sid);
     sid = stage_begin(e, e->side[1], "poa_m2");
     cw_poa_slab_kernel<M2_ARGS, 0><<<p.tier[2].slots / CW_POAM2_WAVES, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);

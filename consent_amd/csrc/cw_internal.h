@@ -34,6 +34,7 @@ struct cw_engine {
     float stage_ms[CW_MAX_STAGES];
     bool timings_valid;
     uint32_t last_windows, last_big_slots;
+    uint32_t linger_wgs; /* tier-L work-groups kept on the live overflow queue (adapted from the previous batch) */
     uint64_t last_words;
 };
 

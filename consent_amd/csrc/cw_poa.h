@@ -810,12 +810,23 @@ __device__ __forceinline__ void poa_hand_over(const DevScratch& sc, const PoaTas
     /* lane 0 only: rc 2 = this tier's capacity was exceeded -> next tier; rc 3 = output capacity / internal -> window overflow */
     if (rc == 2 && next_tier < CW_TIERS) {
         const uint32_t bi = atomicAdd(&sc.ctr->n_over[next_tier], 1u);
-        if (bi < sc.list_cap) sc.over_list[next_tier][bi] = ti;
+        /* the entry itself is the flag (pre-set to 0xFFFFFFFF): tier L may be consuming this list while we produce */
+        if (bi < sc.list_cap) __hip_atomic_store(&sc.over_list[next_tier][bi], ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
     } else if (rc != 1) {
         sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
     }
     sc.tasks[ti].state = (uint32_t)rc;
+}
+
+/* a producing tier's work-group is done: publish (release) and count it */
+__device__ __forceinline__ void poa_producer_done(const DevScratch& sc) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&sc.ctr->done_wgs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 /* ---- tier S: one task per wave, graph + DP matrix in LDS, work-stealing over the task list -------- */
@@ -837,39 +848,84 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         cw_wave_sync();
     }
     poa_flush_prof(sc, 8, acc, lane);
+    poa_producer_done(sc);
 }
 
 /* ---- tiers M1 / M2 / L: graph in LDS, DP matrix in this wave's global slab ------------------------ */
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
-   streams); PASS 1, after those have finished, through the tasks that outgrew the tier below. */
+   streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
 __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t gw = blockIdx.x * WAVES + wave;
-    if (gw >= sc.slots[TIER]) return;
+    const uint32_t gw = blockIdx.x * WAVES + wave; /* the grid never exceeds the slots */
     uint8_t* my_slab = sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER];
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     constexpr uint32_t slab = CW_POA_GRAPH_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab);
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
-    const uint32_t* list = PASS ? sc.over_list[TIER] : sc.tier_list[TIER];
-    const uint32_t n_work = min(PASS ? sc.ctr->n_over[TIER] : sc.ctr->n_tier[TIER], sc.list_cap);
-    uint32_t* cursor = PASS ? &sc.ctr->next_over[TIER] : &sc.ctr->next_tier[TIER];
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-    for (;;) {
-        uint32_t mi = 0;
-        if (lane == 0) mi = atomicAdd(cursor, 1u);
-        mi = (uint32_t)__shfl((int)mi, 0);
-        if (mi >= n_work) break;
-        const uint32_t ti = list[mi];
+    auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
         const int rc = poa_run<int16_t, (TIER < 3)>(M, t, b, sc, lane, acc); /* packed columns where n+len stays in int16 headroom */
         if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
+    };
+    if (PASS == 0) {
+        const uint32_t* list = sc.tier_list[TIER];
+        const uint32_t n_work = min(sc.ctr->n_tier[TIER], sc.list_cap);
+        for (;;) {
+            uint32_t mi = 0;
+            if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER], 1u);
+            mi = (uint32_t)__shfl((int)mi, 0);
+            if (mi >= n_work) break;
+            run_task(list[mi]);
+        }
+    }
+    if (TIER == 3 && (PASS == 1 || blockIdx.x < sc.linger_wgs)) {
+        /* Live queue (only the first few work-groups stay for it: a lingering tier-L work-group holds 76 KiB of LDS that
+           the other tiers could use): tasks that outgrow tiers S/M1/M2 while those kernels are still running on their own streams are
+           picked up here at once instead of waiting for a later pass.  An entry is its own flag (0xFFFFFFFF = not yet
+           written); we stop when every producing work-group has signed off and the queue is drained.  Every wait is
+           bounded: whatever is left (e.g. if this kernel ran before its producers) is handled by the PASS 1 launch. */
+        uint32_t idle = 0;
+        for (;;) {
+            uint32_t claimed = 0xFFFFFFFFu, stop = 0;
+            if (lane == 0) {
+                const uint32_t done = __hip_atomic_load(&sc.ctr->done_wgs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t n = min(__hip_atomic_load(&sc.ctr->n_over[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sc.list_cap);
+                uint32_t c = __hip_atomic_load(&sc.ctr->next_over[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c < n) {
+                    if (__hip_atomic_compare_exchange_strong(&sc.ctr->next_over[3], &c, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) claimed = c;
+                } else if (PASS == 1 || done >= sc.producer_wgs) {
+                    stop = 1;
+                }
+            }
+            claimed = (uint32_t)__shfl((int)claimed, 0);
+            stop = (uint32_t)__shfl((int)stop, 0);
+            if (stop) break;
+            if (claimed == 0xFFFFFFFFu) {
+                if (++idle > (1u << 16)) break; /* ~tens of ms of polling: give up, PASS 1 takes the rest */
+                __builtin_amdgcn_s_sleep(64);
+                continue;
+            }
+            idle = 0;
+            uint32_t ti = 0xFFFFFFFFu;
+            for (uint32_t spin = 0; spin < (1u << 20) && ti == 0xFFFFFFFFu; ++spin)
+                ti = __hip_atomic_load(&sc.over_list[3][claimed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ti == 0xFFFFFFFFu) { /* cannot happen: a claimed slot is written right after its index was taken */
+                if (lane == 0) sc.ctr->any_overflow = 2;
+                break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            run_task(ti);
+        }
+    } else if (PASS == 1) {
+        /* not used for tiers below L */
     }
     poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
+    if (PASS == 0 && TIER < 3) poa_producer_done(sc);
 }
 
 /* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
