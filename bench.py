@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (depth, maxMSA, windows per step per GPU)
     "pacbio_d30_msa20": (30, 20, 16384),
-    "pacbio_d150_msa150": (150, 150, 4096),
+    "pacbio_d150_msa150": (150, 150, 16384),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
