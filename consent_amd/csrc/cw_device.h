@@ -101,6 +101,8 @@ struct DevScratch {
     uint8_t* slab[CW_TIERS];       /* per-wave slabs of tier t (DP matrix; for tier G also the graph) */
     uint64_t slab_bytes[CW_TIERS];
     uint32_t slots[CW_TIERS];      /* resident waves of tier t */
+    uint16_t* p_fallback;          /* index kernel: per-work-group slot for a position matrix that outgrows LDS */
+    uint64_t p_fallback_elems;     /* u16 elements per slot */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */
 };

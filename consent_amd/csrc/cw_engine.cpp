@@ -34,7 +34,8 @@ void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, total;
+    uint64_t pfall_elems;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap;
     TierCfg tier[CW_TIERS];
@@ -64,6 +65,8 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
+    p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
+    put(p.pfall, (size_t)cus * p.pfall_elems * 2);
     p.total = o;
     return p;
 }
@@ -208,6 +211,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
             e->linger_wgs = want < 16 ? 16 : want > 256 ? 256 : want;
         }
     }
+    sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     sc.producer_wgs = (uint32_t)cus * 2 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;

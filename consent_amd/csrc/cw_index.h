@@ -145,8 +145,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     int32_t* csc = (int32_t*)(lds + 31760);
     uint16_t* chain = (uint16_t*)(lds + 35856);
     uint32_t* misc = (uint32_t*)(lds + 37904);                                /* 64 words                */
-    uint16_t* P = (uint16_t*)(lds + 38400);
+    uint16_t* const P_lds = (uint16_t*)(lds + 38400);
     const uint32_t p_cap = (CW_IDX_LDS_BYTES - 38400) / 2;
+    /* position matrix: in LDS when it fits next to the presence bitsets, else in this work-group's global slot
+       (high-identity deep piles: every template k-mer is an anchor).  Accessors pick the address space with a
+       block-uniform branch so that the common case keeps ds_ instructions. */
+    uint16_t* const P_glb = sc.p_fallback + (size_t)blockIdx.x * sc.p_fallback_elems;
+#define PRD(i) (pg ? (uint32_t)P_glb[i] : (uint32_t)P_lds[i])
+#define PWR(i, v) do { if (pg) P_glb[i] = (uint16_t)(v); else P_lds[i] = (uint16_t)(v); } while (0)
 
     for (;;) {
         __syncthreads();
@@ -442,11 +448,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            lanes fall on distinct banks */
         uint32_t Np = (N + 1u) & ~1u;
         if (((Np >> 1) & 1u) == 0u) Np += 2u;
-        if ((uint64_t)A * Np > p_cap) {
+        const uint32_t Nw = (N + 63u) >> 6;
+        /* LDS needs: the matrix (A*Np u16) + presence bitsets (A*Nw u64) + dirty list (N u16) */
+        const bool pg = (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
+        if (pg && (uint64_t)A * Np > sc.p_fallback_elems) {
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             continue;
         }
-        for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) P[i] = CW_NONE16;
+        for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
         __syncthreads();
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
             const uint32_t len = b.seq_len[s0 + s];
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const int e = cw_tpl_lookup(th, tkey, cw_kmer_at(words, p, k));
                 if (e < 0) continue;
                 const int a = tcand[e];
-                if (a >= 0) P[(uint32_t)a * Np + s] = (uint16_t)p;
+                if (a >= 0) PWR((uint32_t)a * Np + s, p);
             }
         }
         __syncthreads();
@@ -465,9 +474,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            pair a < b it holds, so its contribution to score(a,b) is one bit of presence(a) & presence(b); only the few
            sequences with an out-of-order (spurious) anchor hit need their positions compared.  Exact, and ~20x cheaper
            than comparing positions for all N sequences. */
-        const uint32_t Nw = (N + 63u) >> 6;
         uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available) */
-        unsigned long long* pres = (unsigned long long*)(P + (((size_t)A * Np + 3u) & ~(size_t)3u)); /* A x Nw, 8-byte aligned */
+        unsigned long long* pres = (unsigned long long*)(P_lds + (pg ? 0 : (((size_t)A * Np + 3u) & ~(size_t)3u))); /* A x Nw, 8-byte aligned */
         uint16_t* dirty = (uint16_t*)(pres + (size_t)A * Nw);          /* up to N ids */
         const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_LDS_BYTES);
         if (use_bits) {
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool bad = false;
                 for (uint32_t a0 = 0; a0 < A; a0 += 64) {
                     const uint32_t a = a0 + lane;
-                    const uint32_t pv = a < A ? (uint32_t)P[a * Np + s] : (uint32_t)CW_NONE16;
+                    const uint32_t pv = a < A ? PRD(a * Np + s) : (uint32_t)CW_NONE16;
                     const int v = pv != CW_NONE16 ? (int)pv : -1;
                     const int inc = cw_wave_scan_max(v);
                     int before = cw_wave_shr1(inc, -1);
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
                 for (uint32_t w = 0; w < Nw; ++w) {
                     const uint32_t s = w * 64 + lane;
-                    const bool on = s < N && P[a * Np + s] != CW_NONE16 && clean[s];
+                    const bool on = s < N && PRD(a * Np + s) != CW_NONE16 && clean[s];
                     const unsigned long long bal = __ballot(on);
                     if (lane == 0) pres[(size_t)a * Nw + w] = bal;
                 }
@@ -524,7 +532,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             cw_wave_sync();
             for (int a = (int)A - 1; a >= 0; --a) {
                 unsigned long long best = 0ull;
-                const uint32_t* pa_row = (const uint32_t*)(P + (uint32_t)a * Np);
+                const uint32_t* pa_row = (const uint32_t*)((pg ? P_glb : P_lds) + (uint32_t)a * Np);
                 const uint32_t half = Np >> 1; /* pairs of sequences; padding entries are CW_NONE16 and never count */
                 for (uint32_t b0 = (uint32_t)a + 1u; b0 < A; b0 += 64) {
                     const uint32_t bb = b0 + (uint32_t)lane;
@@ -535,11 +543,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                             for (uint32_t w = 0; w < Nw; ++w) cnt += (uint32_t)__popcll(pres[(size_t)a * Nw + w] & pres[(size_t)bb * Nw + w]);
                             for (uint32_t d = 0; d < n_dirty; ++d) {
                                 const uint32_t sd = dirty[d];
-                                const uint32_t pa = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                const uint32_t pa = PRD((uint32_t)a * Np + sd), pb = PRD(bb * Np + sd);
                                 cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
                             }
                         } else {
-                            const uint32_t* pb_row = (const uint32_t*)(P + bb * Np);
+                            const uint32_t* pb_row = (const uint32_t*)((pg ? P_glb : P_lds) + bb * Np);
 #pragma unroll 8
                             for (uint32_t s = 0; s < half; ++s) {
                                 const uint32_t va = pa_row[s], vb = pb_row[s];
@@ -620,8 +628,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
+                    const uint32_t pa = ca >= 0 ? PRD((uint32_t)ca * Np + s) : 0u;
+                    const uint32_t pb = cb >= 0 ? PRD((uint32_t)cb * Np + s) : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
@@ -674,8 +682,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool is = false;
                 uint32_t st = 0, ln = 0;
                 if (s < N) {
-                    const uint32_t pa = ca >= 0 ? P[(uint32_t)ca * Np + s] : 0u;
-                    const uint32_t pb = cb >= 0 ? P[(uint32_t)cb * Np + s] : 0u;
+                    const uint32_t pa = ca >= 0 ? PRD((uint32_t)ca * Np + s) : 0u;
+                    const uint32_t pb = cb >= 0 ? PRD((uint32_t)cb * Np + s) : 0u;
                     if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
                     else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
                     else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
@@ -717,5 +725,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         }
     }
 }
+
+#undef PRD
+#undef PWR
 
 #endif

@@ -127,6 +127,21 @@ def test_edge_piles(engines):
     assert int(got.status[4]) == ca.WIN_TEMPLATE and got.consensus(4) == piles[4][0]
 
 
+def test_high_identity_deep_piles_use_the_global_anchor_matrix(engines):
+    """Nearly every template k-mer is an anchor and the pile is deep: the anchor position matrix outgrows LDS."""
+    rng = random.Random(17)
+    truth = rand_seq(rng, 520)
+    piles = [[truth[:500]] + [mutate(rng, truth[:500], 0.004) for _ in range(150)],
+             [truth[10:510]] * 151,
+             [mutate(rng, truth[:500], 0.01) for _ in range(120)]]
+    prm = (9, 4, 8, 2, 150)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=3)
+    assert_same(got, exp, len(piles), "high identity")
+    assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:3])
+
+
 def test_long_and_outlier_segments_exercise_all_tiers(engines):
     """Few anchors -> segments of hundreds of bases; graphs that outgrow the LDS tiers must give identical results."""
     rng = random.Random(13)
