@@ -46,7 +46,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
     p.seg_cap = (uint64_t)n_windows * (CW_TMAX + 2);
-    p.arena_cap = (uint64_t)n_windows * (8ull * (CW_TMAX + 16) + 1024);
+    p.arena_cap = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096);
     uint64_t tc = 64ull * n_windows + 1024, mc = 2048ull * n_windows + 4096;
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
@@ -330,6 +330,51 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     memcpy(counters26, &c, 26 * 4);
     memcpy(prof32, c.prof, sizeof(c.prof));
     return CW_OK;
+}
+
+/* getCoverages + getAlignmentWindowsPositions (src/alignmentWindows.cpp:5-85) on the host: per-base overlap depth over
+ * [q_start, q_end] inclusive; a window [beg, beg+window_size-1] whenever window_size consecutive bases have depth >=
+ * min_support, then rewind by window_overlap (:40-47); a base below min_support resets (:48-51); finally ONE trailing window
+ * = the last window_size covered bases found scanning backwards from the end, never looking at base 0 (:58-79). */
+int cw_window_positions(uint32_t tpl_len, const cw_overlap* overlaps, uint32_t n_overlaps, uint32_t min_support, uint32_t window_size,
+                        int32_t window_overlap, uint32_t* out_beg_end, uint32_t cap_pairs, uint32_t* n_pairs) {
+    if (!n_pairs || (n_overlaps && !overlaps) || (cap_pairs && !out_beg_end)) return CW_E_INVALID;
+    *n_pairs = 0;
+    if (tpl_len == 0) return CW_OK;
+    std::vector<uint32_t> cov;
+    try { cov.assign(tpl_len, 0); } catch (...) { return CW_E_NOMEM; }
+    for (uint32_t o = 0; o < n_overlaps; ++o) {
+        if (overlaps[o].q_end < overlaps[o].q_start || overlaps[o].q_end >= tpl_len) return CW_E_INVALID; /* the reference would write out of bounds */
+        for (uint32_t i = overlaps[o].q_start; i <= overlaps[o].q_end; ++i) cov[i]++;
+    }
+    uint32_t count = 0;
+    bool over = false;
+    auto push = [&](uint32_t b, uint32_t e2) {
+        if (count < cap_pairs) { out_beg_end[2 * count] = b; out_beg_end[2 * count + 1] = e2; } else over = true;
+        ++count;
+    };
+    uint32_t cur = 0, beg = 0, i = 0;
+    while (i < tpl_len) {
+        if (cur >= window_size) {
+            push(beg, beg + cur - 1);
+            if (window_overlap) i = i - (uint32_t)window_overlap;
+            beg = i;
+            cur = 0;
+        }
+        if (cov[i] < min_support) { cur = 0; i++; beg = i; }
+        else { cur++; i++; }
+    }
+    bool pushed = false;
+    uint32_t end = tpl_len - 1;
+    cur = 0;
+    i = tpl_len - 1;
+    while (i > 0 && !pushed) {
+        if (cur >= window_size) { push(end - cur + 1, end); pushed = true; end = i; cur = 0; }
+        if (cov[i] < min_support) { cur = 0; i--; end = i; }
+        else { cur++; i--; }
+    }
+    *n_pairs = count;
+    return over ? CW_E_CAPACITY : CW_OK;
 }
 
 int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps,

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             tl = ns ? b.seq_len[s0] : 0;
             need_solid = nk / prm.solid + 1;
             need_seg = (tl >= prm.k) ? tl - prm.k + 3 : 1;
-            need_arena = 8 * tl + 1024;
+            need_arena = 16 * tl + 4096;
         }
         part[0][tid] = need_solid; part[1][tid] = need_seg; part[2][tid] = need_arena;
         __syncthreads();

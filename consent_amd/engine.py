@@ -109,6 +109,7 @@ def load_library():
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_extract_piles_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.cw_window_positions.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
     lib.cw_synth_sizes.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -184,6 +185,17 @@ def pack_piles(piles):
             si += 1
     wfs[len(piles)] = si
     return HostBatch(wfs, lens, offs, bases)
+
+
+def window_positions(tpl_len, overlaps, min_support, window_size, window_overlap):
+    """cw_window_positions: `overlaps` is an (n,6) uint32 array of cw_overlap rows; returns [(beg, end), ...]."""
+    lib = load_library()
+    ov = np.ascontiguousarray(overlaps, np.uint32).reshape(-1, 6)
+    n = C.c_uint32()
+    cap = tpl_len // max(1, window_size - window_overlap) + 8
+    out = np.zeros(2 * cap, np.uint32)
+    _check(lib, lib.cw_window_positions(tpl_len, _ptr(ov) if len(ov) else None, len(ov), min_support, window_size, window_overlap, _ptr(out), cap, C.byref(n)), "cw_window_positions")
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)]
 
 
 def synth_host(spec):

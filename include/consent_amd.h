@@ -9,6 +9,7 @@
  *                               i.e. MSABMAAC (call sites correctionMSA.cpp:32,54) + weightConsensus
  *                               (correctionMSA.cpp:6-27) + polishCorrection (correctionDBG.h:11)
  *                               -- batched over windows, because one window per call cannot feed a GPU.
+ *   cw_window_positions      <- getAlignmentWindowsPositions (alignmentWindows.cpp:27-85), host
  *   cw_extract_piles_device  <- getAlignmentWindowsSequences (alignmentWindows.cpp:87-149) evaluated on the device
  *   cw_pack_sequence         <- the vector<string> pile handed to those operators
  *                               (CONSENT-correction.cpp:35-37, CONSENT-polishing.cpp:46-49): 2-bit packing
@@ -145,6 +146,13 @@ typedef struct cw_window_job {     /* one window of one template (pilesPos[i], C
     uint32_t q_beg, q_end;         /* inclusive */
     uint32_t ovl_first, ovl_count; /* the template's pile in `overlaps`, in getNextReadPile order                    */
 } cw_window_job;
+
+/* HOST function: window positions of one template, getAlignmentWindowsPositions (src/alignmentWindows.cpp:27-85, with
+ * getCoverages :5-25).  `overlaps` is the template's pile (only q_start/q_end are read).  Writes (beg,end) pairs, inclusive,
+ * in the reference's order (forward windows, then the one trailing window); *n_pairs = how many exist; CW_E_CAPACITY if
+ * cap_pairs was too small (call again).  CW_E_INVALID if an overlap ends beyond the template. */
+int cw_window_positions(uint32_t tpl_len, const cw_overlap* overlaps, uint32_t n_overlaps, uint32_t min_support, uint32_t window_size,
+                        int32_t window_overlap, uint32_t* out_beg_end, uint32_t cap_pairs, uint32_t* n_pairs);
 
 /* All pointers are DEVICE pointers (read set, overlaps, jobs, and the four output arrays laid out as cw_batch:
  * win_first_seq[n_jobs+1], seq_len[seq_cap], seq_word_off[seq_cap], bases[word_cap]).  On return *n_seqs / *n_words hold

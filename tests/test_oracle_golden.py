@@ -25,6 +25,17 @@ def test_windows_and_piles_match_reference_vectors(i):
         assert got == exp
 
 
+@pytest.mark.parametrize("i", range(len(WP["cases"])))
+def test_product_window_positions_match_reference_vectors(i):
+    """the library's own host A1 (cw_window_positions) against the committed reference-generated vectors"""
+    from consent_amd.engine import window_positions as product_window_positions
+
+    c = WP["cases"][i]
+    rows = np.array([[o[1], o[2], 0, o[5], o[6], o[3]] for o in c["overlaps"]], np.uint32)
+    got = product_window_positions(len(c["tpl"]), rows, c["min_support"], c["window_size"], c["window_overlap"])
+    assert got == [tuple(w) for w in c["windows"]]
+
+
 @pytest.mark.parametrize("i", range(len(CS["cases"])))
 def test_consensus_regression_vectors(i):
     c = CS["cases"][i]

@@ -112,3 +112,18 @@ def test_reference_pile_sort_order_on_ties(tmp_path):
     assert n == 5
     got = [names[i * 16 : (i + 1) * 16].tobytes().split(b"\0")[0].decode() for i in range(n)]
     assert got == ["t2", "t4", "t1", "t3", "t5"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_product_window_positions_match_reference(seed):
+    """cw_window_positions (the library's host implementation of A1) against the reference's own getAlignmentWindowsPositions."""
+    from consent_amd.engine import window_positions as product_window_positions
+
+    r = _need_ref()
+    rng = random.Random(500 + seed)
+    tpl_len = rng.choice([300, 500, 501, 1700, 4000, 8000])
+    ovls, _ = rand_overlaps(rng, tpl_len, rng.randrange(1, 40))
+    rows = np.array([[o[1], o[2], 0, o[5], o[6], o[3]] for o in ovls], np.uint32)
+    for min_support, wsize, wover in ((1, 500, 50), (3, 500, 50), (2, 200, 0), (4, 300, 120)):
+        exp = oracle_lib.window_positions(r.ref_window_positions, tpl_len, ovls, min_support, wsize, wover)
+        assert product_window_positions(tpl_len, rows, min_support, wsize, wover) == exp
