@@ -75,4 +75,21 @@
 #define CW_DBG_MAX_BRANCHES 50   /* correctionDBG.cpp:100 */
 #define CW_DBG_MAX_ANCHORS   5   /* correctionDBG.cpp:144 */
 
+/* --- read re-assembly: alignConsensus uses StripedSmithWaterman::Aligner (Complete-Striped-Smith-Waterman-
+ * Library, bundled inside the absent BMEAN submodule; call sites correctionAlignment.cpp:48-52,90,110).  Restated from the
+ * library's published algorithm: default Aligner() scores, exact local alignment with affine gaps (a gap of length L
+ * costs open + (L-1)*extend), and its position rules:
+ *   end   = first reference column whose column maximum exceeds every earlier one; inside it the smallest query index
+ *           holding that maximum;
+ *   begin = the same search on the reversed prefixes, scanning the reference backwards from the end column and stopping
+ *           at the first column whose running maximum reaches the forward score;
+ *   cigar = banded traceback between begin and end (band |ref_len - query_len| + 1, doubled until the score is reached),
+ *           only its inserted/deleted base totals are used (correctionAlignment.cpp:28-45,111).
+ * str2num on the mixed-case overlap strings (correctionAlignment.cpp:9): every character other than 'A','C','G' counts as T.
+ * PARITY UNPINNED (library absent).                                                                                     */
+#define CW_SSW_MATCH     2
+#define CW_SSW_MISMATCH  2
+#define CW_SSW_GAP_OPEN  3
+#define CW_SSW_GAP_EXT   1
+
 #endif /* CW_POLICY_H */

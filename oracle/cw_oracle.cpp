@@ -781,3 +781,239 @@ std::vector<std::string> window_pile(const std::vector<Ovl>& ovl, const std::str
 }
 
 } // namespace cwo
+
+/* ==================================================================================================
+ * SURVEY 8f-1 -- read re-assembly: alignConsensus (correctionAlignment.cpp:47-140) over a restated
+ * striped-Smith-Waterman (library absent: policy in include/cw_policy.h, PARITY UNPINNED), trimRead / dropRead
+ * (utils.cpp:96-128, :71-73; pinned against oracle/_ref).
+ * ================================================================================================== */
+namespace cwo {
+
+namespace {
+
+inline int ssw_code(char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+inline int ssw_score(int a, int b) { return (a == 4 || b == 4) ? 0 : (a == b ? CW_SSW_MATCH : -CW_SSW_MISMATCH); }
+
+/* One exact local-alignment sweep over the columns of `ref` in the given order; returns the best score, the first column
+ * reaching it (strict '>' while sweeping; stops early once `terminate` is reached, -1 = never) and the smallest query index
+ * of that column holding it. */
+struct Sweep { int score, col, row; };
+Sweep ssw_sweep(const std::vector<int>& q, const std::vector<int>& r, int r_first, int r_last_excl, int step, int terminate) {
+    const int m = (int)q.size();
+    std::vector<int> H(m, 0), E(m, 0), Hn(m, 0);
+    Sweep best{0, -1, 0};
+    for (int i = r_first; i != r_last_excl; i += step) {
+        int f = 0, diag = 0, col_max = 0, col_row = 0;
+        for (int j = 0; j < m; ++j) {
+            /* E: gap along the reference (column to column), F: gap along the query (inside the column) */
+            int e = std::max(E[j] - CW_SSW_GAP_EXT, H[j] - CW_SSW_GAP_OPEN);
+            if (e < 0) e = 0;
+            int h = diag + ssw_score(q[j], r[i]);
+            if (h < e) h = e;
+            if (h < f) h = f;
+            if (h < 0) h = 0;
+            diag = H[j];
+            Hn[j] = h;
+            E[j] = e;
+            f = std::max(f - CW_SSW_GAP_EXT, h - CW_SSW_GAP_OPEN);
+            if (f < 0) f = 0;
+            if (h > col_max) { col_max = h; col_row = j; }
+        }
+        H.swap(Hn);
+        if (col_max > best.score) {
+            best.score = col_max; best.col = i; best.row = col_row;
+            if (best.score == terminate) break;
+        }
+    }
+    return best;
+}
+
+/* banded traceback between the found ends: totals of inserted (query-only) and deleted (reference-only) bases */
+void ssw_banded_indels(const std::vector<int>& ref, const std::vector<int>& read, int score, unsigned* ins, unsigned* del) {
+    const int refLen = (int)ref.size(), readLen = (int)read.size();
+    *ins = 0; *del = 0;
+    if (refLen == 0 || readLen == 0) return;
+    int band = std::abs(refLen - readLen) + 1;
+    std::vector<int8_t> dir;
+    int width_d = 0;
+    for (;;) {
+        const int width = band * 2 + 3;
+        width_d = band * 2 + 1;
+        std::vector<int> h_b(width, 0), e_b(width, 0), h_c(width, 0);
+        dir.assign((size_t)width_d * readLen * 3, 0);
+        int max = 0;
+        auto set_u = [&](int w, int i, int j) { int x = i - w; x = x > 0 ? x : 0; return j - x + 1; };
+        auto set_d = [&](int w, int i, int j, int p) { int x = i - w; x = x > 0 ? x : 0; x = j - x; return x * 3 + p; };
+        for (int i = 0; i < readLen; ++i) {
+            int beg = 0, end = refLen - 1, u = 0;
+            int j = i - band; beg = beg > j ? beg : j;
+            j = i + band; end = end < j ? end : j;
+            const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+            int f = 0;
+            h_b[0] = e_b[0] = h_b[edge] = e_b[edge] = h_c[0] = 0;
+            int8_t* line = dir.data() + (size_t)width_d * i * 3;
+            for (j = beg; j <= end; ++j) {
+                u = set_u(band, i, j);
+                const int e = set_u(band, i - 1, j), b = set_u(band, i, j - 1), d = set_u(band, i - 1, j - 1);
+                const int de = set_d(band, i, j, 0), df = set_d(band, i, j, 1), dh = set_d(band, i, j, 2);
+                int t1 = i == 0 ? -CW_SSW_GAP_OPEN : h_b[e] - CW_SSW_GAP_OPEN;
+                int t2 = i == 0 ? -CW_SSW_GAP_EXT : e_b[e] - CW_SSW_GAP_EXT;
+                e_b[u] = t1 > t2 ? t1 : t2;
+                line[de] = t1 > t2 ? 3 : 2;
+                t1 = h_c[b] - CW_SSW_GAP_OPEN;
+                t2 = f - CW_SSW_GAP_EXT;
+                f = t1 > t2 ? t1 : t2;
+                line[df] = t1 > t2 ? 5 : 4;
+                const int e1 = e_b[u] > 0 ? e_b[u] : 0, f1 = f > 0 ? f : 0;
+                t1 = e1 > f1 ? e1 : f1;
+                t2 = h_b[d] + ssw_score(ref[j], read[i]);
+                h_c[u] = t1 > t2 ? t1 : t2;
+                if (h_c[u] > max) max = h_c[u];
+                if (t1 <= t2) line[dh] = 1;
+                else line[dh] = e1 > f1 ? line[de] : line[df];
+            }
+            for (j = 1; j <= u; ++j) h_b[j] = h_c[j];
+        }
+        if (max >= score || band > refLen + readLen) break;
+        band *= 2;
+    }
+    /* trace back from the last cell */
+    int i = readLen - 1, j = refLen - 1, state = 2;
+    auto set_d = [&](int w, int ii, int jj, int p) { int x = ii - w; x = x > 0 ? x : 0; x = jj - x; return x * 3 + p; };
+    while (i > 0 && j >= 0) {
+        const int8_t* line = dir.data() + (size_t)width_d * i * 3;
+        const int idx = set_d(band, i, j, state);
+        if (idx < 0 || idx >= width_d * 3) break;
+        switch (line[idx]) {
+        case 1: --i; --j; state = 2; break;
+        case 2: --i; state = 0; ++*ins; break;
+        case 3: --i; state = 2; ++*ins; break;
+        case 4: --j; state = 1; ++*del; break;
+        case 5: --j; state = 2; ++*del; break;
+        default: return; /* outside the band */
+        }
+    }
+}
+
+} // namespace
+
+SwResult ssw_align(const std::string& query, const std::string& ref) {
+    SwResult out{0, 0, -1, 0, -1, 0, 0};
+    std::vector<int> q(query.size()), r(ref.size());
+    for (size_t i = 0; i < query.size(); ++i) q[i] = ssw_code(query[i]);
+    for (size_t i = 0; i < ref.size(); ++i) r[i] = ssw_code(ref[i]);
+    if (q.empty() || r.empty()) return out;
+    const Sweep fw = ssw_sweep(q, r, 0, (int)r.size(), 1, -1);
+    out.score = fw.score;
+    if (fw.score <= 0) return out;
+    out.ref_end = fw.col; out.query_end = fw.row;
+    std::vector<int> qrev(q.begin(), q.begin() + fw.row + 1);
+    std::reverse(qrev.begin(), qrev.end());
+    const Sweep bw = ssw_sweep(qrev, r, fw.col, -1, -1, fw.score);
+    out.ref_begin = bw.col; out.query_begin = fw.row - bw.row;
+    std::vector<int> rsub(r.begin() + out.ref_begin, r.begin() + out.ref_end + 1), qsub(q.begin() + out.query_begin, q.begin() + out.query_end + 1);
+    ssw_banded_indels(rsub, qsub, fw.score, &out.ins, &out.del);
+    return out;
+}
+
+static int nb_solid_mers(const std::string& seq, const std::vector<uint32_t>& solid, unsigned k) { /* correctionAlignment.cpp:6-15 */
+    int nb = 0;
+    for (size_t i = 0; i + k <= seq.size(); ++i) {
+        kmer_t v = 0;
+        for (unsigned j = 0; j < k; ++j) {
+            const char c = seq[i + j];
+            v = (v << 2) | (c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u); /* policy: anything else, lower case included, is T */
+        }
+        if (std::binary_search(solid.begin(), solid.end(), (uint32_t)v)) nb++;
+    }
+    return nb;
+}
+static int nb_upper(const std::string& s) { int n = 0; for (char c : s) n += is_upper(c) ? 1 : 0; return n; }
+
+std::string align_consensus(const std::string& sequence, const std::vector<std::string>& consensuses,
+                            const std::vector<std::vector<uint32_t>>& solid, const std::vector<std::pair<uint32_t, uint32_t>>& piles_pos,
+                            const std::vector<std::string>& templates, int start_pos, unsigned window_size, unsigned window_overlap,
+                            unsigned mer_size) {
+    std::string out = sequence;                                                    /* :56-57 */
+    for (char& c : out) if ('A' <= c && c <= 'Z') c = (char)(c + 32);
+    unsigned beg, end, old_end = 0;
+    int cur_pos = start_pos;
+    std::string cur, old_cons;
+    const std::vector<uint32_t>* old_mers = nullptr;
+    for (size_t i = 0; i < consensuses.size(); ++i) {                              /* :74 */
+        cur = consensuses[i].size() < mer_size ? templates[i] : consensuses[i];    /* :75-80 */
+        const std::vector<uint32_t>* cur_mers = &solid[i];
+        const int al_pos = std::max(0, cur_pos - (int)window_overlap);             /* :83 */
+        int size_al;
+        if ((size_t)al_pos + window_size + 2 * window_overlap >= out.size()) size_al = (int)out.size() - al_pos;   /* :84-88 */
+        else size_al = (int)(window_size + 2 * window_overlap);
+        if (size_al <= 0 || cur.empty()) continue;                                 /* Align() refuses an empty query */
+        const SwResult al = ssw_align(cur, out.substr((size_t)al_pos, (size_t)size_al));   /* :90 */
+        if (al.score <= 0) continue;
+        beg = (unsigned)(al.ref_begin + al_pos);                                   /* :91-93 */
+        end = (unsigned)(al.ref_end + al_pos);
+        cur = cur.substr((size_t)al.query_begin, (size_t)(al.query_end - al.query_begin + 1));
+        if (i != 0 && old_end >= beg) {                                            /* :96 */
+            const unsigned overlap = old_end - beg + 1;
+            if (consensuses[i].size() >= mer_size && old_cons.size() >= overlap && cur.size() >= overlap) {
+                const std::string seq1 = old_cons.substr(old_cons.size() - overlap, overlap);   /* :99-100 */
+                const std::string seq2 = cur.substr(0, overlap);
+                if (upper_copy(seq1) != upper_copy(seq2)) {
+                    int s1, s2;
+                    if (overlap >= mer_size) { s1 = nb_solid_mers(seq1, *old_mers, mer_size); s2 = nb_solid_mers(seq2, *cur_mers, mer_size); }
+                    else { s1 = nb_upper(seq1); s2 = nb_upper(seq2); }
+                    if (s1 > s2) {                                                 /* :109-119 */
+                        const size_t rl = std::min(seq1.size(), seq2.size());
+                        const SwResult sub = ssw_align(seq1, seq2.substr(0, rl));
+                        const unsigned cut = overlap - sub.ins + sub.del;
+                        if (cut < cur.size()) cur = seq1 + cur.substr(cut);
+                        else cur.clear();
+                    }
+                }
+            }
+        }
+        if (!cur.empty()) {                                                        /* :124 */
+            if (consensuses[i].size() >= mer_size) out.replace(beg, end - beg + 1, upper_copy(cur));   /* :125-129 */
+            if (i + 1 < consensuses.size()) {                                      /* :130-135 */
+                const long long np = (long long)cur_pos + (long long)piles_pos[i + 1].first - (long long)piles_pos[i].first -
+                                     (long long)(end - beg + 1) + (long long)cur.size();
+                cur_pos = (int)(int32_t)(uint32_t)np;
+                old_cons = cur;
+                old_mers = &solid[i];
+                old_end = beg + (unsigned)cur.size() - 1;
+            }
+        }
+    }
+    return out;
+}
+
+std::string trim_read(const std::string& s, unsigned mer_size) {                  /* utils.cpp:96-128 */
+    unsigned i = 0, n = 0;
+    while (i < s.size() && n < mer_size) { n = is_upper(s[i]) ? n + 1 : 0; i++; }
+    const unsigned beg = i - mer_size;
+    long long k = (long long)s.size() - 1;
+    n = 0;
+    /* the reference loops on an unsigned `i >= 0`; it terminates only because an upper-case run exists whenever beg is valid.
+       A read without such a run is undefined behaviour there; here it yields the empty string. */
+    while (k >= 0 && n < mer_size) { n = is_upper(s[(size_t)k]) ? n + 1 : 0; k--; }
+    if (n < mer_size) return std::string();
+    const unsigned end = (unsigned)(k + mer_size);
+    if (end > beg) return s.substr(beg, end - beg + 1);
+    return std::string();
+}
+
+bool drop_read(const std::string& s) {                                            /* utils.cpp:60-73 */
+    int n = 0;
+    for (char c : s) n += ('A' <= c && c <= 'Z') ? 1 : 0;
+    return (float)n / s.size() < 0.1;
+}
+
+} // namespace cwo

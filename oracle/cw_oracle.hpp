@@ -85,5 +85,23 @@ std::vector<std::pair<uint32_t, uint32_t>> window_positions(uint32_t tpl_len, co
 std::vector<std::string> window_pile(const std::vector<Ovl>& ovl, const std::string& tpl,
                                      const std::vector<std::string>& targets, uint32_t q_beg, uint32_t q_end, unsigned k);
 
+/* ---- read re-assembly -------------------------------------------------------------------------------- */
+/* Result of the local alignment the reference obtains from StripedSmithWaterman::Aligner::Align (policy: cw_policy.h). */
+struct SwResult {
+    int score;
+    int ref_begin, ref_end, query_begin, query_end; /* inclusive, 0-based */
+    unsigned ins, del;                              /* inserted / deleted bases of the banded traceback */
+};
+SwResult ssw_align(const std::string& query, const std::string& ref);
+
+/* alignConsensus (correctionAlignment.cpp:47-140); solid[i] = ascending solid k-mers of window i (what merCounts[i] is read for). */
+std::string align_consensus(const std::string& sequence, const std::vector<std::string>& consensuses,
+                            const std::vector<std::vector<uint32_t>>& solid, const std::vector<std::pair<uint32_t, uint32_t>>& piles_pos,
+                            const std::vector<std::string>& templates, int start_pos, unsigned window_size, unsigned window_overlap,
+                            unsigned mer_size);
+/* trimRead / dropRead (utils.cpp:96-128, :71-73) -- pinned against oracle/_ref */
+std::string trim_read(const std::string& corrected, unsigned mer_size);
+bool drop_read(const std::string& corrected);
+
 } // namespace cwo
 #endif

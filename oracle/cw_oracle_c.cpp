@@ -146,3 +146,57 @@ int cwo_window_pile(const uint32_t* ovl, uint32_t n_ovl, const char* tpl, uint32
 }
 
 } // extern "C"
+
+/* ---- SURVEY 8f-1 entry points ---------------------------------------------------------------------------------------- */
+extern "C" {
+
+/* ssw_align restatement: out7 = score, ref_begin, ref_end, query_begin, query_end, ins, del */
+int cwo_ssw(const char* query, uint32_t qlen, const char* ref, uint32_t rlen, int32_t* out7) {
+    SwResult r = ssw_align(std::string(query, qlen), std::string(ref, rlen));
+    out7[0] = r.score; out7[1] = r.ref_begin; out7[2] = r.ref_end; out7[3] = r.query_begin; out7[4] = r.query_end;
+    out7[5] = (int32_t)r.ins; out7[6] = (int32_t)r.del;
+    return CW_OK;
+}
+
+/* alignConsensus + trimRead(…,1) + dropRead for one read (CONSENT-correction.cpp:47-56).
+ * cons: concatenated consensus strings, cons_len[n]; templates likewise; solid: concatenated ascending k-mers, solid_len[n];
+ * pos: n (beg,end) pairs.  out receives the final read ("" when dropped); *stitched_len / stitched (nullable) the string
+ * before trimming. */
+int cwo_stitch(const char* seq, uint32_t seq_len, uint32_t n, const char* cons, const uint32_t* cons_len, const char* tpls,
+               const uint32_t* tpl_len, const uint32_t* solid, const uint32_t* solid_len, const uint32_t* pos, uint32_t window_size,
+               uint32_t window_overlap, uint32_t mer_size, int do_trim, char* out, uint32_t cap, uint32_t* out_len, char* stitched,
+               uint32_t* stitched_len) {
+    std::vector<std::string> cs(n), ts(n);
+    std::vector<std::vector<uint32_t>> sl(n);
+    std::vector<std::pair<uint32_t, uint32_t>> pp(n);
+    size_t co = 0, to = 0, so = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        cs[i].assign(cons + co, cons_len[i]); co += cons_len[i];
+        ts[i].assign(tpls + to, tpl_len[i]); to += tpl_len[i];
+        sl[i].assign(solid + so, solid + so + solid_len[i]); so += solid_len[i];
+        pp[i] = {pos[2 * i], pos[2 * i + 1]};
+    }
+    std::string r = align_consensus(std::string(seq, seq_len), cs, sl, pp, ts, n ? (int)pp[0].first : 0, window_size, window_overlap, mer_size);
+    if (stitched && stitched_len) {
+        if (r.size() > cap) return CW_E_CAPACITY;
+        memcpy(stitched, r.data(), r.size());
+        *stitched_len = (uint32_t)r.size();
+    }
+    if (do_trim) {
+        r = trim_read(r, 1);
+        if (!r.empty() && drop_read(r)) r.clear();
+    }
+    if (r.size() > cap) return CW_E_CAPACITY;
+    memcpy(out, r.data(), r.size());
+    *out_len = (uint32_t)r.size();
+    return CW_OK;
+}
+
+int cwo_trim_read(const char* s, uint32_t len, uint32_t mer, char* out) {
+    std::string r = trim_read(std::string(s, len), mer);
+    memcpy(out, r.data(), r.size());
+    return (int)r.size();
+}
+int cwo_drop_read(const char* s, uint32_t len) { return drop_read(std::string(s, len)) ? 1 : 0; }
+
+} // extern "C"
