@@ -8,6 +8,7 @@
 #include "cw_poa.h"
 #include "cw_finish.h"
 #include "cw_extract.h"
+#include "cw_stitch.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -163,6 +164,7 @@ void cw_destroy(cw_engine* e) {
     if (e->dev_in) (void)hipFree(e->dev_in);
     if (e->dev_out) (void)hipFree(e->dev_out);
     if (e->xscratch) (void)hipFree(e->xscratch);
+    if (e->stitch_scratch) (void)hipFree(e->stitch_scratch);
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
     for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -421,6 +423,58 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
     if (tot_s > seq_cap || tot_w > word_cap || !win_first_seq || !seq_len || !seq_word_off || !bases) return CW_E_CAPACITY;
     cw_extract_fill_kernel<<<(n_jobs + 1 + 3) / 4, 256, 0, st>>>(a);
     CW_HIP(hipGetLastError());
+    return CW_OK;
+}
+
+int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_read* jobs, uint32_t n_reads, const uint32_t* win_pos,
+                     const cw_batch* batch, const cw_result* res, uint32_t window_size, uint32_t window_overlap, int32_t do_trim,
+                     char* out, const uint64_t* out_off, uint32_t* out_len, uint8_t* read_status, void* hip_stream) {
+    if (!e || !reads || !batch || !res || !out_off || !out_len || !read_status) return CW_E_INVALID;
+    if (n_reads == 0) return CW_OK;
+    if (!jobs || !win_pos || !out || !res->cons || !res->cons_off || !res->cons_len || !res->win_status || !res->solid || !res->solid_off ||
+        !res->solid_len || !batch->win_first_seq || !batch->seq_len || !batch->seq_word_off || !batch->bases)
+        return CW_E_INVALID;
+    if ((uint64_t)window_size + 2ull * window_overlap > CW_ST_RMAX) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const bool want_trace = getenv("CW_STITCH_TRACE") != nullptr;
+    int rc = ensure(&e->xscratch, &e->xscratch_bytes, 256 + (want_trace ? (size_t)batch->n_windows * 32 : 0));
+    if (rc) return rc;
+    CW_HIP(hipMemsetAsync(e->xscratch, 0, 16, st));
+    StitchArgs a;
+    a.trace = want_trace ? (uint32_t*)((uint8_t*)e->xscratch + 256) : nullptr;
+    if (want_trace) CW_HIP(hipMemsetAsync(a.trace, 0xFF, (size_t)batch->n_windows * 32, st));
+    a.reads = *reads; a.jobs = jobs; a.n_reads = n_reads; a.win_pos = win_pos;
+    a.batch.n_windows = batch->n_windows; a.batch.win_first_seq = batch->win_first_seq; a.batch.seq_len = batch->seq_len;
+    a.batch.seq_word_off = batch->seq_word_off; a.batch.bases = batch->bases;
+    a.cons = res->cons; a.cons_off = res->cons_off; a.cons_len = res->cons_len; a.win_status = res->win_status;
+    a.solid = res->solid; a.solid_off = res->solid_off; a.solid_len = res->solid_len;
+    a.window_size = window_size; a.window_overlap = window_overlap; a.mer_size = e->prm.k; a.do_trim = do_trim;
+    a.out = out; a.out_off = out_off; a.out_len = out_len; a.read_status = read_status; a.cursor = (uint32_t*)e->xscratch;
+    const size_t lds = (size_t)CW_ST_WAVES * CW_ST_SLAB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        CW_HIP(hipFuncSetAttribute((const void*)cw_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
+    if (wgs > CW_ST_MAX_WGS) wgs = CW_ST_MAX_WGS;
+    /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
+    a.dir_bytes = getenv("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(getenv("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
+    if (a.dir_bytes < 64) a.dir_bytes = 64;
+    rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs * CW_ST_WAVES * a.dir_bytes);
+    if (rc) return rc;
+    a.dir_scratch = (int8_t*)e->stitch_scratch;
+    cw_stitch_kernel<<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
+    CW_HIP(hipGetLastError());
+    return CW_OK;
+}
+
+int cw_debug_stitch_trace(cw_engine* e, uint32_t n_windows, uint32_t* out) {
+    if (!e || !out || !e->xscratch || e->xscratch_bytes < 256 + (size_t)n_windows * 32) return CW_E_INVALID;
+    CW_HIP(hipSetDevice(e->device));
+    CW_HIP(hipDeviceSynchronize());
+    CW_HIP(hipMemcpy(out, (uint8_t*)e->xscratch + 256, (size_t)n_windows * 32, hipMemcpyDeviceToHost));
     return CW_OK;
 }
 

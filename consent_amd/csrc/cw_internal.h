@@ -24,6 +24,8 @@ struct cw_engine {
     size_t dev_out_bytes;
     void* xscratch; /* pile-extraction scratch */
     size_t xscratch_bytes;
+    void* stitch_scratch; /* banded-traceback directions of cw_stitch_device, per wave */
+    size_t stitch_scratch_bytes;
     /* per-stage timing of the last run */
     hipStream_t side[3];          /* POA tiers run concurrently on their own streams */
     hipEvent_t ev_fork, ev_join[3];

@@ -1,0 +1,456 @@
+/*
+ * cw_stitch.h -- read re-assembly on the device: alignConsensus (correctionAlignment.cpp:47-140),
+ * trimRead(.,1) and dropRead (utils.cpp:96-128, :71-73) for every read of a batch, one wave per read.
+ *
+ * The local alignment the reference gets from StripedSmithWaterman::Aligner is restated per include/cw_policy.h
+ * (library absent: PARITY UNPINNED, bit-identical to the oracle's restatement):
+ *   sweep      lanes = query positions (chunks of 64), loop over reference columns; E carried per lane in LDS,
+ *              F (gap inside the column) as a DPP exclusive prefix max of h'[t] + t*ext, exact because open >= ext;
+ *              per column a wave max + lowest-row argmax; forward sweep finds (score, end), reverse sweep on the
+ *              reversed prefixes finds begin (stops when the forward score is reached)
+ *   indels     banded traceback, run by the whole wave redundantly (rare: only when two overlapping windows disagree)
+ *   the read   lives in its output slot as a gap buffer (left part at the front, untouched tail right-aligned), so a
+ *              replace that changes the length moves only the few hundred characters between the gap and the edit.
+ */
+#ifndef CW_STITCH_H
+#define CW_STITCH_H
+
+#include "cw_device.h"
+
+#define CW_ST_WAVES 4
+#define CW_ST_QMAX 2048 /* consensus length */
+#define CW_ST_RMAX 2048 /* aligned slice of the read: window_size + 2*window_overlap */
+/* per wave: slice codes | current consensus | previous consensus | H, E (int16) | query codes forward, reversed */
+#define CW_ST_DIR_BYTES (256u << 10) /* banded traceback directions, per wave, in global memory */
+#define CW_ST_MAX_WGS 512
+#define CW_ST_SLAB (CW_ST_RMAX + 2 * CW_ST_QMAX + 4 * CW_ST_QMAX + 2 * CW_ST_QMAX)
+
+struct StitchArgs {
+    cw_read_set reads;
+    const cw_stitch_read* jobs;
+    uint32_t n_reads;
+    const uint32_t* win_pos; /* [2 * n_windows] */
+    DevBatch batch;          /* the piles the consensuses came from (template = first sequence of a window) */
+    const char* cons;
+    const uint64_t* cons_off;
+    const uint32_t* cons_len;
+    const uint8_t* win_status;
+    const uint32_t* solid;
+    const uint64_t* solid_off;
+    const uint32_t* solid_len;
+    uint32_t window_size, window_overlap, mer_size;
+    int do_trim;
+    char* out;
+    const uint64_t* out_off;
+    uint32_t* out_len;
+    uint8_t* read_status; /* 0 ok, 1 dropped (dropRead), 2 capacity */
+    uint32_t* cursor;
+    int8_t* dir_scratch; /* dir_bytes per wave of the grid */
+    uint32_t dir_bytes;
+    uint32_t* trace; /* debug: 8 words per window, NULL in production */
+};
+
+__device__ __forceinline__ int st_code(uint8_t c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+__device__ __forceinline__ uint8_t st_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+__device__ __forceinline__ bool st_is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
+
+/* the read under construction: logical string = buf[0, L) + buf[cap-R, cap) */
+struct GapBuf {
+    uint8_t* buf;
+    uint32_t cap, L, R;
+    __device__ __forceinline__ uint32_t len() const { return L + R; }
+    __device__ __forceinline__ uint8_t at(uint32_t p) const { return p < L ? buf[p] : buf[cap - R + (p - L)]; }
+};
+
+/* move the gap so that the left part holds exactly the first `pos` characters (wave-parallel, pos <= len) */
+__device__ __forceinline__ void st_gap_to(GapBuf& g, uint32_t pos, int lane) {
+    if (pos > g.L) { /* bring characters over from the right part */
+        const uint32_t n = pos - g.L;
+        for (uint32_t base = 0; base < n; base += 64) { /* lowest first (ranges may overlap) */
+            const uint32_t x = base + lane;
+            uint8_t v = 0;
+            if (x < n) v = g.buf[g.cap - g.R + x];
+            cw_wave_sync();
+            if (x < n) g.buf[g.L + x] = v;
+            cw_wave_sync();
+        }
+        g.L += n; g.R -= n;
+    } else if (pos < g.L) { /* push the end of the left part to the front of the right part; highest first (ranges may overlap) */
+        const uint32_t n = g.L - pos;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t x = base + lane;
+            uint8_t v = 0;
+            if (x < n) v = g.buf[g.L - 1 - x];
+            cw_wave_sync();
+            if (x < n) g.buf[g.cap - g.R - 1 - x] = v;
+            cw_wave_sync();
+        }
+        g.L -= n; g.R += n;
+    }
+    cw_wave_sync();
+}
+
+/* Everything that steers control flow is wave-uniform; telling the compiler so (scalar registers, scalar branches) keeps
+ * the 64 lanes on one path and the cross-lane operations below well defined. */
+__device__ __forceinline__ int st_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t st_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct StSweep { int score, col, row; };
+
+/*
+ * One local-alignment sweep.  q[] (m codes, already in sweep order) against r[] walked from r_first in `step` until
+ * r_last_excl.  H/E are per-query-position state in LDS.  Stops early when `terminate` is reached (-1: never).
+ */
+__device__ __forceinline__ StSweep st_sweep(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int16_t* H,
+                            int16_t* E, int lane) {
+    const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
+    for (int j = lane; j < m; j += 64) { H[j] = 0; E[j] = 0; }
+    cw_wave_sync();
+    StSweep best{0, -1, 0};
+    for (int i = r_first; i != r_last_excl; i += step) {
+        const int rc = st_uni((int)r[i]);
+        int carry_diag = 0;          /* H of the previous column at row 64c-1 */
+        int carry_f = CW_NEG;        /* running max of h'[t] + t*GE over earlier rows of this column */
+        int lane_max = 0, lane_row = 0x7FFFFFFF;
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int j = c0 + lane;
+            const bool act = j < m;
+            const int hprev = act ? (int)H[j] : 0;
+            int e = act ? max((int)E[j] - GE, hprev - GO) : 0;
+            e = max(e, 0);
+            const int diag = cw_wave_shr1(hprev, carry_diag);
+            carry_diag = cw_lane_value(hprev, 63);
+            const int qc = act ? (int)q[j] : 4;
+            const int s = (qc == 4 || rc == 4) ? 0 : (qc == rc ? CW_SSW_MATCH : -CW_SSW_MISMATCH);
+            int hp = max(max(diag + s, e), 0);
+            /* F[j] = max_{t<j}(h'[t] - GO - (j-1-t)*GE) = pmax_excl(h'[t] + t*GE) - GO - (j-1)*GE, clamped at 0 */
+            const int key = act ? hp + j * GE : CW_NEG;
+            const int inc = cw_wave_scan_max(key);
+            int ex = cw_wave_shr1(inc, CW_NEG);
+            ex = max(ex, carry_f);
+            carry_f = max(carry_f, cw_lane_value(inc, 63));
+            int f = ex - GO - (j - 1) * GE;
+            f = max(f, 0);
+            const int h = max(hp, f);
+            if (act) {
+                H[j] = (int16_t)h; E[j] = (int16_t)e;
+                if (h > lane_max) { lane_max = h; lane_row = j; }
+            }
+        }
+        /* column maximum, lowest row holding it */
+        int cm = lane_max, cr = lane_row;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int om = __shfl_xor(cm, o), orr = __shfl_xor(cr, o);
+            if (om > cm || (om == cm && orr < cr)) { cm = om; cr = orr; }
+        }
+        cm = st_uni(cm); cr = st_uni(cr);
+        if (cm > best.score) {
+            best.score = cm; best.col = i; best.row = cr;
+            if (best.score == terminate) break;
+        }
+        cw_wave_sync();
+    }
+    return best;
+}
+
+/* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
+ * (lane 0 walks the band; rare: only when two overlapping windows disagree and the earlier one wins).
+ * rows: int32 h_b/e_b/h_c (3*width) in LDS; dir: the direction bytes (width_d*readLen*3) in this wave's global scratch. */
+__device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen, const uint8_t* read, int readLen, int score, uint8_t* rows, uint32_t rows_bytes,
+                                 int8_t* dir, uint32_t dir_bytes, unsigned* ins, unsigned* del, int lane) {
+    const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    *ins = 0; *del = 0;
+    refLen = st_uni(refLen); readLen = st_uni(readLen); score = st_uni(score);
+    if (refLen <= 0 || readLen <= 0) return true;
+    int band = abs(refLen - readLen) + 1;
+    int width_d = 0;
+    for (;;) {
+        const int width = band * 2 + 3;
+        width_d = band * 2 + 1;
+        if ((size_t)width * 12 > rows_bytes || (size_t)width_d * readLen * 3 > dir_bytes) return false;
+        int* h_b = (int*)rows; int* e_b = h_b + width; int* h_c = e_b + width;
+        if (lane == 0) for (int x = 0; x < width; ++x) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
+        for (int x = lane; x < width_d * readLen * 3; x += 64) dir[x] = 0; /* cells outside the band read as "stop" */
+        cw_wave_sync();
+        int mx = 0;
+        if (lane == 0) {
+            for (int i = 0; i < readLen; ++i) {
+                int beg = 0, end = refLen - 1, u = 0;
+                int j = i - band; beg = beg > j ? beg : j;
+                j = i + band; end = end < j ? end : j;
+                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+                int f = 0;
+                h_b[0] = e_b[0] = h_b[edge] = e_b[edge] = h_c[0] = 0;
+                int8_t* line = dir + (size_t)width_d * i * 3;
+                for (j = beg; j <= end; ++j) {
+                    int x;
+#define ST_SET_U(res, ii, jj) do { x = (ii) - band; x = x > 0 ? x : 0; (res) = (jj) - x + 1; } while (0)
+#define ST_SET_D(res, ii, jj, pp) do { x = (ii) - band; x = x > 0 ? x : 0; x = (jj) - x; (res) = x * 3 + (pp); } while (0)
+                    int e, b_, d, de, df, dh;
+                    ST_SET_U(u, i, j); ST_SET_U(e, i - 1, j); ST_SET_U(b_, i, j - 1); ST_SET_U(d, i - 1, j - 1);
+                    ST_SET_D(de, i, j, 0); ST_SET_D(df, i, j, 1); ST_SET_D(dh, i, j, 2);
+                    int t1 = i == 0 ? -GO : h_b[e] - GO;
+                    int t2 = i == 0 ? -GE : e_b[e] - GE;
+                    e_b[u] = t1 > t2 ? t1 : t2;
+                    line[de] = t1 > t2 ? 3 : 2;
+                    t1 = h_c[b_] - GO;
+                    t2 = f - GE;
+                    f = t1 > t2 ? t1 : t2;
+                    line[df] = t1 > t2 ? 5 : 4;
+                    const int e1 = e_b[u] > 0 ? e_b[u] : 0, f1 = f > 0 ? f : 0;
+                    t1 = e1 > f1 ? e1 : f1;
+                    const int a = ref[j], bq = read[i];
+                    t2 = h_b[d] + ((a == 4 || bq == 4) ? 0 : (a == bq ? CW_SSW_MATCH : -CW_SSW_MISMATCH));
+                    h_c[u] = t1 > t2 ? t1 : t2;
+                    if (h_c[u] > mx) mx = h_c[u];
+                    if (t1 <= t2) line[dh] = 1;
+                    else line[dh] = e1 > f1 ? line[de] : line[df];
+                }
+                for (j = 1; j <= u; ++j) h_b[j] = h_c[j];
+            }
+        }
+        mx = cw_lane_value(mx, 0);
+        __threadfence_block();
+        cw_wave_sync();
+        if (mx >= score || band > refLen + readLen) break;
+        band *= 2;
+    }
+    unsigned ni = 0, nd = 0;
+    if (lane == 0) {
+        int i = readLen - 1, j = refLen - 1, state = 2;
+        while (i > 0 && j >= 0) {
+            const int8_t* line = dir + (size_t)width_d * i * 3;
+            int x = i - band; x = x > 0 ? x : 0; x = j - x;
+            const int idx = x * 3 + state;
+            if (idx < 0 || idx >= width_d * 3) break;
+            const int dcode = line[idx];
+            if (dcode == 1) { --i; --j; state = 2; }
+            else if (dcode == 2) { --i; state = 0; ++ni; }
+            else if (dcode == 3) { --i; state = 2; ++ni; }
+            else if (dcode == 4) { --j; state = 1; ++nd; }
+            else if (dcode == 5) { --j; state = 2; ++nd; }
+            else break;
+        }
+    }
+#undef ST_SET_U
+#undef ST_SET_D
+    *ins = (unsigned)cw_lane_value((int)ni, 0);
+    *del = (unsigned)cw_lane_value((int)nd, 0);
+    return true;
+}
+
+struct StAlign { int score, ref_begin, ref_end, query_begin, query_end; };
+
+/* full alignment: forward sweep, reverse sweep.  qfw = query codes; qrv = scratch for the reversed prefix. */
+__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int16_t* H, int16_t* E, int lane) {
+    StAlign a{0, 0, -1, 0, -1};
+    m = st_uni(m); n = st_uni(n);
+    if (m <= 0 || n <= 0) return a;
+    const StSweep fw = st_sweep(qfw, m, ref, 0, n, 1, -1, H, E, lane);
+    a.score = fw.score;
+    if (fw.score <= 0) return a;
+    a.ref_end = fw.col; a.query_end = fw.row;
+    const int pm = fw.row + 1;
+    for (int x = lane; x < pm; x += 64) qrv[x] = qfw[fw.row - x];
+    cw_wave_sync();
+    const StSweep bw = st_sweep(qrv, pm, ref, fw.col, -1, -1, fw.score, H, E, lane);
+    a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
+    return a;
+}
+
+/* number of solid k-mers of a string under the policy "anything but A, C, G is T" (correctionAlignment.cpp:6-15) */
+__device__ __forceinline__ int st_nb_solid(const uint8_t* s, int len, const uint32_t* solid, uint32_t n_solid, uint32_t k, int lane) {
+    int nb = 0;
+    for (int p = lane; p + (int)k <= len; p += 64) {
+        uint32_t v = 0;
+        for (uint32_t x = 0; x < k; ++x) { const uint8_t c = s[p + x]; v = (v << 2) | (c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u); }
+        int lo = 0, hi = (int)n_solid - 1;
+        bool hit = false;
+        while (lo <= hi) { const int mid = (lo + hi) >> 1; const uint32_t t = solid[mid]; if (t == v) { hit = true; break; } if (t < v) lo = mid + 1; else hi = mid - 1; }
+        nb += hit ? 1 : 0;
+    }
+    return st_uni(cw_wave_sum(nb));
+}
+
+__global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB;
+    uint8_t* refc = slab;                              /* CW_ST_RMAX codes of the aligned slice              */
+    uint8_t* cur = refc + CW_ST_RMAX;                  /* current consensus (chars), CW_ST_QMAX              */
+    uint8_t* old = cur + CW_ST_QMAX;                   /* previous window's consensus as written, CW_ST_QMAX */
+    int16_t* H = (int16_t*)(old + CW_ST_QMAX);         /* CW_ST_QMAX                                          */
+    int16_t* E = H + CW_ST_QMAX;                       /* CW_ST_QMAX                                          */
+    uint8_t* qfw = (uint8_t*)(E + CW_ST_QMAX);        /* CW_ST_QMAX query codes                              */
+    uint8_t* qrv = qfw + CW_ST_QMAX;                   /* CW_ST_QMAX reversed prefix / build area             */
+    int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * CW_ST_WAVES + wave) * a.dir_bytes;
+    for (;;) {
+        uint32_t ri = 0;
+        if (lane == 0) ri = atomicAdd(a.cursor, 1u);
+        ri = (uint32_t)cw_lane_value((int)ri, 0);
+        if (ri >= a.n_reads) break;
+        cw_stitch_read jb = a.jobs[ri];
+        jb.read = st_uni(jb.read); jb.win_first = st_uni(jb.win_first); jb.win_count = st_uni(jb.win_count);
+        const uint32_t rlen = st_uni(a.reads.read_len[jb.read]);
+        const uint32_t* rwords = a.reads.bases + a.reads.read_word_off[jb.read];
+        GapBuf g;
+        g.buf = (uint8_t*)a.out + a.out_off[ri];
+        g.cap = st_uni((uint32_t)(a.out_off[ri + 1] - a.out_off[ri]));
+        /* One way through the loop body: every read ends at the single store + wave barrier at the bottom.  (A lane-0 store
+           followed by `continue` lets the compiler send lane 0 round a back edge of its own; the cross-lane broadcast at the
+           top of the next iteration then runs without it.) */
+        uint32_t status = g.cap < rlen ? (uint32_t)CW_READ_CAPACITY : 0u;
+        const uint32_t n_fill = status ? 0u : rlen;
+        /* outSequence = lower-case read (:56-57), everything in the right part: the gap starts at 0 */
+        for (uint32_t x = lane; x < n_fill; x += 64) g.buf[g.cap - rlen + x] = "acgt"[cw_base_at(rwords, x)];
+        g.L = 0; g.R = n_fill;
+        cw_wave_sync();
+
+        int cur_pos = jb.win_count ? st_uni((int)a.win_pos[2 * jb.win_first]) : 0;   /* startPos = pilesPos[0].first (CONSENT-correction.cpp:47) */
+        uint32_t old_end = 0, old_len = 0, old_w = 0;
+        bool have_old = false;
+        for (uint32_t wi = 0; wi < jb.win_count && status == 0; ++wi) {
+            const uint32_t w = jb.win_first + wi;
+            if (st_uni((int)a.win_status[w]) == CW_WIN_OVERFLOW) continue;                 /* no consensus for this window: leave the read as it is */
+            uint32_t clen = st_uni(a.cons_len[w]);
+            const bool long_enough = clen >= a.mer_size;                      /* :75 / :98 / :125 */
+            if (long_enough) {
+                if (clen > CW_ST_QMAX) { status = 2; break; }
+                const char* src = a.cons + a.cons_off[w];
+                for (uint32_t x = lane; x < clen; x += 64) cur[x] = (uint8_t)src[x];
+            } else {                                                          /* :76 the window's template */
+                const uint32_t ts = a.batch.win_first_seq[w];
+                clen = st_uni((a.batch.win_first_seq[w + 1] > ts) ? a.batch.seq_len[ts] : 0u);
+                if (clen > CW_ST_QMAX) { status = 2; break; }
+                const uint32_t* tw = a.batch.bases + a.batch.seq_word_off[ts];
+                for (uint32_t x = lane; x < clen; x += 64) cur[x] = "ACGT"[cw_base_at(tw, x)];
+            }
+            cw_wave_sync();
+            const int al_pos = max(0, cur_pos - (int)a.window_overlap);                                    /* :83 */
+            const uint32_t tot = g.len();
+            int size_al;
+            if ((uint64_t)al_pos + a.window_size + 2ull * a.window_overlap >= tot) size_al = (int)tot - al_pos;   /* :84-88 */
+            else size_al = (int)(a.window_size + 2 * a.window_overlap);
+            if (size_al <= 0 || clen == 0) continue;
+            if (size_al > CW_ST_RMAX) { status = 2; break; }
+            for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
+            for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
+            cw_wave_sync();
+            const StAlign al = st_align(qfw, (int)clen, qrv, refc, size_al, H, E, lane);                   /* :90 */
+            if (a.trace && lane == 0) {
+                uint32_t* t = a.trace + 8 * (size_t)w;
+                t[0] = (uint32_t)al_pos; t[1] = (uint32_t)size_al; t[2] = (uint32_t)al.score; t[3] = (uint32_t)al.ref_begin; t[4] = (uint32_t)al.ref_end;
+                t[5] = (uint32_t)al.query_begin; t[6] = (uint32_t)al.query_end; t[7] = clen;
+            }
+            if (al.score <= 0) continue;
+            const uint32_t beg = (uint32_t)(al.ref_begin + al_pos), end = (uint32_t)(al.ref_end + al_pos); /* :91-92 */
+            /* curCons = curCons.substr(query_begin, ...) (:93): shift down in place */
+            uint32_t cl = (uint32_t)(al.query_end - al.query_begin + 1);
+            if (al.query_begin > 0) {
+                for (uint32_t base = 0; base < cl; base += 64) {
+                    const uint32_t x = base + lane;
+                    uint8_t v = 0;
+                    if (x < cl) v = cur[al.query_begin + x];
+                    cw_wave_sync();
+                    if (x < cl) cur[x] = v;
+                    cw_wave_sync();
+                }
+            }
+            bool emptied = false;
+            if (wi != 0 && have_old && old_end >= beg) {                                                   /* :96 */
+                const uint32_t overlap = old_end - beg + 1;
+                if (long_enough && old_len >= overlap && cl >= overlap) {                                   /* :98 */
+                    const uint8_t* seq1 = old + (old_len - overlap);                                        /* :99 */
+                    bool diff = false;
+                    for (uint32_t x = lane; x < overlap; x += 64) diff = diff || (st_upper(seq1[x]) != st_upper(cur[x]));
+                    if (__ballot(diff) != 0ull) {                                                           /* :101 */
+                        int s1, s2;
+                        if (overlap >= a.mer_size) {                                                        /* :102-104 */
+                            s1 = st_nb_solid(seq1, (int)overlap, a.solid + a.solid_off[old_w], a.solid_len[old_w], a.mer_size, lane);
+                            s2 = st_nb_solid(cur, (int)overlap, a.solid + a.solid_off[w], a.solid_len[w], a.mer_size, lane);
+                        } else {                                                                            /* :106-107 */
+                            int u1 = 0, u2 = 0;
+                            for (uint32_t x = lane; x < overlap; x += 64) { u1 += st_is_upper(seq1[x]) ? 1 : 0; u2 += st_is_upper(cur[x]) ? 1 : 0; }
+                            s1 = st_uni(cw_wave_sum(u1)); s2 = st_uni(cw_wave_sum(u2));
+                        }
+                        if (s1 > s2) {                                                                      /* :109-119 */
+                            /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
+                            for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
+                            cw_wave_sync();
+                            const StAlign sub = st_align(qfw, (int)overlap, qrv, refc, (int)overlap, H, E, lane);
+                            unsigned ins = 0, del = 0;
+                            if (sub.score > 0) {
+                                if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
+                                                      sub.score, (uint8_t*)H, 4u * CW_ST_QMAX, dirbuf, a.dir_bytes, &ins, &del, lane)) { status = 2; break; }
+                            }
+                            const uint32_t cut = overlap - ins + del;
+                            if (cut < cl) {                                                                 /* :114-115 curCons = seq1 + curCons.substr(cut) */
+                                const uint32_t tail = cl - cut, nl = overlap + tail;
+                                if (nl > CW_ST_QMAX) { status = 2; break; }
+                                /* build in qrv (free now), then copy back */
+                                for (uint32_t x = lane; x < nl; x += 64) qrv[x] = x < overlap ? seq1[x] : cur[cut + (x - overlap)];
+                                cw_wave_sync();
+                                for (uint32_t x = lane; x < nl; x += 64) cur[x] = qrv[x];
+                                cl = nl;
+                                cw_wave_sync();
+                            } else {
+                                emptied = true;                                                             /* :117 */
+                            }
+                        }
+                    }
+                }
+            }
+            if (!emptied && cl > 0) {                                                                       /* :124 */
+                if (long_enough) {                                                                          /* :125-129 replace(beg, end-beg+1, upper(cur)) */
+                    const uint32_t rl = end - beg + 1;
+                    if (g.len() - rl + cl > g.cap) { status = 2; break; }
+                    st_gap_to(g, beg + rl, lane);
+                    g.L = beg;
+                    for (uint32_t x = lane; x < cl; x += 64) g.buf[g.L + x] = st_upper(cur[x]);
+                    g.L += cl;
+                    cw_wave_sync();
+                }
+                if (wi + 1 < jb.win_count) {                                                                /* :130-135 */
+                    const long long np = (long long)cur_pos + (long long)st_uni(a.win_pos[2 * (w + 1)]) - (long long)st_uni(a.win_pos[2 * w]) - (long long)(end - beg + 1) + (long long)cl;
+                    cur_pos = (int)(uint32_t)np;
+                    for (uint32_t x = lane; x < cl; x += 64) old[x] = cur[x];
+                    old_len = cl; old_w = w; have_old = true;
+                    old_end = beg + cl - 1;
+                    cw_wave_sync();
+                }
+            }
+        }
+        /* make the string contiguous */
+        if (status == 0) st_gap_to(g, g.len(), lane);
+        uint32_t flen = status == 0 ? g.L : 0u, fbeg = 0;
+        if (a.do_trim && status == 0) { /* trimRead(.,1): first and last upper-case character; dropRead: < 10 % upper case */
+            uint32_t first = 0xFFFFFFFFu, last = 0, ups = 0;
+            for (uint32_t x = lane; x < flen; x += 64) if (st_is_upper(g.buf[x])) { first = min(first, x); last = max(last, x); ups++; }
+            for (int o = 32; o > 0; o >>= 1) { first = min(first, (uint32_t)__shfl_xor((int)first, o)); last = max(last, (uint32_t)__shfl_xor((int)last, o)); }
+            ups = st_uni((uint32_t)cw_wave_sum((int)ups)); first = st_uni(first); last = st_uni(last);
+            if (first == 0xFFFFFFFFu || !(last > first)) { flen = 0; }            /* utils.cpp:123-127: end > beg else "" */
+            else {
+                fbeg = first; flen = last - first + 1;
+                if ((float)ups / (float)flen < 0.1) { flen = 0; status = 1; }     /* dropRead on the trimmed read (CONSENT-correction.cpp:52) */
+            }
+            if (flen && fbeg) {
+                for (uint32_t base = 0; base < flen; base += 64) {
+                    const uint32_t x = base + lane;
+                    uint8_t v = 0;
+                    if (x < flen) v = g.buf[fbeg + x];
+                    cw_wave_sync();
+                    if (x < flen) g.buf[x] = v;
+                    cw_wave_sync();
+                }
+            }
+        }
+        flen = st_uni(flen); status = st_uni(status);
+        if (lane == 0) { a.out_len[ri] = flen; a.read_status[ri] = (uint8_t)status; }
+        cw_wave_sync();
+    }
+}
+
+#endif

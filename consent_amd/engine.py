@@ -109,6 +109,8 @@ def load_library():
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_extract_piles_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.cw_stitch_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_uint32, C.c_uint32,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_window_positions.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
@@ -311,11 +313,50 @@ class Engine:
         o_len = torch.zeros(max(ns.value, 1), dtype=torch.int32, device=dev)
         o_off = torch.zeros(max(ns.value, 1), dtype=torch.int64, device=dev)
         o_bases = torch.zeros(max(nw.value, 1) + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # the engine launches on its own stream: torch's fills above must have landed
         _check(self.lib, self.lib.cw_extract_piles_device(self.handle, C.byref(rs), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), len(jb), k, o_wfs.data_ptr(), o_len.data_ptr(),
                                                           o_off.data_ptr(), o_bases.data_ptr(), ns.value, nw.value, C.byref(ns), C.byref(nw), None), "cw_extract_piles_device")
         torch.cuda.synchronize()
         return HostBatch(o_wfs.cpu().numpy().view(np.uint32), o_len.cpu().numpy().view(np.uint32)[: ns.value], o_off.cpu().numpy().view(np.uint64)[: ns.value],
                          o_bases.cpu().numpy().view(np.uint32)[: max(nw.value, 1)])
+
+    def stitch(self, reads, jobs, win_pos, batch, results, window_size=500, window_overlap=50, do_trim=True):
+        """Device-side alignConsensus + trimRead + dropRead (cw_stitch_device).  `reads`: HostBatch-like packing of the read set;
+        `jobs`: (n,3) uint32 (read, win_first, win_count); `win_pos`: (W,2) uint32 window (beg,end); `batch`/`results`: the piles
+        and what the engine returned for them.  Returns [(corrected_read, status)]."""
+        import torch
+
+        dev = torch.device("cuda", 0)
+
+        def up(a, dt):
+            a = np.ascontiguousarray(a)
+            if a.size == 0:
+                a = np.zeros(1, a.dtype)
+            return torch.from_numpy(a.view(dt)).to(dev)
+
+        jb = np.ascontiguousarray(jobs, np.uint32).reshape(-1, 3)
+        t_len, t_off, t_bases = up(reads.seq_len, np.int32), up(reads.seq_word_off, np.int64), up(np.concatenate([reads.bases, np.zeros(1, np.uint32)]), np.int32)
+        rs = ReadSet(len(reads.seq_len), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr())
+        b_wfs, b_len, b_off, b_bases = up(batch.win_first_seq, np.int32), up(batch.seq_len, np.int32), up(batch.seq_word_off, np.int64), up(np.concatenate([batch.bases, np.zeros(1, np.uint32)]), np.int32)
+        bs = Batch(batch.n_windows, len(batch.seq_len), len(batch.bases), b_wfs.data_ptr(), b_len.data_ptr(), b_off.data_ptr(), b_bases.data_ptr())
+        r = results
+        r_cons, r_coff, r_clen, r_st = up(r.cons, np.uint8), up(r.cons_off, np.int64), up(r.cons_len, np.int32), up(r.status, np.uint8)
+        r_sol, r_soff, r_slen = up(r.solid, np.int32), up(r.solid_off, np.int64), up(r.solid_len, np.int32)
+        rstruct = Result(r_cons.data_ptr(), r_coff.data_ptr(), r_clen.data_ptr(), r_st.data_ptr(), r_sol.data_ptr(), r_soff.data_ptr(), r_slen.data_ptr())
+        t_jb, t_pos = up(jb, np.int32), up(np.ascontiguousarray(win_pos, np.uint32).reshape(-1), np.int32)
+        cap = 2 * reads.seq_len[jb[:, 0]].astype(np.int64) + 1024
+        out_off = np.zeros(len(jb) + 1, np.uint64)
+        out_off[1:] = np.cumsum(cap)
+        t_ooff = up(out_off, np.int64)
+        t_out = torch.zeros(int(out_off[-1]) + 1, dtype=torch.uint8, device=dev)
+        t_olen = torch.zeros(len(jb) + 1, dtype=torch.int32, device=dev)
+        t_ost = torch.full((len(jb) + 1,), 255, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()  # the engine launches on its own stream: torch's fills above must have landed
+        _check(self.lib, self.lib.cw_stitch_device(self.handle, C.byref(rs), t_jb.data_ptr(), len(jb), t_pos.data_ptr(), C.byref(bs), C.byref(rstruct), window_size, window_overlap,
+                                                   int(bool(do_trim)), t_out.data_ptr(), t_ooff.data_ptr(), t_olen.data_ptr(), t_ost.data_ptr(), None), "cw_stitch_device")
+        torch.cuda.synchronize()
+        out, olen, ost = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy()
+        return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode(), int(ost[i])) for i in range(len(jb))]
 
     def timings(self):
         ms = (C.c_float * 16)()

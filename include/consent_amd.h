@@ -164,6 +164,34 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
                             uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
                             uint64_t* n_words, void* hip_stream);
 
+/* ---- read re-assembly on the device -------------------------------------------------
+ * Stands in for alignConsensus (src/correctionAlignment.cpp:47-140) followed, when do_trim != 0, by trimRead(.,1) and
+ * dropRead (src/CONSENT-correction.cpp:47-58, src/utils.cpp:96-128, :71-73): every window consensus of a read is
+ * aligned back onto the lower-cased read (local alignment, scores and position rules in include/cw_policy.h) and
+ * replaces the aligned stretch in upper case; overlapping windows are reconciled by their solid k-mers. */
+typedef struct cw_stitch_read {
+    uint32_t read;                 /* the template in the read set (sequences[alignments[0].qName])                  */
+    uint32_t win_first, win_count; /* its windows in the batch / result arrays, in pilesPos order                     */
+} cw_stitch_read;
+
+#define CW_READ_OK       0
+#define CW_READ_DROPPED  1  /* dropRead: fewer than 10 % corrected bases after trimming; out_len = 0                    */
+#define CW_READ_CAPACITY 2  /* output slot, consensus (> 2048) or aligned slice (> 2048) too large; out_len = 0          */
+
+/* All pointers are DEVICE pointers.  `win_pos` = (beg,end) per window as cw_window_positions wrote them; `batch` = the piles
+ * the consensuses were computed from (the first sequence of a window is its template, CONSENT-correction.cpp:37);
+ * `res` = what cw_run_device filled (cons, cons_off, cons_len, win_status, solid, solid_off, solid_len; solid is required).
+ * out_off[n_reads+1] gives every read a slot (2*read_len + 1024 is ample); the corrected read is written at its start,
+ * out_len[r] characters, upper case = corrected.  Windows with CW_WIN_OVERFLOW are left uncorrected.  Asynchronous on
+ * `hip_stream` (NULL = the engine's stream). */
+int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_read* jobs, uint32_t n_reads, const uint32_t* win_pos,
+                     const cw_batch* batch, const cw_result* res, uint32_t window_size, uint32_t window_overlap, int32_t do_trim,
+                     char* out, const uint64_t* out_off, uint32_t* out_len, uint8_t* read_status, void* hip_stream);
+
+/* debug: with CW_STITCH_TRACE set in the environment the last cw_stitch_device call records, per window, 8 words
+ * (al_pos, size_al, score, ref_begin, ref_end, query_begin, query_end, query_len); 0xFFFFFFFF = window not aligned. */
+int cw_debug_stitch_trace(cw_engine* e, uint32_t n_windows, uint32_t* out);
+
 /* ---- synthetic PacBio/ONT-profile piles (bench + tests; SURVEY 8d generator) --------------------- */
 typedef struct cw_synth_spec {
     uint64_t seed;        /* window w draws from seed + first_window + w            */

@@ -1,0 +1,172 @@
+"""GPU: cw_stitch_device (alignConsensus + trimRead + dropRead on the device) against the oracle's restatement,
+fed with the same window consensuses and solid sets.  Bit-exact strings and statuses."""
+import random
+
+import numpy as np
+import pytest
+
+import consent_amd as ca
+import oracle_lib
+from test_oracle_ref import rand_seq
+from test_oracle_stitch import noisy, stitch
+
+pytestmark = pytest.mark.gpu
+
+K, SOLID = 9, 4
+
+
+def make_reads(seed, n_reads, depth, lo=900, hi=3200, rate=0.12):
+    """n_reads templates over one genome, each with `depth` covering reads (coordinates by construction)."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n_reads):
+        glen = rng.randrange(lo, hi)
+        genome = rand_seq(rng, glen)
+        read = noisy(rng, genome, rate)
+        targets, rows = [], []
+        for t in range(depth):
+            a = rng.randrange(0, max(1, glen // 5)) if rng.random() < 0.5 else 0
+            b = glen - (rng.randrange(0, max(1, glen // 5)) if rng.random() < 0.5 else 0)
+            tg = noisy(rng, genome[a:b], rate)
+            targets.append(tg)
+            qs = int(a / glen * len(read))
+            qe = min(len(read) - 1, int(b / glen * len(read)))
+            rows.append([len(read), qs, qe, 0, len(tg), 0, len(tg) - 1, t])
+        out.append((read, targets, rows))
+    return out
+
+
+def build(reads_spec, window_size=500, window_overlap=50, min_support=3):
+    """windows + piles of every read with the (reference-pinned) oracle feeders"""
+    o = oracle_lib.oracle()
+    piles, pos, jobs, reads = [], [], [], []
+    for ri, (read, targets, rows) in enumerate(reads_spec):
+        wins = oracle_lib.window_positions(o.cwo_window_positions, len(read), rows, min_support, window_size, window_overlap)
+        jobs.append((ri, len(piles), len(wins)))
+        for (qb, qe) in wins:
+            piles.append(oracle_lib.window_pile(o.cwo_window_pile, rows, read, targets, qb, qe, K))
+            pos.append((qb, qe))
+        reads.append(read)
+    return reads, jobs, pos, piles
+
+
+def oracle_stitch_all(reads, jobs, pos, piles, res, do_trim, window_size=500, window_overlap=50, k=K):
+    out = []
+    for (ri, w0, wn) in jobs:
+        cons = [res.consensus(w) for w in range(w0, w0 + wn)]
+        solid = [res.solid_kmers(w) for w in range(w0, w0 + wn)]
+        tpls = [piles[w][0] if piles[w] else "" for w in range(w0, w0 + wn)]
+        final, _ = stitch(reads[ri], cons, tpls, solid, pos[w0 : w0 + wn], do_trim=do_trim, k=k, wsize=window_size, wover=window_overlap)
+        out.append(final)
+    return out
+
+
+def run_case(spec, do_trim=True, mutate=None, window_size=500, window_overlap=50, prm=None):
+    reads, jobs, pos, piles = build(spec, window_size, window_overlap)
+    prm = prm or ca.Params(K, SOLID, 8, 2, 150)
+    eng = ca.Engine(prm)
+    try:
+        batch = ca.pack_piles(piles)
+        res = eng.run(batch, want_solid=True)
+        assert not (res.status == ca.WIN_OVERFLOW).any()
+        if mutate:
+            mutate(res, piles)
+        got = eng.stitch(ca.pack_piles([reads]), np.array(jobs, np.uint32), np.array(pos, np.uint32), batch, res, window_size, window_overlap, do_trim)
+    finally:
+        eng.close()
+    want = oracle_stitch_all(reads, jobs, pos, piles, res, do_trim, window_size, window_overlap, prm.k)
+    n_up = 0
+    for i, ((g, st), w) in enumerate(zip(got, want)):
+        assert st in (0, 1), (i, st)
+        assert g == w, (i, len(g), len(w), first_diff(g, w))
+        n_up += sum(c.isupper() for c in g)
+    return got, n_up
+
+
+def first_diff(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            return i, a[max(0, i - 20) : i + 20], b[max(0, i - 20) : i + 20]
+    return min(len(a), len(b)), "", ""
+
+
+def test_stitch_matches_oracle_pacbio_like():
+    got, n_up = run_case(make_reads(101, 6, 20))
+    assert n_up > 0 and all(g for g, _ in got)
+
+
+def test_stitch_without_trimming_keeps_the_uncorrected_ends():
+    got, _ = run_case(make_reads(102, 4, 14), do_trim=False)
+    assert any(g[0].islower() or g[-1].islower() for g, _ in got)
+
+
+def test_stitch_with_sparse_coverage_and_dropped_reads():
+    # depth 3 with partial overlaps: few windows, long lower-case stretches, some reads dropped or empty
+    spec = make_reads(103, 8, 3, lo=700, hi=2500)
+    got, _ = run_case(spec)
+    spec0 = [(spec[0][0], [], [])]  # a read without any overlap: no window at all
+    got0, _ = run_case(spec0)
+    assert got0[0][0] == ""
+
+
+def test_stitch_overlap_reconciliation_paths():
+    """Damage the head of every second consensus: overlapping windows now disagree, the previous window has more solid k-mers,
+    and the banded traceback decides where to cut (correctionAlignment.cpp:101-119)."""
+    rng = random.Random(7)
+
+    def mutate(res, piles):
+        for w in range(1, len(piles), 2):
+            o, n = int(res.cons_off[w]), int(res.cons_len[w])
+            if n < 120:
+                continue
+            s = bytearray(res.cons[o : o + n].tobytes())
+            for _ in range(6):
+                p = rng.randrange(5, 70)
+                s[p] = ord(rng.choice("ACGT"))
+            # one deletion and one insertion inside the overlap, length preserved
+            p = rng.randrange(10, 40)
+            del s[p]
+            q = rng.randrange(40, 70)
+            s.insert(q, ord(rng.choice("ACGT")))
+            res.cons[o : o + n] = np.frombuffer(bytes(s), np.uint8)
+
+    run_case(make_reads(104, 6, 18), mutate=mutate)
+
+
+def test_stitch_short_consensus_falls_back_to_the_template_without_writing():
+    def mutate(res, piles):
+        for w in range(0, len(piles), 3):
+            res.cons_len[w] = 5  # < merSize: correctionAlignment.cpp:75-77 aligns the template and :125 skips the replace
+
+    run_case(make_reads(105, 4, 16), mutate=mutate)
+
+
+def test_stitch_other_window_geometry_and_k():
+    run_case(make_reads(106, 4, 16), window_size=300, window_overlap=30, prm=ca.Params(7, 4, 8, 2, 150))
+    run_case(make_reads(107, 3, 16, rate=0.15), window_size=700, window_overlap=80, prm=ca.Params(11, 3, 6, 2, 150))
+
+
+def test_stitch_many_reads_in_one_launch():
+    got, n_up = run_case(make_reads(108, 40, 10, lo=600, hi=1800))
+    assert len(got) == 40 and n_up > 0
+
+
+def test_stitch_capacity_path_reports_status_and_does_not_disturb_other_reads(monkeypatch):
+    """Shrink the banded-traceback scratch: reads that need it report CW_READ_CAPACITY (2) with an empty result, the others
+    are still bit-exact."""
+    spec = make_reads(102, 4, 14)
+    reads, jobs, pos, piles = build(spec)
+    prm = ca.Params(K, SOLID, 8, 2, 150)
+    eng = ca.Engine(prm)
+    try:
+        batch = ca.pack_piles(piles)
+        res = eng.run(batch, want_solid=True)
+        full = eng.stitch(ca.pack_piles([reads]), np.array(jobs, np.uint32), np.array(pos, np.uint32), batch, res, 500, 50, False)
+        monkeypatch.setenv("CW_STITCH_DIR_BYTES", "64")
+        small = eng.stitch(ca.pack_piles([reads]), np.array(jobs, np.uint32), np.array(pos, np.uint32), batch, res, 500, 50, False)
+    finally:
+        eng.close()
+    assert all(st == 0 for _, st in full)
+    assert any(st == 2 for _, st in small)
+    for (g, st), (f, _) in zip(small, full):
+        assert (st == 2 and g == "") or (st == 0 and g == f)
