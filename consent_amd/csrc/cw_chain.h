@@ -1,0 +1,358 @@
+/*
+ * cw_chain.h -- anchor chaining + segmentation (A4b, A4c), one wave per window.
+ *
+ * cw_index_kernel leaves every window an anchor block in HBM/L2 (candidate keys, presence bitsets of the "clean"
+ * sequences, the list of "dirty" ones, the anchor-major position matrix).  Chaining is a serial recurrence over the
+ * anchors, so a window is one wave here and the CU holds many windows at once (8 waves against the single busy wave the
+ * 160 KiB index work-group could offer).
+ *    C  longest ordered chain (cw_policy.h "chaining"): best(a) for a = A-1 .. 0, lanes score 64 successors at a time,
+ *       nearest first; smax[b] = longest chain from b onwards stops the scan as soon as no later successor can tie.
+ *    D  segmentation: pieces between consecutive chain anchors; identical-by-construction segments go straight to the
+ *       arena, the others become POA tasks routed to a memory tier by their expected graph size.
+ * Per-wave LDS: the DP arrays (16 B per candidate) + presence bitsets + the dirty sequences' columns of the position
+ * matrix; when the last two do not fit they are read from the block in place.  The matrix rows phase D needs are read
+ * from the block (consecutive lanes = consecutive sequences of one anchor row: coalesced).
+ */
+#ifndef CW_CHAIN_H
+#define CW_CHAIN_H
+
+#include "cw_device.h"
+#include "cw_index.h"
+
+#define CW_CH_WAVES 4
+#define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
+#define CW_CH_LIST_BYTES 1536
+
+__device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t ch_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, DevScratch sc, cw_params prm) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* slab = lds + (size_t)wave * CW_CH_SLAB;
+    const uint32_t k = prm.k;
+
+    for (;;) {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(&sc.ctr->next_chain, 1u);
+        w = (uint32_t)cw_lane_value((int)w, 0);
+        if (w >= b.n_windows) break;
+        WinInfo* wi = &sc.win[w];
+        /* one way through the body: every window ends at the status store + wave barrier at the bottom */
+        const bool ready = ch_uni(wi->status) == CW_WIN_CONSENSUS && ch_uni(wi->ab_ready) == 1u;
+        uint32_t new_status = 0xFFFFFFFFu; /* unchanged */
+        uint32_t n_segs_out = 0, arena_used = 0;
+        CW_PROF_T0();
+        if (ready) {
+            const uint32_t s0 = ch_uni(b.win_first_seq[w]);
+            const uint8_t* blk = sc.ablock + ((size_t)ch_uni(wi->ab_base) << 4);
+            const uint32_t* hdr = (const uint32_t*)blk;
+            const uint32_t A = ch_uni(hdr[0]), N = ch_uni(hdr[1]), n_dirty = ch_uni(hdr[2]);
+            const bool use_bits = ch_uni(hdr[3]) != 0u;
+            const uint32_t Np = cw_ab_np(N), Nw = (N + 63u) >> 6;
+            const uint32_t* ckey = (const uint32_t*)(blk + CW_AB_HDR);
+            const unsigned long long* gpres = (const unsigned long long*)((const uint8_t*)ckey + cw_ab_align((uint64_t)A * 4));
+            const uint16_t* gdirty = (const uint16_t*)((const uint8_t*)gpres + cw_ab_align((uint64_t)A * Nw * 8));
+            const uint16_t* P = (const uint16_t*)((const uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
+            const int sup_min = min((int)prm.common_kmers, (int)N / 2); /* correctionMSA.cpp:31 */
+            const uint32_t seg_base = ch_uni(wi->seg_base), seg_cap = ch_uni(wi->seg_cap);
+            const uint32_t arena_base = ch_uni(wi->arena_base), arena_cap = ch_uni(wi->arena_cap);
+
+            /* LDS carve */
+            int16_t* clen = (int16_t*)slab;                    /* A     */
+            int16_t* cnxt = clen + A;                          /* A     */
+            int16_t* smax = cnxt + A;                          /* A + 1 */
+            uint16_t* chain = (uint16_t*)(smax + A + 1);       /* A     */
+            int32_t* csc = (int32_t*)(((uintptr_t)(chain + A) + 3) & ~(uintptr_t)3); /* A */
+            uint8_t* var = (uint8_t*)(((uintptr_t)(csc + A) + 7) & ~(uintptr_t)7);
+            /* the last CW_CH_LIST_BYTES of the slab: segments waiting for the whole wave (phase D), 64 entries */
+            uint32_t* q_off = (uint32_t*)(slab + CW_CH_SLAB - CW_CH_LIST_BYTES);   /* arena offset            */
+            uint32_t* q_need = q_off + 64;                                           /* arena bytes reserved    */
+            uint16_t* q_seg = (uint16_t*)(q_need + 64);
+            int16_t* q_ca = (int16_t*)(q_seg + 64);
+            int16_t* q_cb = q_ca + 64;
+            uint16_t* q_n = (uint16_t*)(q_cb + 64);
+            uint16_t* q_mx = q_n + 64;
+            uint16_t* q_fs = q_mx + 64;
+            uint16_t* q_fst = q_fs + 64;
+            const size_t var_room = (size_t)((uint8_t*)q_off - var);
+            const size_t pres_bytes = use_bits ? (size_t)A * Nw * 8 : 0;
+            const size_t pd_bytes = use_bits ? (size_t)A * n_dirty * 2 : 0;
+            const bool pres_lds = use_bits && pres_bytes <= var_room;
+            const bool pd_lds = pres_lds && n_dirty > 0 && pres_bytes + pd_bytes <= var_room;
+            unsigned long long* lpres = (unsigned long long*)var;
+            uint16_t* lpd = (uint16_t*)(var + pres_bytes);     /* Pd[a * n_dirty + d] */
+            if (pres_lds) for (uint32_t i = lane; i < A * Nw; i += 64) lpres[i] = gpres[i];
+            if (pd_lds)
+                for (uint32_t i = lane; i < A * n_dirty; i += 64) {
+                    const uint32_t a = i / n_dirty, d = i - a * n_dirty;
+                    lpd[i] = P[a * Np + gdirty[d]];
+                }
+            if (lane == 0) smax[A] = -1;
+            cw_wave_sync();
+
+            /* ================= phase C: chain ================= */
+            for (int a = (int)A - 1; a >= 0; --a) {
+                unsigned long long best = 0ull;
+                const uint32_t* pa_row = (const uint32_t*)(P + (uint32_t)a * Np);
+                const uint32_t half = Np >> 1; /* pairs of sequences; padding entries are CW_NONE16 and never count */
+                for (uint32_t b0 = (uint32_t)a + 1u; b0 < A; b0 += 64) {
+                    const uint32_t bb = b0 + (uint32_t)lane;
+                    unsigned long long key = 0ull;
+                    if (bb < A) {
+                        uint32_t cnt = 0;
+                        if (use_bits) {
+                            if (pres_lds) { for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(lpres[(size_t)a * Nw + x] & lpres[(size_t)bb * Nw + x]); }
+                            else { for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(gpres[(size_t)a * Nw + x] & gpres[(size_t)bb * Nw + x]); }
+                            if (pd_lds) {
+                                for (uint32_t d = 0; d < n_dirty; ++d) {
+                                    const uint32_t pa = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
+                                    cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                                }
+                            } else {
+                                for (uint32_t d = 0; d < n_dirty; ++d) {
+                                    const uint32_t sd = gdirty[d];
+                                    const uint32_t pa = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                    cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                                }
+                            }
+                        } else {
+                            const uint32_t* pb_row = (const uint32_t*)(P + bb * Np);
+#pragma unroll 8
+                            for (uint32_t s = 0; s < half; ++s) {
+                                const uint32_t va = pa_row[s], vb = pb_row[s];
+                                const uint32_t a0 = va & 0xFFFFu, a1 = va >> 16, b0_ = vb & 0xFFFFu, b1_ = vb >> 16;
+                                cnt += (a0 < b0_ && b0_ != CW_NONE16) ? 1u : 0u;
+                                cnt += (a1 < b1_ && b1_ != CW_NONE16) ? 1u : 0u;
+                            }
+                        }
+                        if ((int)cnt >= sup_min)
+                            key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
+                                  (unsigned long long)(0xFFFFu - bb);
+                    }
+                    key = cw_wave_max_u64(key);
+                    best = key > best ? key : best;
+                    bool stop = false;
+                    if (best != 0ull && b0 + 64 < A) {
+                        const int blen = (int)(best >> 48) - 1;
+                        stop = (int)smax[b0 + 64] < blen;
+                    }
+                    if (ch_uni(stop ? 1 : 0)) break;
+                }
+                if (lane == 0) {
+                    int la = 0;
+                    if (best == 0ull) { clen[a] = 0; csc[a] = 0; cnxt[a] = -1; }
+                    else {
+                        la = (int)(best >> 48); /* stored length+1 of b == length of a */
+                        clen[a] = (int16_t)la;
+                        csc[a] = (int32_t)((best >> 16) & 0xFFFFFFFFull);
+                        cnxt[a] = (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
+                    }
+                    const int sm = smax[a + 1];
+                    smax[a] = (int16_t)(la > sm ? la : sm);
+                }
+                cw_wave_sync();
+            }
+            /* chain start: longest, then best score, then largest index; a chain needs at least one edge */
+            uint32_t m = 0;
+            {
+                int b_len = 0, b_sc = 0, b_a = -1;
+                for (int a = (int)A - 1 - lane; a >= 0; a -= 64) {
+                    const int l = clen[a], s = csc[a];
+                    if (l > b_len || (l == b_len && l > 0 && (s > b_sc || b_a < 0))) { b_len = l; b_sc = s; b_a = a; }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int ol = __shfl_xor(b_len, o), os = __shfl_xor(b_sc, o), oa = __shfl_xor(b_a, o);
+                    const bool take = (oa >= 0) && (b_a < 0 || ol > b_len || (ol == b_len && (os > b_sc || (os == b_sc && oa > b_a))));
+                    if (take) { b_len = ol; b_sc = os; b_a = oa; }
+                }
+                b_len = ch_uni(b_len); b_a = ch_uni(b_a);
+                if (b_a >= 0 && b_len > 0) {
+                    int a = b_a;
+                    while (a != -1) {
+                        if (lane == 0) chain[m] = (uint16_t)a;
+                        m++;
+                        a = ch_uni((int)cnxt[a]);
+                    }
+                }
+                cw_wave_sync();
+            }
+            CW_PROF(sc.ctr, 5, lane == 0);
+
+            if (m == 0 || m < prm.min_anchors) {
+                new_status = CW_WIN_TEMPLATE;
+            } else if (m + 1 > seg_cap) {
+                new_status = CW_WIN_OVERFLOW;
+            } else {
+                /* ================= phase D: segments =================
+                   Lanes = segments, 64 at a time.  Each lane walks the pile once (two matrix reads per sequence, no stores
+                   in between, so the loads pipeline), then writes its own segment if it is trivial: empty, a prefix of its
+                   left anchor (all pieces equal and no longer than k), or a single short piece.  The few segments that need
+                   the whole wave -- POA tasks and long single pieces -- follow one by one. */
+                bool over = false;
+                uint32_t q_cnt = 0;
+                auto flush = [&]() {
+                    const bool e = (uint32_t)lane < q_cnt;
+                    const uint32_t e_n = e ? q_n[lane] : 0u, e_mx = e ? q_mx[lane] : 0u;
+                    const bool poa = e && e_n > 1u;
+                    /* route by the expected graph size: the graph has at least max_len nodes once its longest member is in
+                       and typically ends at 1.4-1.6x that; a task that still outgrows its tier is redone in the next one */
+                    const uint32_t est = (e_mx * 17u + 9u) / 10u;
+                    const uint32_t tier = !poa ? 0xFFu
+                                          : ((est + 1) * (e_mx + 1) <= 4096u && est <= 160u) ? 0u
+                                          : (est <= 256u && e_mx <= 255u)                   ? 1u
+                                          : (est <= 512u && e_mx <= 511u)                   ? 2u
+                                                                                            : 3u;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const unsigned long long pm = __ballot(poa);
+                    const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u);
+                    const int minc = cw_wave_scan_add(poa ? (int)e_n : 0);
+                    const uint32_t m_total = (uint32_t)cw_lane_value(minc, 63);
+                    uint32_t tb = 0, mb = 0, b1 = 0, b2 = 0, b3 = 0;
+                    if (lane == 0 && pm) {
+                        tb = atomicAdd(&sc.ctr->n_tasks, (uint32_t)__popcll(pm));
+                        mb = atomicAdd(&sc.ctr->n_members, m_total);
+                        if (tm1) b1 = atomicAdd(&sc.ctr->n_tier[1], (uint32_t)__popcll(tm1));
+                        if (tm2) b2 = atomicAdd(&sc.ctr->n_tier[2], (uint32_t)__popcll(tm2));
+                        if (tm3) b3 = atomicAdd(&sc.ctr->n_tier[3], (uint32_t)__popcll(tm3));
+                    }
+                    tb = (uint32_t)cw_lane_value((int)tb, 0); mb = (uint32_t)cw_lane_value((int)mb, 0);
+                    b1 = (uint32_t)cw_lane_value((int)b1, 0); b2 = (uint32_t)cw_lane_value((int)b2, 0); b3 = (uint32_t)cw_lane_value((int)b3, 0);
+                    const bool cap_ok = (uint64_t)tb + (uint32_t)__popcll(pm) <= sc.task_cap && (uint64_t)mb + m_total <= sc.member_cap &&
+                                        b1 + (uint32_t)__popcll(tm1) <= sc.list_cap && b2 + (uint32_t)__popcll(tm2) <= sc.list_cap &&
+                                        b3 + (uint32_t)__popcll(tm3) <= sc.list_cap;
+                    if (!cap_ok) { over = true; }
+                    else {
+                        const uint32_t t_idx = tb + (uint32_t)__popcll(pm & below);
+                        const uint32_t m_off = mb + (uint32_t)minc - (poa ? e_n : 0u);
+                        if (poa) { /* task records: one lane each */
+                            PoaTask t;
+                            t.window = w; t.seg_slot = seg_base + q_seg[lane]; t.member_off = m_off; t.n_members = e_n; t.max_len = e_mx;
+                            t.out_off = q_off[lane]; t.out_cap = q_need[lane];
+                            t.state = tier ? 2u : 0u;
+                            sc.tasks[t_idx] = t;
+                            if (tier == 1u) sc.tier_list[1][b1 + (uint32_t)__popcll(tm1 & below)] = t_idx;
+                            else if (tier == 2u) sc.tier_list[2][b2 + (uint32_t)__popcll(tm2 & below)] = t_idx;
+                            else if (tier == 3u) sc.tier_list[3][b3 + (uint32_t)__popcll(tm3 & below)] = t_idx;
+                            sc.seg_off[t.seg_slot] = t.out_off; sc.seg_len[t.seg_slot] = 0;
+                        }
+                        /* the wave-wide part, entry by entry: member lists (coalesced matrix rows) and long single pieces */
+                        for (uint32_t q = 0; q < q_cnt; ++q) {
+                            const uint32_t g_seg = q_seg[q], g_n = q_n[q], g_mx = q_mx[q], g_off = q_off[q];
+                            const int g_ca = q_ca[q], g_cb = q_cb[q];
+                            if (g_n == 1u) {
+                                const uint32_t* words = b.bases + b.seq_word_off[s0 + q_fs[q]];
+                                const uint32_t fst = q_fst[q];
+                                for (uint32_t i = lane; i < g_mx; i += 64) sc.arena[g_off + i] = "ACGT"[cw_base_at(words, fst + i)];
+                                if (lane == 0) { sc.seg_off[seg_base + g_seg] = g_off; sc.seg_len[seg_base + g_seg] = g_mx; }
+                            } else {
+                                const uint32_t g_moff = (uint32_t)cw_lane_value((int)m_off, (int)q);
+                                uint32_t done = 0;
+                                for (uint32_t sb = 0; sb < N && done < g_n; sb += 64) {
+                                    const uint32_t s = sb + lane;
+                                    bool is = false;
+                                    uint32_t st = 0, ln = 0;
+                                    if (s < N) {
+                                        const uint32_t pa = g_ca >= 0 ? (uint32_t)P[(uint32_t)g_ca * Np + s] : 0u;
+                                        const uint32_t pb = g_cb >= 0 ? (uint32_t)P[(uint32_t)g_cb * Np + s] : 0u;
+                                        if (g_seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
+                                        else if (g_seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
+                                        else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
+                                    }
+                                    const unsigned long long bal = __ballot(is);
+                                    const uint32_t idx = done + (uint32_t)__popcll(bal & below);
+                                    if (is && idx < g_n) {
+                                        PoaMember pmb;
+                                        pmb.seq = s0 + s; pmb.start = (uint16_t)st; pmb.len = (uint16_t)ln;
+                                        sc.members[g_moff + idx] = pmb;
+                                    }
+                                    done += (uint32_t)__popcll(bal);
+                                }
+                            }
+                            cw_wave_sync();
+                        }
+                    }
+                    q_cnt = 0;
+                    cw_wave_sync();
+                };
+                for (uint32_t seg0 = 0; seg0 <= m && !over; seg0 += 64) {
+                    const uint32_t seg = seg0 + (uint32_t)lane;
+                    const bool valid = seg <= m;
+                    const int ca = (valid && seg > 0) ? (int)chain[seg - 1] : -1;
+                    const int cb = (valid && seg < m) ? (int)chain[seg] : -1;
+                    uint32_t n_mem = 0, mn = 0xFFFFFFFFu, mx = 0, first_seq = 0, first_start = 0;
+                    const uint32_t ra = (uint32_t)(ca >= 0 ? ca : 0) * Np, rb = (uint32_t)(cb >= 0 ? cb : 0) * Np;
+#pragma unroll 8
+                    for (uint32_t s = 0; s < N; ++s) {
+                        /* the loads do not depend on what was counted so far, so they issue ahead of the bookkeeping */
+                        const uint32_t va = P[ra + s], vb = P[rb + s];
+                        if (valid && n_mem < prm.max_msa) {
+                            const uint32_t pa = ca >= 0 ? va : 0u;
+                            const uint32_t pb = cb >= 0 ? vb : 0u;
+                            bool is; uint32_t st, ln;
+                            if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
+                            else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
+                            else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
+                            if (is) {
+                                if (n_mem == 0) { first_seq = s; first_start = st; }
+                                n_mem++;
+                                mn = min(mn, ln); mx = max(mx, ln);
+                            }
+                        }
+                    }
+                    const bool by_anchor = n_mem > 0 && seg > 0 && seg < m && mn == mx && mx <= k; /* all pieces = first mx bases of anchor a */
+                    const bool single = n_mem == 1;
+                    const uint32_t need = n_mem == 0 ? 0u : (by_anchor || single) ? mx : 2 * mx + 2;
+                    const int inc = cw_wave_scan_add((int)need);
+                    const uint32_t total = (uint32_t)cw_lane_value(inc, 63);
+                    if (arena_used + total > arena_cap) { over = true; }
+                    else {
+                        const uint32_t abs_off = arena_base + arena_used + (uint32_t)inc - need;
+                        const uint32_t slot = seg_base + seg;
+                        bool serial = false;
+                        if (valid) {
+                            if (n_mem == 0) { sc.seg_off[slot] = arena_base; sc.seg_len[slot] = 0; }
+                            else if (by_anchor) {
+                                const uint32_t key = ckey[ca];
+                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = "ACGT"[(key >> (2 * (k - 1 - i))) & 3u];
+                                sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx;
+                            } else if (single && mx <= 16u) {
+                                const uint32_t* words = b.bases + b.seq_word_off[s0 + first_seq];
+                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = "ACGT"[cw_base_at(words, first_start + i)];
+                                sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx;
+                            } else serial = true;
+                        }
+                        arena_used += total;
+                        /* queue the segments that need the whole wave; the queue is emptied when it could overflow and
+                           at the end of the window, so that the batch-wide counters see a handful of atomics per window
+                           instead of three per task (same-address atomics from 2048 waves serialise in L2) */
+                        const unsigned long long sm = __ballot(serial);
+                        const uint32_t n_new = (uint32_t)__popcll(sm);
+                        if (q_cnt + n_new > 64u) { flush(); }
+                        if (serial) {
+                            const uint32_t qi = q_cnt + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                            q_off[qi] = abs_off; q_need[qi] = need; q_seg[qi] = (uint16_t)seg; q_ca[qi] = (int16_t)ca; q_cb[qi] = (int16_t)cb;
+                            q_n[qi] = (uint16_t)n_mem; q_mx[qi] = (uint16_t)mx; q_fs[qi] = (uint16_t)first_seq; q_fst[qi] = (uint16_t)first_start;
+                        }
+                        q_cnt += n_new;
+                        cw_wave_sync();
+                    }
+                    over = ch_uni(over ? 1 : 0) != 0;
+                    cw_wave_sync();
+                }
+                if (!over && q_cnt) flush();
+                if (over) new_status = CW_WIN_OVERFLOW;
+                else n_segs_out = m + 1;
+            }
+            CW_PROF(sc.ctr, 6, lane == 0);
+        }
+        new_status = ch_uni(new_status); n_segs_out = ch_uni(n_segs_out); arena_used = ch_uni(arena_used);
+        if (lane == 0) {
+            if (new_status != 0xFFFFFFFFu) { wi->status = new_status; if (new_status == CW_WIN_OVERFLOW) sc.ctr->any_overflow = 1; }
+            else if (ready) { wi->n_segs = n_segs_out; wi->arena_used = arena_used; }
+        }
+        cw_wave_sync();
+    }
+}
+
+#endif

@@ -36,7 +36,9 @@ struct WinInfo {
     uint32_t arena_base; /* first byte in arena */
     uint32_t arena_cap;
     uint32_t arena_used;
-    uint32_t pad[3];
+    uint32_t ab_base;    /* anchor block (index kernel -> chain kernel), in 16-byte units into DevScratch::ablock */
+    uint32_t ab_cap;     /* 16-byte units */
+    uint32_t ab_ready;   /* 1 once the index kernel has written the block */
 };
 
 struct PoaTask {
@@ -71,7 +73,7 @@ struct BatchCounters {
     uint32_t n_over[CW_TIERS];    /* tasks that outgrew a tier and were handed to tier t */
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
-    uint32_t pad_;
+    uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
     unsigned long long prof[32];  /* cycle totals per phase, see cw_debug_profile */
 };
 
@@ -103,6 +105,8 @@ struct DevScratch {
     uint32_t slots[CW_TIERS];      /* resident waves of tier t */
     uint16_t* p_fallback;          /* index kernel: per-work-group slot for a position matrix that outgrows LDS */
     uint64_t p_fallback_elems;     /* u16 elements per slot */
+    uint8_t* ablock;               /* per-window anchor blocks: candidates, presence bitsets, position matrix */
+    uint64_t ablock_units;         /* capacity in 16-byte units */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */
 };

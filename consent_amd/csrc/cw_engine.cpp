@@ -5,6 +5,7 @@
 #include "cw_internal.h"
 #include "cw_device.h"
 #include "cw_index.h"
+#include "cw_chain.h"
 #include "cw_poa.h"
 #include "cw_finish.h"
 #include "cw_extract.h"
@@ -35,8 +36,8 @@ void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, total;
-    uint64_t pfall_elems;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, total;
+    uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap;
     TierCfg tier[CW_TIERS];
@@ -66,6 +67,10 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
+    /* anchor blocks: the position matrix is at most 2 bytes per (template k-mer, sequence) <= 8x the packed pile; the rest is
+       per template k-mer */
+    p.ablock_units = ((uint64_t)n_words * 4 * 10 + (uint64_t)n_windows * ((CW_TMAX + 16) * 16ull + 8192)) / 16 + 64;
+    put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);
     p.total = o;
@@ -135,6 +140,7 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
     for (int i = 0; i < CW_MAX_STAGES && ok; ++i) ok = hipEventCreate(&e->ev0[i]) == hipSuccess && hipEventCreate(&e->ev1[i]) == hipSuccess;
     if (!ok) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_GRAPH_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
@@ -214,6 +220,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
         }
     }
     sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
+    sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     sc.producer_wgs = (uint32_t)cus * 2 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
@@ -245,6 +252,13 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     {
         const uint32_t grid = batch->n_windows < (uint32_t)cus ? batch->n_windows : (uint32_t)cus;
         cw_index_kernel<<<grid, CW_IDX_THREADS, CW_IDX_LDS_BYTES, st>>>(db, sc, e->prm);
+    }
+    stage_end(e, st, sid);
+    sid = stage_begin(e, st, "chain");
+    {
+        const uint32_t want = (batch->n_windows + CW_CH_WAVES - 1) / CW_CH_WAVES;
+        const uint32_t cap = (uint32_t)cus * 2u; /* 2 work-groups x 4 waves x 20 KiB per CU */
+        cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are

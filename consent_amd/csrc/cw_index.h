@@ -28,16 +28,25 @@
 #define CW_TH_SLOTS 2048
 
 /* ------------------------------------------------------------------------------------------------ */
+/* anchor block of one window (index kernel -> chain kernel): sizes in bytes, everything 16-byte aligned */
+__host__ __device__ __forceinline__ uint32_t cw_ab_np(uint32_t N) { uint32_t Np = (N + 1u) & ~1u; if (((Np >> 1) & 1u) == 0u) Np += 2u; return Np; }
+__host__ __device__ __forceinline__ uint64_t cw_ab_align(uint64_t x) { return (x + 15ull) & ~15ull; }
+#define CW_AB_HDR 64u
+__host__ __device__ __forceinline__ uint64_t cw_ab_bytes(uint32_t A, uint32_t N, uint32_t n_dirty) {
+    const uint32_t Np = cw_ab_np(N), Nw = (N + 63u) >> 6;
+    return CW_AB_HDR + cw_ab_align((uint64_t)A * 4) + cw_ab_align((uint64_t)A * Nw * 8) + cw_ab_align((uint64_t)n_dirty * 2) + cw_ab_align((uint64_t)A * Np * 2);
+}
+
 __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch sc, cw_params prm, uint64_t solid_total_cap,
                                                          uint64_t seg_total_cap, uint64_t arena_total_cap) {
-    __shared__ uint32_t part[3][1024];
-    __shared__ uint64_t run[3];
+    __shared__ uint32_t part[4][1024];
+    __shared__ uint64_t run[4];
     const int tid = threadIdx.x;
-    if (tid < 3) run[tid] = 0;
+    if (tid < 4) run[tid] = 0;
     __syncthreads();
     for (uint32_t w0 = 0; w0 < b.n_windows; w0 += 1024) {
         const uint32_t w = w0 + tid;
-        uint32_t need_solid = 0, need_seg = 0, need_arena = 0;
+        uint32_t need_solid = 0, need_seg = 0, need_arena = 0, need_ab = 0;
         uint32_t nk = 0, tl = 0, ns = 0;
         if (w < b.n_windows) {
             const uint32_t s0 = b.win_first_seq[w], s1 = b.win_first_seq[w + 1];
@@ -50,15 +59,17 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             need_solid = nk / prm.solid + 1;
             need_seg = (tl >= prm.k) ? tl - prm.k + 3 : 1;
             need_arena = 16 * tl + 4096;
+            const uint32_t nk0 = (tl >= prm.k && tl - prm.k + 1 <= CW_TMAX) ? tl - prm.k + 1 : 0;
+            need_ab = (uint32_t)(cw_ab_bytes(nk0, ns, ns) >> 4);
         }
-        part[0][tid] = need_solid; part[1][tid] = need_seg; part[2][tid] = need_arena;
+        part[0][tid] = need_solid; part[1][tid] = need_seg; part[2][tid] = need_arena; part[3][tid] = need_ab;
         __syncthreads();
         /* simple in-LDS inclusive scan, 10 steps */
         for (int o = 1; o < 1024; o <<= 1) {
-            uint32_t v0 = 0, v1 = 0, v2 = 0;
-            if (tid >= o) { v0 = part[0][tid - o]; v1 = part[1][tid - o]; v2 = part[2][tid - o]; }
+            uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+            if (tid >= o) { v0 = part[0][tid - o]; v1 = part[1][tid - o]; v2 = part[2][tid - o]; v3 = part[3][tid - o]; }
             __syncthreads();
-            part[0][tid] += v0; part[1][tid] += v1; part[2][tid] += v2;
+            part[0][tid] += v0; part[1][tid] += v1; part[2][tid] += v2; part[3][tid] += v3;
             __syncthreads();
         }
         if (w < b.n_windows) {
@@ -66,17 +77,18 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             wi.status = CW_WIN_CONSENSUS;
             wi.n_seqs = ns; wi.tpl_len = tl; wi.n_kmers = nk;
             uint64_t sb = run[0] + part[0][tid] - need_solid, gb = run[1] + part[1][tid] - need_seg,
-                     ab = run[2] + part[2][tid] - need_arena;
-            bool over = sb + need_solid > solid_total_cap || gb + need_seg > seg_total_cap || ab + need_arena > arena_total_cap;
+                     ab = run[2] + part[2][tid] - need_arena, kb = run[3] + part[3][tid] - need_ab;
+            bool over = sb + need_solid > solid_total_cap || gb + need_seg > seg_total_cap || ab + need_arena > arena_total_cap ||
+                        kb + need_ab > sc.ablock_units || kb + need_ab > 0xFFFFFFFFull;
             wi.solid_base = (uint32_t)sb; wi.solid_cap = need_solid; wi.n_solid = 0;
             wi.seg_base = (uint32_t)gb; wi.seg_cap = need_seg; wi.n_segs = 0;
             wi.arena_base = (uint32_t)ab; wi.arena_cap = need_arena; wi.arena_used = 0;
-            wi.pad[0] = wi.pad[1] = wi.pad[2] = 0;
-            if (over) { wi.status = CW_WIN_OVERFLOW; wi.solid_cap = wi.seg_cap = wi.arena_cap = 0; wi.solid_base = wi.seg_base = wi.arena_base = 0; }
+            wi.ab_base = (uint32_t)kb; wi.ab_cap = need_ab; wi.ab_ready = 0;
+            if (over) { wi.status = CW_WIN_OVERFLOW; wi.solid_cap = wi.seg_cap = wi.arena_cap = wi.ab_cap = 0; wi.solid_base = wi.seg_base = wi.arena_base = wi.ab_base = 0; }
             sc.win[w] = wi;
         }
         __syncthreads();
-        if (tid < 3) run[tid] += part[tid][1023];
+        if (tid < 4) run[tid] += part[tid][1023];
         __syncthreads();
     }
 }
@@ -521,208 +533,39 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         }
         const uint32_t n_dirty = use_bits ? misc[3] : 0u;
 
+        /* ================= hand-over: the window's anchor block =================
+           Chaining is a serial recurrence over the anchors: one wave's work.  Doing it here would idle 15 of this
+           work-group's 16 waves (and the CU, which the 160 KiB of LDS keeps to itself), so the candidates, the
+           presence bitsets, the dirty list and the position matrix go to HBM/L2 and cw_chain_kernel finishes the
+           window with one wave per window and many windows per CU. */
+        {
+            uint8_t* blk = sc.ablock + ((size_t)wi->ab_base << 4);
+            if (cw_ab_bytes(A, N, n_dirty) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
+                if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                continue;
+            }
+            uint32_t* hdr = (uint32_t*)blk;
+            uint32_t* ckey = (uint32_t*)(blk + CW_AB_HDR);
+            unsigned long long* gpres = (unsigned long long*)((uint8_t*)ckey + cw_ab_align((uint64_t)A * 4));
+            uint16_t* gdirty = (uint16_t*)((uint8_t*)gpres + cw_ab_align((uint64_t)A * Nw * 8));
+            uint16_t* gP = (uint16_t*)((uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
+            if (tid == 0) { hdr[0] = A; hdr[1] = N; hdr[2] = n_dirty; hdr[3] = use_bits ? 1u : 0u; }
+            for (uint32_t a = tid; a < A; a += CW_IDX_THREADS) ckey[a] = tkey[cand_tp[a]];
+            if (use_bits) {
+                for (uint32_t i = tid; i < A * Nw; i += CW_IDX_THREADS) gpres[i] = pres[i];
+                for (uint32_t i = tid; i < n_dirty; i += CW_IDX_THREADS) gdirty[i] = dirty[i];
+            }
+            {   /* rows are Np (even) u16: copy as u32 pairs */
+                const uint32_t* src = (const uint32_t*)(pg ? P_glb : P_lds);
+                uint32_t* dst = (uint32_t*)gP;
+                const uint32_t n2 = (A * Np) >> 1;
+                for (uint32_t i = tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) wi->ab_ready = 1;
+        }
         CW_PROF(sc.ctr, 4, tid == 0);
-        /* ================= phase C: chain ================= */
-        /* best(a) for a = A-1 .. 0 by one wave: lanes score 64 successors b > a at a time against all N sequences,
-           nearest successors first; smax[b] = max length from b onwards lets the scan stop as soon as no later
-           successor can tie or beat the best link found (exact; cw_policy.h "chaining"). */
-        if (wave == 0) {
-            int16_t* smax = bnext; /* A + 1 entries */
-            if (lane == 0) smax[A] = -1;
-            cw_wave_sync();
-            for (int a = (int)A - 1; a >= 0; --a) {
-                unsigned long long best = 0ull;
-                const uint32_t* pa_row = (const uint32_t*)((pg ? P_glb : P_lds) + (uint32_t)a * Np);
-                const uint32_t half = Np >> 1; /* pairs of sequences; padding entries are CW_NONE16 and never count */
-                for (uint32_t b0 = (uint32_t)a + 1u; b0 < A; b0 += 64) {
-                    const uint32_t bb = b0 + (uint32_t)lane;
-                    unsigned long long key = 0ull;
-                    if (bb < A) {
-                        uint32_t cnt = 0;
-                        if (use_bits) {
-                            for (uint32_t w = 0; w < Nw; ++w) cnt += (uint32_t)__popcll(pres[(size_t)a * Nw + w] & pres[(size_t)bb * Nw + w]);
-                            for (uint32_t d = 0; d < n_dirty; ++d) {
-                                const uint32_t sd = dirty[d];
-                                const uint32_t pa = PRD((uint32_t)a * Np + sd), pb = PRD(bb * Np + sd);
-                                cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
-                            }
-                        } else {
-                            const uint32_t* pb_row = (const uint32_t*)((pg ? P_glb : P_lds) + bb * Np);
-#pragma unroll 8
-                            for (uint32_t s = 0; s < half; ++s) {
-                                const uint32_t va = pa_row[s], vb = pb_row[s];
-                                const uint32_t a0 = va & 0xFFFFu, a1 = va >> 16, b0_ = vb & 0xFFFFu, b1_ = vb >> 16;
-                                cnt += (a0 < b0_ && b0_ != CW_NONE16) ? 1u : 0u;
-                                cnt += (a1 < b1_ && b1_ != CW_NONE16) ? 1u : 0u;
-                            }
-                        }
-                        if ((int)cnt >= sup_min)
-                            key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
-                                  (unsigned long long)(0xFFFFu - bb);
-                    }
-                    key = cw_wave_max_u64(key);
-                    best = key > best ? key : best;
-                    if (best != 0ull && b0 + 64 < A) {
-                        const int blen = (int)(best >> 48) - 1;
-                        if ((int)smax[b0 + 64] < blen) break;
-                    }
-                }
-                if (lane == 0) {
-                    int la = 0;
-                    if (best == 0ull) { clen[a] = 0; csc[a] = 0; cnxt[a] = -1; }
-                    else {
-                        la = (int)(best >> 48); /* stored length+1 of b == length of a */
-                        clen[a] = (int16_t)la;
-                        csc[a] = (int32_t)((best >> 16) & 0xFFFFFFFFull);
-                        cnxt[a] = (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
-                    }
-                    const int sm = smax[a + 1];
-                    smax[a] = (int16_t)(la > sm ? la : sm);
-                }
-                cw_wave_sync();
-            }
-        }
-        if (wave == 0) {
-            /* chain start: longest, then best score, then largest index; a chain needs at least one edge */
-            int b_len = 0, b_sc = 0, b_a = -1;
-            for (int a = (int)A - 1 - lane; a >= 0; a -= 64) {
-                const int l = clen[a], s = csc[a];
-                if (l > b_len || (l == b_len && l > 0 && (s > b_sc || b_a < 0))) { b_len = l; b_sc = s; b_a = a; }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ol = __shfl_xor(b_len, o), os = __shfl_xor(b_sc, o), oa = __shfl_xor(b_a, o);
-                const bool take = (oa >= 0) && (b_a < 0 || ol > b_len || (ol == b_len && (os > b_sc || (os == b_sc && oa > b_a))));
-                if (take) { b_len = ol; b_sc = os; b_a = oa; }
-            }
-            int m = 0;
-            if (b_a >= 0 && b_len > 0) {
-                for (int a = b_a; a != -1; a = cnxt[a]) {
-                    if (lane == 0) chain[m] = (uint16_t)a;
-                    m++;
-                }
-            }
-            if (lane == 0) misc[0] = (uint32_t)m;
-        }
-        __syncthreads();
-        CW_PROF(sc.ctr, 5, tid == 0);
-        const uint32_t m = misc[0];
-        if (m == 0 || m < prm.min_anchors) {
-            if (tid == 0) wi->status = CW_WIN_TEMPLATE;
-            continue;
-        }
-        if (m + 1 > wi->seg_cap) {
-            if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
-            continue;
-        }
-        if (tid == 0) { misc[1] = 0; /* arena used */ misc[2] = 0; /* overflow */ }
-        __syncthreads();
-
-        /* ================= phase D: segments ================= */
-        for (uint32_t seg = wave; seg <= m; seg += CW_IDX_WAVES) {
-            const int ca = seg > 0 ? (int)chain[seg - 1] : -1;
-            const int cb = seg < m ? (int)chain[seg] : -1;
-            /* pass 1: count members, min/max piece length */
-            uint32_t n_mem = 0, mn = 0xFFFFFFFFu, mx = 0, first_seq = 0, first_start = 0;
-            for (uint32_t sb = 0; sb < N && n_mem < prm.max_msa; sb += 64) {
-                const uint32_t s = sb + lane;
-                bool is = false;
-                uint32_t st = 0, ln = 0;
-                if (s < N) {
-                    const uint32_t pa = ca >= 0 ? PRD((uint32_t)ca * Np + s) : 0u;
-                    const uint32_t pb = cb >= 0 ? PRD((uint32_t)cb * Np + s) : 0u;
-                    if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
-                    else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
-                    else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
-                }
-                const unsigned long long bal = __ballot(is);
-                const uint32_t before = n_mem + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                const bool keep = is && before < prm.max_msa;
-                uint32_t lmn = keep ? ln : 0xFFFFFFFFu, lmx = keep ? ln : 0u;
-                for (int o = 32; o > 0; o >>= 1) { lmn = min(lmn, (uint32_t)__shfl_xor((int)lmn, o)); lmx = max(lmx, (uint32_t)__shfl_xor((int)lmx, o)); }
-                mn = min(mn, lmn); mx = max(mx, lmx);
-                if (n_mem == 0 && bal) {
-                    const int fl = __ffsll((long long)bal) - 1;
-                    first_seq = sb + fl; first_start = (uint32_t)__shfl((int)st, fl);
-                }
-                n_mem = min(prm.max_msa, n_mem + (uint32_t)__popcll(bal));
-            }
-            const uint32_t slot = wi->seg_base + seg;
-            if (n_mem == 0) {
-                if (lane == 0) { sc.seg_off[slot] = wi->arena_base; sc.seg_len[slot] = 0; }
-                continue;
-            }
-            const bool by_anchor = (seg > 0 && seg < m && mn == mx && mx <= k); /* all pieces = first mx bases of anchor a */
-            const bool single = n_mem == 1;
-            const uint32_t need = (by_anchor || single) ? mx : 2 * mx + 2;
-            uint32_t aoff = 0;
-            if (lane == 0) aoff = atomicAdd(&misc[1], need);
-            aoff = (uint32_t)__shfl((int)aoff, 0);
-            if (aoff + need > wi->arena_cap) { if (lane == 0) misc[2] = 1; continue; }
-            const uint32_t abs_off = wi->arena_base + aoff;
-            if (by_anchor) {
-                const uint32_t key = tkey[cand_tp[ca]];
-                if ((uint32_t)lane < mx) sc.arena[abs_off + lane] = "ACGT"[(key >> (2 * (k - 1 - lane))) & 3u];
-                if (lane == 0) { sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx; }
-                continue;
-            }
-            if (single) {
-                const uint32_t* words = b.bases + b.seq_word_off[s0 + first_seq];
-                for (uint32_t i = lane; i < mx; i += 64) sc.arena[abs_off + i] = "ACGT"[cw_base_at(words, first_start + i)];
-                if (lane == 0) { sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx; }
-                continue;
-            }
-            /* POA task */
-            uint32_t t_idx = 0, m_off = 0;
-            if (lane == 0) { t_idx = atomicAdd(&sc.ctr->n_tasks, 1u); m_off = atomicAdd(&sc.ctr->n_members, n_mem); }
-            t_idx = (uint32_t)__shfl((int)t_idx, 0); m_off = (uint32_t)__shfl((int)m_off, 0);
-            if (t_idx >= sc.task_cap || m_off + n_mem > sc.member_cap) { if (lane == 0) misc[2] = 1; continue; }
-            uint32_t done = 0;
-            for (uint32_t sb = 0; sb < N && done < n_mem; sb += 64) {
-                const uint32_t s = sb + lane;
-                bool is = false;
-                uint32_t st = 0, ln = 0;
-                if (s < N) {
-                    const uint32_t pa = ca >= 0 ? PRD((uint32_t)ca * Np + s) : 0u;
-                    const uint32_t pb = cb >= 0 ? PRD((uint32_t)cb * Np + s) : 0u;
-                    if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
-                    else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
-                    else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
-                }
-                const unsigned long long bal = __ballot(is);
-                const uint32_t idx = done + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                if (is && idx < n_mem) {
-                    PoaMember pm;
-                    pm.seq = s0 + s; pm.start = (uint16_t)st; pm.len = (uint16_t)ln;
-                    sc.members[m_off + idx] = pm;
-                }
-                done += (uint32_t)__popcll(bal);
-            }
-            if (lane == 0) {
-                PoaTask t;
-                t.window = w; t.seg_slot = slot; t.member_off = m_off; t.n_members = n_mem; t.max_len = mx;
-                t.out_off = abs_off; t.out_cap = need;
-                /* route by the expected graph size: the graph has at least max_len nodes once its longest member is in
-                   and typically ends at 1.4-1.6x that; a task that still outgrows its tier is redone in the next one */
-                const uint32_t est = (mx * 17u + 9u) / 10u;
-                const uint32_t tier = ((est + 1) * (mx + 1) <= 4096u && est <= 160u) ? 0u
-                                      : (est <= 256u && mx <= 255u)                 ? 1u
-                                      : (est <= 512u && mx <= 511u)                 ? 2u
-                                                                                    : 3u;
-                t.state = tier ? 2u : 0u;
-                sc.tasks[t_idx] = t;
-                if (tier) {
-                    const uint32_t bi = atomicAdd(&sc.ctr->n_tier[tier], 1u);
-                    if (bi < sc.list_cap) sc.tier_list[tier][bi] = t_idx; else misc[2] = 1;
-                }
-                sc.seg_off[slot] = abs_off; sc.seg_len[slot] = 0;
-            }
-        }
-        __syncthreads();
-        CW_PROF(sc.ctr, 6, tid == 0);
-        if (tid == 0) {
-            if (misc[2]) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
-            else { wi->n_segs = m + 1; wi->arena_used = misc[1]; }
-        }
     }
 }
 
