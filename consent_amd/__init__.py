@@ -6,7 +6,9 @@ This package only marshals buffers; it never computes a consensus itself and rai
 from .engine import (  # noqa: F401
     Engine,
     EngineError,
+    PafReader,
     Params,
+    ReadIndex,
     SynthSpec,
     WIN_CONSENSUS,
     WIN_OVERFLOW,

@@ -1,0 +1,244 @@
+/*
+ * cw_hostio.cpp -- host feeders of the path: the read indexer and the PAF pile reader.
+ *
+ *   cw_index_reads      <- indexReads      (src/utils.cpp:166-205): FASTA/FASTQ -> 2-bit reads keyed by name
+ *   cw_paf_next_pile    <- getNextReadPile (src/alignmentPiles.cpp:22-58) + Overlap(std::string) (src/Overlap.h:26-58)
+ *
+ * Plain host C++ (no device code); results are handed over as the same cw_read_set / cw_overlap structures the device
+ * entry points take.  Behaviours kept on purpose (each pinned against the reference's own TUs in tests/test_hostio_ref.py):
+ *   - names are the header up to the first blank; a later record with the same name replaces the earlier one
+ *   - bases are upper-cased, then anything but A, C, G packs as T (utils.cpp:21-32, :189)
+ *   - multi-line FASTA/FASTQ: sequence lines are joined until a line starting with '>' or '+'; for FASTQ the quality block is
+ *     skipped by line count; the loop ends at the first empty header line
+ *   - PAF ends are made inclusive on parse; a pile = consecutive lines with the same query name; it is sorted with the
+ *     reference's own expression -- std::sort over reverse iterators with operator< on resMatches (unstable: the permutation
+ *     of ties is whatever libstdc++'s introsort produces, reproduced here by running the same algorithm on the same keys) --
+ *     and cut to max_support
+ *   - a blank line closes the pile being read and is skipped, as the reference's driver loop ends up doing
+ *   Files whose last line lacks a newline make the reference spin (a failed getline leaves its string untouched); here they
+ *   simply end.
+ */
+#include "../../include/consent_amd.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct cw_read_index {
+    std::vector<std::string> names;
+    std::vector<uint32_t> len;
+    std::vector<uint64_t> word_off;
+    std::vector<uint32_t> words;
+    std::unordered_map<std::string, uint32_t> by_name;
+};
+
+namespace {
+
+void pack_into(const std::string& seq, std::vector<uint32_t>& words) {
+    const size_t nw = (seq.size() + 15) / 16;
+    const size_t base = words.size();
+    words.resize(base + nw, 0u);
+    for (size_t j = 0; j < seq.size(); ++j) {
+        const int c = toupper((unsigned char)seq[j]);
+        const uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u;
+        words[base + (j >> 4)] |= code << (30 - 2 * (j & 15));
+    }
+}
+
+/* std::stoi as the reference uses it: leading blanks, optional sign, digits; anything after is ignored; no digits = error */
+bool parse_int(const std::string& tok, long* out) {
+    const char* s = tok.c_str();
+    char* end = nullptr;
+    const long v = strtol(s, &end, 10);
+    if (end == s) return false;
+    *out = v;
+    return true;
+}
+
+struct PafLine {
+    std::string q_name, t_name;
+    uint32_t q_len, q_start, q_end, strand, t_len, t_start, t_end, res_matches;
+    bool operator<(const PafLine& o) const { return res_matches < o.res_matches; } /* Overlap.h:90-96 */
+};
+
+bool parse_paf(const std::string& line, PafLine* o) {
+    std::string tok[12];
+    size_t p = 0;
+    for (int f = 0; f < 12; ++f) {
+        if (p > line.size()) return false;
+        const size_t e = line.find('\t', p);
+        tok[f] = line.substr(p, e == std::string::npos ? std::string::npos : e - p);
+        p = e == std::string::npos ? line.size() + 1 : e + 1;
+    }
+    long v[10];
+    const int num[10] = {1, 2, 3, 6, 7, 8, 9, 10, 11, 0};
+    for (int i = 0; i < 9; ++i)
+        if (!parse_int(tok[num[i]], &v[i])) return false;
+    o->q_name = tok[0]; o->t_name = tok[5];
+    o->q_len = (uint32_t)v[0]; o->q_start = (uint32_t)v[1]; o->q_end = (uint32_t)(v[2] - 1);   /* Overlap.h:39 */
+    o->strand = tok[4] == "+" ? 0u : 1u;
+    o->t_len = (uint32_t)v[3]; o->t_start = (uint32_t)v[4]; o->t_end = (uint32_t)(v[5] - 1);   /* Overlap.h:49 */
+    o->res_matches = (uint32_t)v[6];
+    return true;
+}
+
+} // namespace
+
+struct cw_paf_reader {
+    std::ifstream f;
+    const cw_read_index* idx;
+    uint32_t max_support;
+    bool bad, has_pending;
+    std::string pending;
+};
+
+extern "C" {
+
+int cw_index_reads(const char* path, cw_read_index** out) {
+    if (!path || !out) return CW_E_INVALID;
+    *out = nullptr;
+    std::ifstream f(path);
+    if (!f) return CW_E_INVALID;
+    cw_read_index* ix = new (std::nothrow) cw_read_index();
+    if (!ix) return CW_E_NOMEM;
+    try {
+        std::string header, seq, sequence;
+        std::getline(f, header);
+        while (header.length() > 0) {
+            header.erase(0, 1);
+            const size_t sp = header.find(' ');
+            if (sp != std::string::npos) header.erase(sp);
+            std::getline(f, seq);
+            sequence = seq;
+            int nb_lines = 1;
+            seq.clear();
+            std::getline(f, seq);
+            while (seq.length() > 0 && seq[0] != '>' && seq[0] != '+') {
+                sequence += seq;
+                nb_lines++;
+                seq.clear();
+                std::getline(f, seq);
+            }
+            uint32_t id;
+            auto it = ix->by_name.find(header);
+            if (it == ix->by_name.end()) {
+                id = (uint32_t)ix->names.size();
+                ix->by_name.emplace(header, id);
+                ix->names.push_back(header);
+                ix->len.push_back(0);
+                ix->word_off.push_back(0);
+            } else id = it->second;                              /* index[header] = ... replaces */
+            ix->len[id] = (uint32_t)sequence.size();
+            ix->word_off[id] = ix->words.size();
+            pack_into(sequence, ix->words);
+            if (!seq.empty() && seq[0] == '+') {                  /* FASTQ: skip the quality block by line count */
+                seq.clear();
+                std::getline(f, seq);
+                for (int i = 1; i < nb_lines; ++i) { seq.clear(); std::getline(f, seq); }
+                seq.clear();
+                std::getline(f, seq);
+            }
+            header = seq;
+        }
+        ix->words.push_back(0u); /* readers may look one word past a sequence's last word */
+    } catch (...) {
+        delete ix;
+        return CW_E_NOMEM;
+    }
+    *out = ix;
+    return CW_OK;
+}
+
+void cw_read_index_free(cw_read_index* ix) { delete ix; }
+
+uint32_t cw_read_index_count(const cw_read_index* ix) { return ix ? (uint32_t)ix->names.size() : 0u; }
+
+int cw_read_index_view(const cw_read_index* ix, cw_read_set* view, uint64_t* n_words) {
+    if (!ix || !view) return CW_E_INVALID;
+    view->n_reads = (uint32_t)ix->names.size();
+    view->read_len = ix->len.data();
+    view->read_word_off = ix->word_off.data();
+    view->bases = ix->words.data();
+    if (n_words) *n_words = ix->words.size();
+    return CW_OK;
+}
+
+int32_t cw_read_index_find(const cw_read_index* ix, const char* name) {
+    if (!ix || !name) return -1;
+    auto it = ix->by_name.find(name);
+    return it == ix->by_name.end() ? -1 : (int32_t)it->second;
+}
+
+const char* cw_read_index_name(const cw_read_index* ix, uint32_t id) {
+    return (ix && id < ix->names.size()) ? ix->names[id].c_str() : nullptr;
+}
+
+int cw_paf_open(const char* path, const cw_read_index* idx, uint32_t max_support, cw_paf_reader** out) {
+    if (!path || !idx || !out) return CW_E_INVALID;
+    *out = nullptr;
+    cw_paf_reader* r = new (std::nothrow) cw_paf_reader();
+    if (!r) return CW_E_NOMEM;
+    r->f.open(path);
+    if (!r->f) { delete r; return CW_E_INVALID; }
+    r->idx = idx; r->max_support = max_support; r->bad = false; r->has_pending = false;
+    *out = r;
+    return CW_OK;
+}
+
+void cw_paf_close(cw_paf_reader* r) { delete r; }
+
+int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw_overlap* out, uint32_t* res_matches, uint32_t cap,
+                     uint32_t* n) {
+    if (!r || !tpl_read || !n) return CW_E_INVALID;
+    *n = 0;
+    if (r->bad) return CW_E_INVALID;
+    try {
+        std::vector<PafLine> cur;
+        std::string line;
+        PafLine al;
+        /* One line of look-ahead instead of the reference's seekg(-len-1): the same piles for any file whose lines end in a
+           newline.  A blank line closes the current pile and is skipped (the reference returns an empty pile there and its
+           driver asks again, CONSENT-correction.cpp:88-91). */
+        for (;;) {
+            if (r->has_pending) { line.swap(r->pending); r->has_pending = false; }
+            else {
+                line.clear();
+                if (!std::getline(r->f, line) && line.empty()) break;
+            }
+            if (line.empty()) { if (!cur.empty()) break; else continue; }
+            if (!parse_paf(line, &al)) { r->bad = true; return CW_E_INVALID; }
+            if (cur.empty() || al.q_name == cur[0].q_name) cur.push_back(al);
+            else { r->pending.swap(line); r->has_pending = true; break; }
+        }
+        if (cur.empty()) return CW_OK; /* end of the stream */
+        std::sort(cur.rbegin(), cur.rend());                   /* alignmentPiles.cpp:43 / :53 */
+        if (cur.size() > r->max_support) cur.resize(r->max_support);
+        const int32_t q = cw_read_index_find(r->idx, cur[0].q_name.c_str());
+        if (q < 0) { r->bad = true; return CW_E_INVALID; }
+        *tpl_read = (uint32_t)q;
+        if (tpl_len) *tpl_len = cur[0].q_len;
+        *n = (uint32_t)cur.size();
+        if (cur.size() > cap || !out) return CW_E_CAPACITY;  /* the pile is consumed: size the buffer for max_support */
+        for (size_t i = 0; i < cur.size(); ++i) {
+            const int32_t t = cw_read_index_find(r->idx, cur[i].t_name.c_str());
+            if (t < 0) { r->bad = true; return CW_E_INVALID; }
+            out[i].q_start = cur[i].q_start; out[i].q_end = cur[i].q_end;
+            out[i].t_read = (uint32_t)t; out[i].t_start = cur[i].t_start; out[i].t_end = cur[i].t_end;
+            out[i].strand = cur[i].strand;
+            if (res_matches) res_matches[i] = cur[i].res_matches;
+        }
+        return CW_OK;
+    } catch (...) {
+        r->bad = true;
+        return CW_E_NOMEM;
+    }
+}
+
+} // extern "C"

@@ -111,6 +111,20 @@ def load_library():
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p]
     lib.cw_stitch_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_uint32, C.c_uint32,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cw_index_reads.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.cw_read_index_free.argtypes = [C.c_void_p]
+    lib.cw_read_index_free.restype = None
+    lib.cw_read_index_count.argtypes = [C.c_void_p]
+    lib.cw_read_index_count.restype = C.c_uint32
+    lib.cw_read_index_view.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.POINTER(C.c_uint64)]
+    lib.cw_read_index_find.argtypes = [C.c_void_p, C.c_char_p]
+    lib.cw_read_index_find.restype = C.c_int32
+    lib.cw_read_index_name.argtypes = [C.c_void_p, C.c_uint32]
+    lib.cw_read_index_name.restype = C.c_char_p
+    lib.cw_paf_open.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.cw_paf_next_pile.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.cw_paf_close.argtypes = [C.c_void_p]
+    lib.cw_paf_close.restype = None
     lib.cw_window_positions.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
@@ -210,6 +224,77 @@ def synth_host(spec):
     bases = np.zeros(nw.value, np.uint32)
     _check(lib, lib.cw_synth_host(C.byref(spec), _ptr(wfs), _ptr(lens), _ptr(offs), _ptr(bases)), "cw_synth_host")
     return HostBatch(wfs, lens, offs, bases)
+
+
+class ReadIndex:
+    """indexReads (utils.cpp:166-205) through the library's host feeder: names, lengths and the 2-bit read set."""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.cw_index_reads(os.fsencode(path), C.byref(h)), f"cw_index_reads({path})")
+        self.handle = h
+        n = self.lib.cw_read_index_count(h)
+        view, nw = ReadSet(), C.c_uint64()
+        _check(self.lib, self.lib.cw_read_index_view(h, C.byref(view), C.byref(nw)), "cw_read_index_view")
+        self.names = [self.lib.cw_read_index_name(h, i).decode() for i in range(n)]
+        as_np = lambda ptr, ct, cnt: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].copy()
+        self.seq_len = as_np(view.read_len, C.c_uint32, n)
+        self.seq_word_off = as_np(view.read_word_off, C.c_uint64, n)
+        self.bases = as_np(view.bases, C.c_uint32, nw.value)
+
+    def find(self, name):
+        return self.lib.cw_read_index_find(self.handle, name.encode())
+
+    def sequence(self, i):
+        o, n = int(self.seq_word_off[i]), int(self.seq_len[i])
+        w = self.bases[o : o + (n + 15) // 16]
+        codes = ((w[:, None] >> (30 - 2 * np.arange(16, dtype=np.uint32))) & 3).reshape(-1)[:n]
+        return np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.cw_read_index_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PafReader:
+    """getNextReadPile (alignmentPiles.cpp:22-58): iterate over (template id, template length, overlaps (n,6), resMatches (n,))."""
+
+    def __init__(self, path, index, max_support=150):
+        self.lib = load_library()
+        self.index = index
+        self.max_support = max_support
+        h = C.c_void_p()
+        _check(self.lib, self.lib.cw_paf_open(os.fsencode(path), index.handle, max_support, C.byref(h)), f"cw_paf_open({path})")
+        self.handle = h
+
+    def __iter__(self):
+        ov = np.zeros((max(self.max_support, 1), 6), np.uint32)
+        rm = np.zeros(max(self.max_support, 1), np.uint32)
+        tpl, tlen, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        while True:
+            _check(self.lib, self.lib.cw_paf_next_pile(self.handle, C.byref(tpl), C.byref(tlen), _ptr(ov), _ptr(rm), len(ov), C.byref(n)), "cw_paf_next_pile")
+            if n.value == 0:
+                return
+            yield tpl.value, tlen.value, ov[: n.value].copy(), rm[: n.value].copy()
+
+    def close(self):
+        if self.handle:
+            self.lib.cw_paf_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class WindowResults:

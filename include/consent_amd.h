@@ -11,6 +11,8 @@
  *                               -- batched over windows, because one window per call cannot feed a GPU.
  *   cw_window_positions      <- getAlignmentWindowsPositions (alignmentWindows.cpp:27-85), host
  *   cw_extract_piles_device  <- getAlignmentWindowsSequences (alignmentWindows.cpp:87-149) evaluated on the device
+ *   cw_stitch_device         <- alignConsensus + trimRead + dropRead (correctionAlignment.cpp:47-140, utils.cpp:96-128, :71-73)
+ *   cw_index_reads / cw_paf_next_pile <- indexReads (utils.cpp:166-205) / getNextReadPile (alignmentPiles.cpp:22-58), host
  *   cw_pack_sequence         <- the vector<string> pile handed to those operators
  *                               (CONSENT-correction.cpp:35-37, CONSENT-polishing.cpp:46-49): 2-bit packing
  *                               with the reference's own alphabet (utils.cpp:21-32: A=00 C=01 G=10 else=11).
@@ -163,6 +165,30 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
                             const cw_window_job* jobs, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len,
                             uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
                             uint64_t* n_words, void* hip_stream);
+
+/* ---- host feeders: read indexer and PAF pile reader, plain host code ------------------------------------
+ * cw_index_reads stands in for indexReads (src/utils.cpp:166-205): FASTA or FASTQ (multi-line allowed) -> 2-bit reads keyed by
+ * name (header up to the first blank; a later record with the same name replaces the earlier one; bases upper-cased, anything
+ * but A/C/G packs as T).  The view's pointers are HOST pointers laid out like the device read set: upload them once. */
+typedef struct cw_read_index cw_read_index;
+int cw_index_reads(const char* path, cw_read_index** out);
+void cw_read_index_free(cw_read_index* idx);
+uint32_t cw_read_index_count(const cw_read_index* idx);
+int cw_read_index_view(const cw_read_index* idx, cw_read_set* host_view, uint64_t* n_words);
+int32_t cw_read_index_find(const cw_read_index* idx, const char* name);   /* read id or -1 */
+const char* cw_read_index_name(const cw_read_index* idx, uint32_t id);
+
+/* cw_paf_next_pile stands in for getNextReadPile (src/alignmentPiles.cpp:22-58) with Overlap(std::string) (src/Overlap.h:26-58):
+ * the next run of consecutive PAF lines sharing a query name, ends made inclusive, sorted by residue matches descending with the
+ * reference's own std::sort expression (ties in libstdc++'s order), cut to max_support.  *n = overlaps in the pile, 0 at the end
+ * of the file; *tpl_read / *tpl_len = the query's id in the index and its length as the PAF states it; res_matches may be NULL.
+ * CW_E_CAPACITY when cap < *n (the pile is consumed: size the buffer for max_support); CW_E_INVALID on a malformed line or a
+ * name missing from the index. */
+typedef struct cw_paf_reader cw_paf_reader;
+int cw_paf_open(const char* path, const cw_read_index* idx, uint32_t max_support, cw_paf_reader** out);
+int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw_overlap* out, uint32_t* res_matches, uint32_t cap,
+                     uint32_t* n);
+void cw_paf_close(cw_paf_reader* r);
 
 /* ---- read re-assembly on the device -------------------------------------------------
  * Stands in for alignConsensus (src/correctionAlignment.cpp:47-140) followed, when do_trim != 0, by trimRead(.,1) and

@@ -81,6 +81,47 @@ int ref_paf_pile_order(const char* paf_path, uint32_t max_support, uint32_t* pil
     return (int)n;
 }
 
+/* indexReads (utils.cpp:166-205) on a file; for the read called `name`: its length and decoded bases (fullnum2str).
+ * Returns the number of reads in the index, or -1 when `name` is not in it. */
+int ref_index_reads_lookup(const char* path, const char* name, char* out, uint32_t cap, uint32_t* len) {
+    robin_hood::unordered_map<std::string, std::vector<bool>> index;
+    indexReads(index, path);
+    auto it = index.find(name);
+    if (it == index.end()) return -1;
+    std::string s = fullnum2str(it->second);
+    *len = (uint32_t)s.size();
+    if (s.size() > cap) return -4;
+    memcpy(out, s.data(), s.size());
+    return (int)index.size();
+}
+
+/* Every pile of a PAF file through getNextReadPile: per kept overlap the parsed fields (qStart qEnd tStart tEnd strand resMatches
+ * qLength tLength), 8 words each, and the pile index; names go to qnames/tnames.  Returns overlaps written. */
+int ref_paf_piles(const char* paf_path, uint32_t max_support, uint32_t* pile_id, uint32_t* fields8, char* qnames, char* tnames,
+                  uint32_t name_stride, uint32_t cap) {
+    std::ifstream f(paf_path);
+    uint32_t n = 0, pile = 0;
+    std::vector<Overlap> cur = getNextReadPile(f, max_support);
+    while (!cur.empty() || !f.eof()) {
+        for (auto& o : cur) {
+            if (n >= cap) return -4;
+            pile_id[n] = pile;
+            uint32_t* w = fields8 + 8 * (size_t)n;
+            w[0] = o.qStart; w[1] = o.qEnd; w[2] = o.tStart; w[3] = o.tEnd; w[4] = o.strand ? 1u : 0u; w[5] = o.resMatches;
+            w[6] = o.qLength; w[7] = o.tLength;
+            strncpy(qnames + (size_t)n * name_stride, o.qName.c_str(), name_stride - 1);
+            qnames[(size_t)n * name_stride + name_stride - 1] = 0;
+            strncpy(tnames + (size_t)n * name_stride, o.tName.c_str(), name_stride - 1);
+            tnames[(size_t)n * name_stride + name_stride - 1] = 0;
+            n++;
+        }
+        if (!cur.empty()) pile++;
+        if (f.eof()) break;
+        cur = getNextReadPile(f, max_support);   /* as the driver does: ask again after an empty pile (CONSENT-correction.cpp:88-91) */
+    }
+    return (int)n;
+}
+
 int ref_revcomp(const char* s, uint32_t len, char* out) {
     std::string r = rev_comp::run(std::string(s, len));
     memcpy(out, r.data(), r.size());

@@ -1,0 +1,128 @@
+"""GPU: the whole read-correction loop through the library (host feeders -> device extraction -> consensus -> re-assembly,
+consent_amd/pipeline.py) against the same loop assembled from the oracle's pieces.  FASTA text must be identical."""
+import io
+import random
+
+import numpy as np
+import pytest
+
+import consent_amd as ca
+import oracle_lib
+from consent_amd.pipeline import correct_reads
+from test_oracle_ref import rand_seq
+from test_oracle_stitch import stitch
+
+pytestmark = pytest.mark.gpu
+
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def noisy_map(rng, s, rate):
+    """noisy copy of s and, for every position of s, the position of the copy it ends up at"""
+    out, pos = [], []
+    for c in s:
+        pos.append(len(out))
+        x = rng.random()
+        if x < rate * 0.3:
+            continue  # deletion
+        if x < rate * 0.6:
+            out.append(rng.choice("ACGT"))  # insertion before the base
+        out.append(rng.choice("ACGT") if x < rate else c)
+    pos.append(len(out))
+    return "".join(out), pos
+
+
+def make_dataset(tmp_path, seed, n_reads=36, glen=7000, rate=0.1):
+    rng = random.Random(seed)
+    genome = rand_seq(rng, glen)
+    reads = []
+    for i in range(n_reads):
+        ln = rng.randrange(1200, 3200)
+        g0 = rng.randrange(0, glen - ln)
+        fwd, pos = noisy_map(rng, genome[g0 : g0 + ln], rate)
+        rev = rng.random() < 0.4
+        seq = fwd[::-1].translate(COMP) if rev else fwd
+        reads.append(dict(name=f"r{i}", g0=g0, g1=g0 + ln, pos=pos, rev=rev, seq=seq))
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for r in reads:
+            f.write(f">{r['name']} len={len(r['seq'])}\n{r['seq']}\n")
+
+    def span(r, a, b):
+        """coordinates of genome [a,b) on read r's own forward strand: (start, end_exclusive)"""
+        s, e = r["pos"][a - r["g0"]], r["pos"][b - r["g0"]]
+        if r["rev"]:
+            n = len(r["seq"])
+            s, e = n - e, n - s
+        return s, max(e, s + 1)
+
+    paf = tmp_path / "ovl.paf"
+    with open(paf, "w") as f:
+        for q in reads:
+            for t in reads:
+                if t is q:
+                    continue
+                a, b = max(q["g0"], t["g0"]), min(q["g1"], t["g1"])
+                if b - a < 400:
+                    continue
+                qs, qe = span(q, a, b)
+                ts, te = span(t, a, b)
+                strand = "+" if q["rev"] == t["rev"] else "-"
+                matches = int((b - a) * (1 - 2 * rate)) + rng.randrange(0, 3)
+                f.write("\t".join(str(x) for x in [q["name"], len(q["seq"]), qs, qe, strand, t["name"], len(t["seq"]), ts, te, matches, b - a, 60]) + "\n")
+    return str(fa), str(paf)
+
+
+def oracle_pipeline(fa, paf, *, min_support, max_support, window_size, mer_size, common_kmers, min_anchors, solid_thresh, window_overlap, max_msa, do_trim=True):
+    """CONSENT-correction.cpp:19-58 with the oracle's restatements (parsing through the reference-pinned host feeders)"""
+    o = oracle_lib.oracle()
+    ix = ca.ReadIndex(fa)
+    seqs = [ix.sequence(i) for i in range(len(ix.names))]
+    prm = ca.Params(mer_size, solid_thresh, common_kmers, min_anchors, max_msa)
+    out = []
+    for tpl, tpl_len, ov, _ in ca.PafReader(paf, ix, max_support):
+        rows = [[tpl_len, int(r[0]), int(r[1]), int(r[5]), int(ix.seq_len[int(r[2])]), int(r[3]), int(r[4]), i] for i, r in enumerate(ov)]
+        targets = [seqs[int(r[2])] for r in ov]
+        wins = oracle_lib.window_positions(o.cwo_window_positions, tpl_len, rows, min_support, window_size, window_overlap)
+        if not wins:
+            continue
+        piles = [oracle_lib.window_pile(o.cwo_window_pile, rows, seqs[tpl], targets, qb, qe, mer_size) for qb, qe in wins]
+        res, _ = oracle_lib.oracle_run(prm, ca.pack_piles(piles))
+        cons = [res.consensus(w) for w in range(len(piles))]
+        solid = [res.solid_kmers(w) for w in range(len(piles))]
+        final, _ = stitch(seqs[tpl], cons, [p[0] if p else "" for p in piles], solid, wins, do_trim=do_trim, k=mer_size, wsize=window_size, wover=window_overlap)
+        if final:
+            out.append((ix.names[tpl], final))
+    return out
+
+
+PRM = dict(min_support=3, max_support=1000, window_size=500, mer_size=9, common_kmers=8, min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150)
+
+
+def test_fasta_identical_to_the_oracle_pipeline(tmp_path):
+    fa, paf = make_dataset(tmp_path, 31)
+    buf = io.StringIO()
+    got = correct_reads(fa, paf, buf, **PRM)
+    want = oracle_pipeline(fa, paf, **PRM)
+    assert len(want) > 10
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, g), (_, w) in zip(got, want):
+        assert g == w, n
+    assert buf.getvalue() == "".join(f">{n}\n{s}\n" for n, s in want)
+    up = sum(c.isupper() for _, s in got for c in s) / sum(len(s) for _, s in got)
+    assert up > 0.9
+
+
+def test_batching_does_not_change_the_output(tmp_path):
+    fa, paf = make_dataset(tmp_path, 32, n_reads=24)
+    a = correct_reads(fa, paf, None, windows_per_batch=1, **PRM)
+    b = correct_reads(fa, paf, None, windows_per_batch=100000, **PRM)
+    assert a == b and len(a) > 5
+
+
+def test_other_parameters_and_max_support_cut(tmp_path):
+    fa, paf = make_dataset(tmp_path, 33, n_reads=30, rate=0.13)
+    prm = dict(PRM, max_support=6, mer_size=8, min_anchors=2, max_msa=20, window_size=400, window_overlap=40)
+    got = correct_reads(fa, paf, None, **prm)
+    want = oracle_pipeline(fa, paf, **prm)
+    assert got == want and len(got) > 5
