@@ -18,4 +18,7 @@ from .engine import (  # noqa: F401
     lib_path,
     load_library,
     pack_piles,
+    paf_explode,
+    paf_merge,
+    paf_reformat,
 )

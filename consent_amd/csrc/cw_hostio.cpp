@@ -3,6 +3,7 @@
  *
  *   cw_index_reads      <- indexReads      (src/utils.cpp:166-205): FASTA/FASTQ -> 2-bit reads keyed by name
  *   cw_paf_next_pile    <- getNextReadPile (src/alignmentPiles.cpp:22-58) + Overlap(std::string) (src/Overlap.h:26-58)
+ *   cw_paf_reformat / cw_paf_explode / cw_paf_merge <- the wrapper tools reformatPAF.cpp, explode.cpp, merge.cpp
  *
  * Plain host C++ (no device code); results are handed over as the same cw_read_set / cw_overlap structures the device
  * entry points take.  Behaviours kept on purpose (each pinned against the reference's own TUs in tests/test_hostio_ref.py):
@@ -239,6 +240,104 @@ int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw
         r->bad = true;
         return CW_E_NOMEM;
     }
+}
+
+/* ---- wrapper plumbing: what CONSENT-correct / CONSENT-polish run around the binary ------------------------------ */
+
+/* reformatPAF (src/reformatPAF.cpp:22-46): swap query and target columns of every line (fields 6-9, 5, 1-4, then the rest). */
+int cw_paf_reformat(const char* in_path, const char* out_path) {
+    if (!in_path || !out_path) return CW_E_INVALID;
+    std::ifstream in(in_path);
+    std::ofstream out(out_path);
+    if (!in || !out) return CW_E_INVALID;
+    try {
+        std::string line;
+        while (std::getline(in, line)) {
+            std::vector<std::string> v;
+            size_t p = 0;
+            while (p <= line.size()) {
+                const size_t e = line.find('\t', p);
+                if (e == std::string::npos) { if (p < line.size()) v.push_back(line.substr(p)); break; }   /* getline-style split: no trailing empty field */
+                v.push_back(line.substr(p, e - p));
+                p = e + 1;
+            }
+            if (v.size() < 9) return CW_E_INVALID;
+            out << v[5] << '\t' << v[6] << '\t' << v[7] << '\t' << v[8] << '\t' << v[4] << '\t' << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3];
+            for (size_t i = 9; i < v.size(); ++i) out << '\t' << v[i];
+            out << '\n';
+        }
+    } catch (...) { return CW_E_NOMEM; }
+    return out.good() ? CW_OK : CW_E_INTERNAL;
+}
+
+/* explode (src/explode.cpp:14-51): split a PAF into prefix_1, prefix_2, ... so that inside one file every query name forms a
+ * single run of lines: a new file starts when a name comes back after other names.  Stops at the first empty line. */
+int cw_paf_explode(const char* in_path, const char* out_prefix, uint32_t* n_files) {
+    if (!in_path || !out_prefix) return CW_E_INVALID;
+    std::ifstream f(in_path);
+    if (!f) return CW_E_INVALID;
+    try {
+        std::unordered_map<std::string, char> seen;
+        uint32_t nb = 1;
+        std::ofstream cur(std::string(out_prefix) + "_" + std::to_string(nb));
+        if (!cur) return CW_E_INVALID;
+        std::string line, cur_read, old_read, pending;
+        auto next = [&]() { line.clear(); std::getline(f, line); };
+        next();
+        while (!line.empty()) {
+            old_read = cur_read;
+            const size_t t = line.find('\t');
+            cur_read = line.substr(0, t);
+            if (old_read.empty() || cur_read == old_read) {
+                pending += line; pending += '\n';
+                next();
+            } else {
+                seen.emplace(old_read, 1);
+                cur << pending;
+                pending = line; pending += '\n';
+                next();
+                if (seen.count(cur_read)) {
+                    seen.clear();
+                    cur.close();
+                    nb++;
+                    cur.open(std::string(out_prefix) + "_" + std::to_string(nb));
+                    if (!cur) return CW_E_INVALID;
+                }
+            }
+        }
+        if (!pending.empty()) cur << pending;
+        cur.close();
+        if (n_files) *n_files = nb;
+    } catch (...) { return CW_E_NOMEM; }
+    return CW_OK;
+}
+
+/* merge (src/merge.cpp:29-65): for every header line (its first character dropped) copy, file after file, the run of lines whose
+ * first column equals it -- all overlaps of one read end up contiguous, in header order. */
+int cw_paf_merge(const char* out_path, const char* headers_path, const char* const* in_paths, uint32_t n_in) {
+    if (!out_path || !headers_path || (n_in && !in_paths)) return CW_E_INVALID;
+    std::ofstream out(out_path);
+    std::ifstream headers(headers_path);
+    if (!out || !headers) return CW_E_INVALID;
+    try {
+        std::vector<std::ifstream> files(n_in);
+        std::vector<std::string> pending(n_in);
+        std::vector<char> has_pending(n_in, 0);
+        for (uint32_t i = 0; i < n_in; ++i) { files[i].open(in_paths[i]); if (!files[i]) return CW_E_INVALID; }
+        std::string header, line;
+        while (std::getline(headers, header)) {
+            header = header.empty() ? header : header.substr(1);
+            for (uint32_t i = 0; i < n_in; ++i) {
+                for (;;) {
+                    if (has_pending[i]) { line.swap(pending[i]); has_pending[i] = 0; }
+                    else { line.clear(); if (!std::getline(files[i], line)) break; }
+                    if (line.substr(0, line.find('\t')) == header) out << line << '\n';
+                    else { pending[i].swap(line); has_pending[i] = 1; break; }   /* the reference seeks back one line */
+                }
+            }
+        }
+    } catch (...) { return CW_E_NOMEM; }
+    return out.good() ? CW_OK : CW_E_INTERNAL;
 }
 
 } // extern "C"

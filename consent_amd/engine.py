@@ -125,6 +125,9 @@ def load_library():
     lib.cw_paf_next_pile.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cw_paf_close.argtypes = [C.c_void_p]
     lib.cw_paf_close.restype = None
+    lib.cw_paf_reformat.argtypes = [C.c_char_p, C.c_char_p]
+    lib.cw_paf_explode.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]
+    lib.cw_paf_merge.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]
     lib.cw_window_positions.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cw_pack_sequence.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.cw_pack_sequence.restype = C.c_int64
@@ -224,6 +227,27 @@ def synth_host(spec):
     bases = np.zeros(nw.value, np.uint32)
     _check(lib, lib.cw_synth_host(C.byref(spec), _ptr(wfs), _ptr(lens), _ptr(offs), _ptr(bases)), "cw_synth_host")
     return HostBatch(wfs, lens, offs, bases)
+
+
+def paf_reformat(in_path, out_path):
+    """reformatPAF (src/reformatPAF.cpp): swap the query and target columns of a PAF file."""
+    lib = load_library()
+    _check(lib, lib.cw_paf_reformat(os.fsencode(in_path), os.fsencode(out_path)), "cw_paf_reformat")
+
+
+def paf_explode(in_path, out_prefix):
+    """explode (src/explode.cpp): returns the list of chunk files written (out_prefix_1 ...)."""
+    lib = load_library()
+    n = C.c_uint32()
+    _check(lib, lib.cw_paf_explode(os.fsencode(in_path), os.fsencode(out_prefix), C.byref(n)), "cw_paf_explode")
+    return [f"{out_prefix}_{i}" for i in range(1, n.value + 1)]
+
+
+def paf_merge(out_path, headers_path, in_paths):
+    """merge (src/merge.cpp): gather every read's lines from the chunks, in the order of the header file."""
+    lib = load_library()
+    arr = (C.c_char_p * max(len(in_paths), 1))(*[os.fsencode(p) for p in in_paths])
+    _check(lib, lib.cw_paf_merge(os.fsencode(out_path), os.fsencode(headers_path), arr, len(in_paths)), "cw_paf_merge")
 
 
 class ReadIndex:

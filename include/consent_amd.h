@@ -190,6 +190,14 @@ int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw
                      uint32_t* n);
 void cw_paf_close(cw_paf_reader* r);
 
+/* ---- wrapper plumbing: the small tools CONSENT-correct / CONSENT-polish run around the binary, as host functions.
+ * cw_paf_reformat <- src/reformatPAF.cpp:22-46 (swap query and target columns); cw_paf_explode <- src/explode.cpp:14-51 (split so
+ * that every query name is one run of lines per file; files are out_prefix_1 .. out_prefix_N); cw_paf_merge <- src/merge.cpp:29-65
+ * (gather, in the order of a header file, every read's lines from the exploded chunks). */
+int cw_paf_reformat(const char* in_path, const char* out_path);
+int cw_paf_explode(const char* in_path, const char* out_prefix, uint32_t* n_files);
+int cw_paf_merge(const char* out_path, const char* headers_path, const char* const* in_paths, uint32_t n_in);
+
 /* ---- read re-assembly on the device -------------------------------------------------
  * Stands in for alignConsensus (src/correctionAlignment.cpp:47-140) followed, when do_trim != 0, by trimRead(.,1) and
  * dropRead (src/CONSENT-correction.cpp:47-58, src/utils.cpp:96-128, :71-73): every window consensus of a read is
