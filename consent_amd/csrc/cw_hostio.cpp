@@ -102,14 +102,11 @@ struct cw_paf_reader {
 
 extern "C" {
 
-int cw_index_reads(const char* path, cw_read_index** out) {
-    if (!path || !out) return CW_E_INVALID;
-    *out = nullptr;
+static int index_file(cw_read_index* ix, const char* path) {
     std::ifstream f(path);
     if (!f) return CW_E_INVALID;
-    cw_read_index* ix = new (std::nothrow) cw_read_index();
-    if (!ix) return CW_E_NOMEM;
     try {
+        if (!ix->words.empty()) ix->words.pop_back(); /* the guard word of an earlier file */
         std::string header, seq, sequence;
         std::getline(f, header);
         while (header.length() > 0) {
@@ -150,11 +147,26 @@ int cw_index_reads(const char* path, cw_read_index** out) {
         }
         ix->words.push_back(0u); /* readers may look one word past a sequence's last word */
     } catch (...) {
-        delete ix;
         return CW_E_NOMEM;
     }
+    return CW_OK;
+}
+
+int cw_index_reads(const char* path, cw_read_index** out) {
+    if (!path || !out) return CW_E_INVALID;
+    *out = nullptr;
+    cw_read_index* ix = new (std::nothrow) cw_read_index();
+    if (!ix) return CW_E_NOMEM;
+    const int rc = index_file(ix, path);
+    if (rc != CW_OK) { delete ix; return rc; }
     *out = ix;
     return CW_OK;
+}
+
+/* a second file into the same index, as runCorrection does with the proof file (CONSENT-correction.cpp:69-73): same names replace */
+int cw_index_reads_append(cw_read_index* ix, const char* path) {
+    if (!ix || !path) return CW_E_INVALID;
+    return index_file(ix, path);
 }
 
 void cw_read_index_free(cw_read_index* ix) { delete ix; }

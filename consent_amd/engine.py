@@ -112,6 +112,7 @@ def load_library():
     lib.cw_stitch_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_uint32, C.c_uint32,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_index_reads.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.cw_index_reads_append.argtypes = [C.c_void_p, C.c_char_p]
     lib.cw_read_index_free.argtypes = [C.c_void_p]
     lib.cw_read_index_free.restype = None
     lib.cw_read_index_count.argtypes = [C.c_void_p]
@@ -253,11 +254,13 @@ def paf_merge(out_path, headers_path, in_paths):
 class ReadIndex:
     """indexReads (utils.cpp:166-205) through the library's host feeder: names, lengths and the 2-bit read set."""
 
-    def __init__(self, path):
+    def __init__(self, path, *more_paths):
         self.lib = load_library()
         h = C.c_void_p()
         _check(self.lib, self.lib.cw_index_reads(os.fsencode(path), C.byref(h)), f"cw_index_reads({path})")
         self.handle = h
+        for p in more_paths:
+            _check(self.lib, self.lib.cw_index_reads_append(h, os.fsencode(p)), f"cw_index_reads_append({p})")
         n = self.lib.cw_read_index_count(h)
         view, nw = ReadSet(), C.c_uint64()
         _check(self.lib, self.lib.cw_read_index_view(h, C.byref(view), C.byref(nw)), "cw_read_index_view")

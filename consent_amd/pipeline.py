@@ -24,14 +24,19 @@ class _DeviceReads:
 
 
 def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=1000, window_size=500, mer_size=9, common_kmers=8,
-                  min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150, do_trim=True, windows_per_batch=8192, device=0):
+                  min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150, do_trim=True, proof_path=None, windows_per_batch=8192,
+                  device=0):
     """Corrects every read that has a pile in `paf_path`; writes FASTA (">name\\nsequence\\n", upper case = corrected) to `out`
     (a text file object; None = collect) and returns the list of (name, sequence) in PAF order.  Reads whose corrected
-    sequence is empty -- no window, or dropped by the 10 % rule -- are skipped, as CONSENT-correction.cpp:101-103 does."""
+    sequence is empty -- no window, or dropped by the 10 % rule -- are skipped, as CONSENT-correction.cpp:101-103 does.
+    With `proof_path` (assembly polishing, or correction against proof reads) that file is indexed into the same read set and the
+    result is neither trimmed nor dropped (CONSENT-correction.cpp:69-73, CONSENT-polishing.cpp:112-116)."""
     import torch
 
     dev = torch.device("cuda", device)
-    index = ReadIndex(reads_path)
+    index = ReadIndex(reads_path, *([proof_path] if proof_path else []))
+    if proof_path:
+        do_trim = False
     eng = Engine(Params(mer_size, solid_thresh, common_kmers, min_anchors, max_msa), device)
     lib = eng.lib
     reads_dev = _DeviceReads(index, dev)
@@ -151,9 +156,11 @@ def main(argv=None):
     ap.add_argument("-f", dest="solid_thresh", type=int, default=4)
     ap.add_argument("-m", dest="window_overlap", type=int, default=50)
     ap.add_argument("-M", dest="max_msa", type=int, default=150)
+    ap.add_argument("-R", dest="proof", default=None, help="proof reads / contigs: indexed too, no trimming")
     a = ap.parse_args(argv)
     correct_reads(a.reads, a.paf, sys.stdout, min_support=a.min_support, max_support=a.max_support, window_size=a.window_size, mer_size=a.mer_size,
-                  common_kmers=a.common_kmers, min_anchors=a.min_anchors, solid_thresh=a.solid_thresh, window_overlap=a.window_overlap, max_msa=a.max_msa)
+                  common_kmers=a.common_kmers, min_anchors=a.min_anchors, solid_thresh=a.solid_thresh, window_overlap=a.window_overlap, max_msa=a.max_msa,
+                  proof_path=a.proof)
 
 
 if __name__ == "__main__":

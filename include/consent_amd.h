@@ -172,6 +172,7 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
  * but A/C/G packs as T).  The view's pointers are HOST pointers laid out like the device read set: upload them once. */
 typedef struct cw_read_index cw_read_index;
 int cw_index_reads(const char* path, cw_read_index** out);
+int cw_index_reads_append(cw_read_index* idx, const char* path);   /* a second file into the same index (the proof file, CONSENT-correction.cpp:69-73) */
 void cw_read_index_free(cw_read_index* idx);
 uint32_t cw_read_index_count(const cw_read_index* idx);
 int cw_read_index_view(const cw_read_index* idx, cw_read_set* host_view, uint64_t* n_words);

@@ -126,3 +126,59 @@ def test_other_parameters_and_max_support_cut(tmp_path):
     got = correct_reads(fa, paf, None, **prm)
     want = oracle_pipeline(fa, paf, **prm)
     assert got == want and len(got) > 5
+
+
+def test_polishing_mode_contigs_as_templates(tmp_path):
+    """CONSENT-polishing: the templates come from a second file (-R), nothing is trimmed or dropped (CONSENT-polishing.cpp:112-116)."""
+    rng = random.Random(34)
+    glen = 5200
+    genome = rand_seq(rng, glen)
+    reads = []
+    for i in range(40):
+        ln = rng.randrange(900, 2400)
+        g0 = rng.randrange(0, glen - ln)
+        fwd, pos = noisy_map(rng, genome[g0 : g0 + ln], 0.1)
+        rev = rng.random() < 0.5
+        reads.append(dict(name=f"r{i}", g0=g0, g1=g0 + ln, pos=pos, rev=rev, seq=fwd[::-1].translate(COMP) if rev else fwd))
+    contigs = []
+    for c, (a, b) in enumerate([(0, 2600), (2500, glen)]):
+        fwd, pos = noisy_map(rng, genome[a:b], 0.03)
+        contigs.append(dict(name=f"ctg{c}", g0=a, g1=b, pos=pos, rev=False, seq=fwd))
+    fa, proof, paf = tmp_path / "reads.fa", tmp_path / "contigs.fa", tmp_path / "ovl.paf"
+    open(fa, "w").write("".join(f">{r['name']}\n{r['seq']}\n" for r in reads))
+    open(proof, "w").write("".join(f">{c['name']}\n{c['seq']}\n" for c in contigs))
+
+    def span(r, a, b):
+        s, e = r["pos"][a - r["g0"]], r["pos"][b - r["g0"]]
+        if r["rev"]:
+            n = len(r["seq"])
+            s, e = n - e, n - s
+        return s, max(e, s + 1)
+
+    with open(paf, "w") as f:
+        for q in contigs:
+            for t in reads:
+                a, b = max(q["g0"], t["g0"]), min(q["g1"], t["g1"])
+                if b - a < 300:
+                    continue
+                qs, qe = span(q, a, b)
+                ts, te = span(t, a, b)
+                f.write("\t".join(str(x) for x in [q["name"], len(q["seq"]), qs, qe, "-" if t["rev"] else "+", t["name"], len(t["seq"]), ts, te, b - a - 50, b - a, 60]) + "\n")
+    got = correct_reads(str(fa), str(paf), None, proof_path=str(proof), **PRM)
+    # the same loop from the oracle's pieces, untrimmed
+    o = oracle_lib.oracle()
+    ix = ca.ReadIndex(str(fa), str(proof))
+    seqs = [ix.sequence(i) for i in range(len(ix.names))]
+    prm = ca.Params(PRM["mer_size"], PRM["solid_thresh"], PRM["common_kmers"], PRM["min_anchors"], PRM["max_msa"])
+    want = []
+    for tpl, tpl_len, ov, _ in ca.PafReader(str(paf), ix, PRM["max_support"]):
+        rows = [[tpl_len, int(r[0]), int(r[1]), int(r[5]), int(ix.seq_len[int(r[2])]), int(r[3]), int(r[4]), i] for i, r in enumerate(ov)]
+        targets = [seqs[int(r[2])] for r in ov]
+        wins = oracle_lib.window_positions(o.cwo_window_positions, tpl_len, rows, PRM["min_support"], 500, 50)
+        piles = [oracle_lib.window_pile(o.cwo_window_pile, rows, seqs[tpl], targets, qb, qe, 9) for qb, qe in wins]
+        res, _ = oracle_lib.oracle_run(prm, ca.pack_piles(piles))
+        final, _ = stitch(seqs[tpl], [res.consensus(w) for w in range(len(piles))], [p[0] if p else "" for p in piles],
+                          [res.solid_kmers(w) for w in range(len(piles))], wins, do_trim=False, k=9, wsize=500, wover=50)
+        want.append((ix.names[tpl], final))
+    assert got == want and len(got) == 2
+    assert all(len(s) > 2000 for _, s in got)
