@@ -4,10 +4,10 @@
  *
  * The local alignment the reference gets from StripedSmithWaterman::Aligner is restated per include/cw_policy.h
  * (library absent: PARITY UNPINNED, bit-identical to the oracle's restatement):
- *   sweep      lanes = query positions (chunks of 64), loop over reference columns; E carried per lane in LDS,
- *              F (gap inside the column) as a DPP exclusive prefix max of h'[t] + t*ext, exact because open >= ext;
- *              per column a wave max + lowest-row argmax; forward sweep finds (score, end), reverse sweep on the
- *              reversed prefixes finds begin (stops when the forward score is reached)
+ *   sweep      two query positions per lane (packed int16), loop over reference columns; H, E and the per-position best in
+ *              registers; F (gap inside the column) as a DPP exclusive prefix max of h'[t] + t*ext, exact because open >= ext;
+ *              forward sweep finds (score, end), reverse sweep on the reversed prefixes finds begin (stops when the forward
+ *              score is reached)
  *   indels     banded traceback, run by the whole wave redundantly (rare: only when two overlapping windows disagree)
  *   the read   lives in its output slot as a gap buffer (left part at the front, untouched tail right-aligned), so a
  *              replace that changes the length moves only the few hundred characters between the gap and the edit.
@@ -16,14 +16,16 @@
 #define CW_STITCH_H
 
 #include "cw_device.h"
+#include "cw_poa.h" /* packed int16 helpers (pk_add, pk_max, pk_wave_scan_max, ...) */
 
 #define CW_ST_WAVES 4
 #define CW_ST_QMAX 2048 /* consensus length */
 #define CW_ST_RMAX 2048 /* aligned slice of the read: window_size + 2*window_overlap */
-/* per wave: slice codes | current consensus | previous consensus | H, E (int16) | query codes forward, reversed */
 #define CW_ST_DIR_BYTES (256u << 10) /* banded traceback directions, per wave, in global memory */
 #define CW_ST_MAX_WGS 512
-#define CW_ST_SLAB (CW_ST_RMAX + 2 * CW_ST_QMAX + 4 * CW_ST_QMAX + 2 * CW_ST_QMAX)
+#define CW_ST_ROWS_BYTES 4096u /* banded traceback rows: 3 x (2*band + 3) int32 -> band <= 169 */
+/* per wave: slice codes | current consensus | previous consensus | traceback rows | query codes forward, reversed */
+#define CW_ST_SLAB (CW_ST_RMAX + 2 * CW_ST_QMAX + CW_ST_ROWS_BYTES + 2 * CW_ST_QMAX)
 
 struct StitchArgs {
     cw_read_set reads;
@@ -100,60 +102,108 @@ __device__ __forceinline__ uint32_t st_uni(uint32_t v) { return (uint32_t)__buil
 struct StSweep { int score, col, row; };
 
 /*
- * One local-alignment sweep.  q[] (m codes, already in sweep order) against r[] walked from r_first in `step` until
- * r_last_excl.  H/E are per-query-position state in LDS.  Stops early when `terminate` is reached (-1: never).
+ * One local-alignment sweep.  q[] (m codes, already in sweep order) against r[] walked from r_first in `step` until r_last_excl.
+ * Two query positions per lane in packed int16 (scores <= 2 * CW_ST_QMAX fit); the column state (H, E) and the per-position best
+ * (value, first column reaching it) stay in registers: no LDS traffic and no per-column reduction.  The in-column gap F is an
+ * exclusive prefix max of h'[t] + t*ext in position order (exact because open >= ext).  The reference's "first column reaching
+ * the best score, smallest query index in it" falls out at the end: the global maximum, the earliest column among the positions
+ * holding it, the smallest position among those.  A reverse sweep stops at the first column holding `terminate` (-1: never).
+ * NCH2 = chunks of 128 query positions.
  */
-__device__ __forceinline__ StSweep st_sweep(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int16_t* H,
-                            int16_t* E, int lane) {
+template <int NCH2>
+__device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate,
+                                               int lane) {
     const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), FADJ = pk_make(GE - GO, GE - GO);
     m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
-    for (int j = lane; j < m; j += 64) { H[j] = 0; E[j] = 0; }
-    cw_wave_sync();
-    StSweep best{0, -1, 0};
+    const int TERMPK = pk_make(terminate, terminate);
+    int hprev[NCH2], ee[NCH2], jg[NCH2], amask[NCH2], scq[NCH2][4], bestv[NCH2], bce[NCH2], bco[NCH2];
+#pragma unroll
+    for (int c = 0; c < NCH2; ++c) {
+        const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
+        jg[c] = pk_make(j0 * GE, j1 * GE);
+        amask[c] = (j0 < m ? 0xFFFF : 0) | (j1 < m ? (int)0xFFFF0000 : 0);
+        const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+            scq[c][bb] = pk_make(q0 == 4 ? 0 : (q0 == bb ? CW_SSW_MATCH : -CW_SSW_MISMATCH), q1 == 4 ? 0 : (q1 == bb ? CW_SSW_MATCH : -CW_SSW_MISMATCH));
+        hprev[c] = 0; ee[c] = 0; bestv[c] = 0; bce[c] = -1; bco[c] = -1;
+    }
+    int hit_col = -1;
     for (int i = r_first; i != r_last_excl; i += step) {
         const int rc = st_uni((int)r[i]);
-        int carry_diag = 0;          /* H of the previous column at row 64c-1 */
-        int carry_f = CW_NEG;        /* running max of h'[t] + t*GE over earlier rows of this column */
-        int lane_max = 0, lane_row = 0x7FFFFFFF;
-        for (int c0 = 0; c0 < m; c0 += 64) {
-            const int j = c0 + lane;
-            const bool act = j < m;
-            const int hprev = act ? (int)H[j] : 0;
-            int e = act ? max((int)E[j] - GE, hprev - GO) : 0;
-            e = max(e, 0);
-            const int diag = cw_wave_shr1(hprev, carry_diag);
-            carry_diag = cw_lane_value(hprev, 63);
-            const int qc = act ? (int)q[j] : 4;
-            const int s = (qc == 4 || rc == 4) ? 0 : (qc == rc ? CW_SSW_MATCH : -CW_SSW_MISMATCH);
-            int hp = max(max(diag + s, e), 0);
-            /* F[j] = max_{t<j}(h'[t] - GO - (j-1-t)*GE) = pmax_excl(h'[t] + t*GE) - GO - (j-1)*GE, clamped at 0 */
-            const int key = act ? hp + j * GE : CW_NEG;
-            const int inc = cw_wave_scan_max(key);
-            int ex = cw_wave_shr1(inc, CW_NEG);
-            ex = max(ex, carry_f);
-            carry_f = max(carry_f, cw_lane_value(inc, 63));
-            int f = ex - GO - (j - 1) * GE;
-            f = max(f, 0);
-            const int h = max(hp, f);
-            if (act) {
-                H[j] = (int16_t)h; E[j] = (int16_t)e;
-                if (h > lane_max) { lane_max = h; lane_row = j; }
+        int carry_pair = 0;      /* H of the previous column at rows (.., 128c - 1) */
+        int carry_f = CW_NEGPK;  /* running max of h'[t] + t*GE over the rows of this column so far, in both halves */
+        unsigned long long hit = 0ull;
+#pragma unroll
+        for (int c = 0; c < NCH2; ++c) {
+            if (c * 128 < m) {
+                const int hp_ = hprev[c];
+                int e = pk_max(pk_sub(ee[c], GEPK), pk_sub(hp_, GOPK));
+                e = pk_max(e, 0);
+                const int sh = CW_DPP(carry_pair, hp_, 0x138, 0xF);
+                carry_pair = cw_lane_value(hp_, 63);
+                const int dg = __builtin_amdgcn_alignbit(hp_, sh, 16);          /* rows (2l-1, 2l) of the previous column */
+                const int sv = rc == 0 ? scq[c][0] : rc == 1 ? scq[c][1] : rc == 2 ? scq[c][2] : rc == 3 ? scq[c][3] : 0;
+                const int hp = pk_max(pk_max(pk_add(dg, sv), e), 0);
+                /* F[j] = max_{t<j}(h'[t] + t*GE) - GO - (j-1)*GE: exclusive prefix max in position order */
+                const int w = pk_add(hp, jg[c]);
+                const int tot = pk_max(w, __builtin_amdgcn_perm(w, w, 0x01000302)); /* both halves = the lane's larger key */
+                const int inc = pk_wave_scan_max(tot);
+                int ex = CW_DPP(carry_f, inc, 0x138, 0xF);
+                ex = pk_max(ex, carry_f);
+                carry_f = pk_max(carry_f, cw_lane_value(inc, 63));
+                const int pre = pk_max(ex, (w << 16) | (CW_NEGPK & 0xFFFF));        /* the odd position also sees the even one of its lane */
+                const int f = pk_max(pk_add(pk_sub(pre, jg[c]), FADJ), 0);
+                const int h = pk_max(hp, f);
+                hprev[c] = h; ee[c] = e;
+                const int hm = h & amask[c];
+                const int nb = pk_max(bestv[c], hm);
+                const int ch = nb ^ bestv[c];
+                bestv[c] = nb;
+                bce[c] = (ch & 0xFFFF) ? i : bce[c];
+                bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
+                if (terminate >= 0) {
+                    const int d = hm ^ TERMPK;
+                    hit |= __ballot((d & 0xFFFF) == 0 || ((unsigned)d >> 16) == 0u);
+                }
             }
         }
-        /* column maximum, lowest row holding it */
-        int cm = lane_max, cr = lane_row;
-        for (int o = 32; o > 0; o >>= 1) {
-            const int om = __shfl_xor(cm, o), orr = __shfl_xor(cr, o);
-            if (om > cm || (om == cm && orr < cr)) { cm = om; cr = orr; }
-        }
-        cm = st_uni(cm); cr = st_uni(cr);
-        if (cm > best.score) {
-            best.score = cm; best.col = i; best.row = cr;
-            if (best.score == terminate) break;
-        }
-        cw_wave_sync();
+        if (hit) { hit_col = i; break; }
     }
+    /* the best score, the first column that reached it, the smallest position holding it there */
+    int lm = 0;
+#pragma unroll
+    for (int c = 0; c < NCH2; ++c) lm = max(lm, max((int)(short)(bestv[c] & 0xFFFF), (int)(short)((unsigned)bestv[c] >> 16)));
+    const int M = hit_col >= 0 ? terminate : st_uni(cw_wave_max(lm));
+    StSweep best{0, -1, 0};
+    if (M <= 0) return best;
+    /* sweep order = increasing i*step: compare columns through that key */
+    int kc = 0x7FFFFFFF;
+#pragma unroll
+    for (int c = 0; c < NCH2; ++c) {
+        if ((int)(short)(bestv[c] & 0xFFFF) == M) kc = min(kc, bce[c] * step);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M) kc = min(kc, bco[c] * step);
+    }
+    kc = st_uni(-cw_wave_max(-kc));
+    const int col = kc * step;
+    int jr = 0x7FFFFFFF;
+#pragma unroll
+    for (int c = 0; c < NCH2; ++c) {
+        const int j0 = c * 128 + 2 * lane;
+        if ((int)(short)(bestv[c] & 0xFFFF) == M && bce[c] == col) jr = min(jr, j0);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M && bco[c] == col) jr = min(jr, j0 + 1);
+    }
+    jr = st_uni(-cw_wave_max(-jr));
+    best.score = M; best.col = col; best.row = jr;
     return best;
+}
+
+__device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
+    m = st_uni(m);
+    if (m <= 512) return st_sweep_pk<4>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1024) return st_sweep_pk<8>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    return st_sweep_pk<16>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 }
 
 /* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
@@ -245,18 +295,18 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
 struct StAlign { int score, ref_begin, ref_end, query_begin, query_end; };
 
 /* full alignment: forward sweep, reverse sweep.  qfw = query codes; qrv = scratch for the reversed prefix. */
-__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int16_t* H, int16_t* E, int lane) {
+__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane) {
     StAlign a{0, 0, -1, 0, -1};
     m = st_uni(m); n = st_uni(n);
     if (m <= 0 || n <= 0) return a;
-    const StSweep fw = st_sweep(qfw, m, ref, 0, n, 1, -1, H, E, lane);
+    const StSweep fw = st_sweep_any(qfw, m, ref, 0, n, 1, -1, lane);
     a.score = fw.score;
     if (fw.score <= 0) return a;
     a.ref_end = fw.col; a.query_end = fw.row;
     const int pm = fw.row + 1;
     for (int x = lane; x < pm; x += 64) qrv[x] = qfw[fw.row - x];
     cw_wave_sync();
-    const StSweep bw = st_sweep(qrv, pm, ref, fw.col, -1, -1, fw.score, H, E, lane);
+    const StSweep bw = st_sweep_any(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
 }
@@ -282,9 +332,8 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
     uint8_t* refc = slab;                              /* CW_ST_RMAX codes of the aligned slice              */
     uint8_t* cur = refc + CW_ST_RMAX;                  /* current consensus (chars), CW_ST_QMAX              */
     uint8_t* old = cur + CW_ST_QMAX;                   /* previous window's consensus as written, CW_ST_QMAX */
-    int16_t* H = (int16_t*)(old + CW_ST_QMAX);         /* CW_ST_QMAX                                          */
-    int16_t* E = H + CW_ST_QMAX;                       /* CW_ST_QMAX                                          */
-    uint8_t* qfw = (uint8_t*)(E + CW_ST_QMAX);        /* CW_ST_QMAX query codes                              */
+    uint8_t* rows = old + CW_ST_QMAX;                  /* CW_ST_ROWS_BYTES: the three int32 rows of the banded traceback */
+    uint8_t* qfw = rows + CW_ST_ROWS_BYTES;            /* CW_ST_QMAX query codes                              */
     uint8_t* qrv = qfw + CW_ST_QMAX;                   /* CW_ST_QMAX reversed prefix / build area             */
     int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * CW_ST_WAVES + wave) * a.dir_bytes;
     for (;;) {
@@ -339,7 +388,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
             for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
             cw_wave_sync();
-            const StAlign al = st_align(qfw, (int)clen, qrv, refc, size_al, H, E, lane);                   /* :90 */
+            const StAlign al = st_align(qfw, (int)clen, qrv, refc, size_al, lane);                   /* :90 */
             if (a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
                 t[0] = (uint32_t)al_pos; t[1] = (uint32_t)size_al; t[2] = (uint32_t)al.score; t[3] = (uint32_t)al.ref_begin; t[4] = (uint32_t)al.ref_end;
@@ -380,11 +429,11 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
                             cw_wave_sync();
-                            const StAlign sub = st_align(qfw, (int)overlap, qrv, refc, (int)overlap, H, E, lane);
+                            const StAlign sub = st_align(qfw, (int)overlap, qrv, refc, (int)overlap, lane);
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
-                                                      sub.score, (uint8_t*)H, 4u * CW_ST_QMAX, dirbuf, a.dir_bytes, &ins, &del, lane)) { status = 2; break; }
+                                                      sub.score, rows, CW_ST_ROWS_BYTES, dirbuf, a.dir_bytes, &ins, &del, lane)) { status = 2; break; }
                             }
                             const uint32_t cut = overlap - ins + del;
                             if (cut < cl) {                                                                 /* :114-115 curCons = seq1 + curCons.substr(cut) */
