@@ -142,6 +142,22 @@ def test_high_identity_deep_piles_use_the_global_anchor_matrix(engines):
     assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:3])
 
 
+def test_very_deep_piles_score_chains_without_presence_bitsets(engines):
+    """More than 2048 sequences in a pile: no presence bitsets, the chain kernel compares positions row against row, and the
+    segmentation loops over the pile in several 64-sequence chunks."""
+    rng = random.Random(23)
+    truth = rand_seq(rng, 140)
+    # low error rates: at this depth a noisier pile has more than 2048 k-mers seen >= 15 times, a documented capacity of the counter table
+    piles = [[truth[:120]] + [mutate(rng, truth[:120], 0.03) for _ in range(2100)],
+             [truth[10:130]] + [mutate(rng, truth[10:130], 0.02) for _ in range(2300)]]
+    prm = (7, 4, 8, 2, 20)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=2)
+    assert_same(got, exp, len(piles), "very deep")
+    assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:2])
+
+
 def test_long_and_outlier_segments_exercise_all_tiers(engines):
     """Few anchors -> segments of hundreds of bases; graphs that outgrow the LDS tiers must give identical results."""
     rng = random.Random(13)
