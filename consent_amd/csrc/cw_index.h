@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than the exact table holds */
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
         /* export the solid set in ascending key order.  Thread t owns the contiguous words [t*wpt, (t+1)*wpt) (so thread
@@ -405,6 +406,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 if (nk0 == 0) wi->status = CW_WIN_TEMPLATE;
                 else { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             }
+            __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
@@ -465,6 +467,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const bool pg = (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
         if (pg && (uint64_t)A * Np > sc.p_fallback_elems) {
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
         for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
@@ -542,6 +545,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             uint8_t* blk = sc.ablock + ((size_t)wi->ab_base << 4);
             if (cw_ab_bytes(A, N, n_dirty) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
                 if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
                 continue;
             }
             uint32_t* hdr = (uint32_t*)blk;
