@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
         if (w >= b.n_windows) break;
         WinInfo* wi = &sc.win[w];
         /* one way through the body: every window ends at the status store + wave barrier at the bottom */
-        const bool ready = ch_uni(wi->status) == CW_WIN_CONSENSUS && ch_uni(wi->ab_ready) == 1u;
+        const bool ready = ch_uni(wi->status) == CW_WIN_CONSENSUS; /* the index kernel got to the end of this window */
         uint32_t new_status = 0xFFFFFFFFu; /* unchanged */
         uint32_t n_segs_out = 0, arena_used = 0;
         CW_PROF_T0();

@@ -38,7 +38,7 @@ struct WinInfo {
     uint32_t arena_used;
     uint32_t ab_base;    /* anchor block (index kernel -> chain kernel), in 16-byte units into DevScratch::ablock */
     uint32_t ab_cap;     /* 16-byte units */
-    uint32_t ab_ready;   /* 1 once the index kernel has written the block */
+    uint32_t pad_;
 };
 
 struct PoaTask {

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             wi.solid_base = (uint32_t)sb; wi.solid_cap = need_solid; wi.n_solid = 0;
             wi.seg_base = (uint32_t)gb; wi.seg_cap = need_seg; wi.n_segs = 0;
             wi.arena_base = (uint32_t)ab; wi.arena_cap = need_arena; wi.arena_used = 0;
-            wi.ab_base = (uint32_t)kb; wi.ab_cap = need_ab; wi.ab_ready = 0;
+            wi.ab_base = (uint32_t)kb; wi.ab_cap = need_ab; wi.pad_ = 0;
             if (over) { wi.status = CW_WIN_OVERFLOW; wi.solid_cap = wi.seg_cap = wi.arena_cap = wi.ab_cap = 0; wi.solid_base = wi.seg_base = wi.arena_base = wi.ab_base = 0; }
             sc.win[w] = wi;
         }
@@ -565,9 +565,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t n2 = (A * Np) >> 1;
                 for (uint32_t i = tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
             }
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) wi->ab_ready = 1;
+            /* no flag, no fence: every early exit above changes wi->status, so "still CW_WIN_CONSENSUS when the kernel has ended"
+               means the block is complete, and the kernel boundary makes it visible to cw_chain_kernel */
         }
         CW_PROF(sc.ctr, 4, tid == 0);
     }
