@@ -133,14 +133,18 @@ template <typename HT, int NCH>
 __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs) {
     const int nch = (cols + 63) >> 6;
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
-    int sq_[NCH], prev[NCH];
+    /* the last RC rows stay in registers (rc_[0] = the previous row): a predecessor a few ranks back -- the other arm of a bubble --
+       costs no memory round trip */
+    constexpr int RC = NCH <= 4 ? 2 : 1;
+    int sq_[NCH], rc_[RC][NCH];
     bool act[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int j = c * 64 + lane;
         act[c] = j < cols;
         sq_[c] = (j > 0 && act[c]) ? (int)M.sq[j - 1] : -1;
-        prev[c] = j * G; /* row 0 */
+#pragma unroll
+        for (int k = 0; k < RC; ++k) rc_[k][c] = j * G; /* row 0 */
     }
     uint32_t meta_n = M.rmeta[0];
     uint32_t pr0_n = M.rpred0[0];
@@ -155,32 +159,32 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
-            if (prow == i - 1) {
-                int carry_in = CW_NEG;
+            const int dist = i - prow;
+            int up[NCH];
+            if (dist <= RC) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int dg = cw_wave_shr1(prev[c], carry_in);
-                    carry_in = cw_lane_value(prev[c], 63);
-                    const int s = (sq_[c] == base) ? MS : XS;
-                    dgv[c] = dg + s; upv[c] = prev[c] + G;
-                    v[c] = max(v[c], max(dgv[c], upv[c]));
+                    up[c] = rc_[0][c];
+#pragma unroll
+                    for (int k = 1; k < RC; ++k) up[c] = (dist == k + 1) ? rc_[k][c] : up[c];
                 }
             } else {
                 cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
                 const int pr = prow * cols;
-                int up[NCH], dg[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int j = c * 64 + lane;
                     up[c] = act[c] ? (int)M.H[pr + j] : CW_NEG;
-                    dg[c] = (act[c] && j > 0) ? (int)M.H[pr + j - 1] : CW_NEG;
                 }
+            }
+            int carry_in = CW_NEG;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int s = (sq_[c] == base) ? MS : XS;
-                    dgv[c] = dg[c] + s; upv[c] = up[c] + G;
-                    v[c] = max(v[c], max(dgv[c], upv[c]));
-                }
+            for (int c = 0; c < NCH; ++c) {
+                const int dg = cw_wave_shr1(up[c], carry_in); /* the cell up-left: lane l-1 of the same row, column 0 has none */
+                carry_in = cw_lane_value(up[c], 63);
+                const int s = (sq_[c] == base) ? MS : XS;
+                dgv[c] = dg + s; upv[c] = up[c] + G;
+                v[c] = max(v[c], max(dgv[c], upv[c]));
             }
         }
         int carry = CW_NEG;
@@ -191,12 +195,15 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             w = cw_wave_scan_max(w);
             w = max(w, carry);
             carry = cw_lane_value(w, 63);
-            prev[c] = w + j * G;
-            if (act[c]) M.H[i * cols + j] = (HT)prev[c];
+            const int nv = w + j * G;
+#pragma unroll
+            for (int k = RC - 1; k > 0; --k) rc_[k][c] = rc_[k - 1][c];
+            rc_[0][c] = nv;
+            if (act[c]) M.H[i * cols + j] = (HT)nv;
             if (use_dirs && c < nch) {
                 /* single-predecessor row: the code the traceback would derive (diagonal, then vertical, then horizontal) */
                 int code = 3;
-                if (np == 1) code = (j > 0 && prev[c] == dgv[c]) ? 0 : (prev[c] == upv[c]) ? 1 : 2;
+                if (np == 1) code = (j > 0 && nv == dgv[c]) ? 0 : (nv == upv[c]) ? 1 : 2;
                 const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code >> 1);
                 if (lane == 0) { M.dirs[(r * nch + c) * 2] = b0; M.dirs[(r * nch + c) * 2 + 1] = b1; }
             }
@@ -248,13 +255,15 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     const int GPK = pk_make(G, G);
     const int nch = (cols + 127) >> 7;
-    int prev[NCH2], jg[NCH2], amask[NCH2], sc_[NCH2][4];
+    constexpr int RC = NCH2 <= 2 ? 3 : NCH2 <= 4 ? 2 : 1; /* rows kept in registers, rc_[0] = the previous one (see poa_fill) */
+    int rc_[RC][NCH2], jg[NCH2], amask[NCH2], sc_[NCH2][4];
     int* Hw = (int*)M.H;
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
         const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
         jg[c] = pk_make(j0 * G, j1 * G);
-        prev[c] = jg[c]; /* row 0 */
+#pragma unroll
+        for (int k = 0; k < RC; ++k) rc_[k][c] = jg[c]; /* row 0 */
         amask[c] = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
         const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
 #pragma unroll
@@ -274,9 +283,14 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
             int up[NCH2];
-            if (prow == i - 1) {
+            const int dist = i - prow;
+            if (dist <= RC) {
 #pragma unroll
-                for (int c = 0; c < NCH2; ++c) up[c] = prev[c];
+                for (int c = 0; c < NCH2; ++c) {
+                    up[c] = rc_[0][c];
+#pragma unroll
+                    for (int k = 1; k < RC; ++k) up[c] = (dist == k + 1) ? rc_[k][c] : up[c];
+                }
             } else {
                 cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
 #pragma unroll
@@ -308,13 +322,16 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
             ex = pk_max(ex, carry);
             w = pk_max(w, ex);
             carry = cw_lane_value(pk_max(inc, carry), 63);
-            prev[c] = pk_add(w, jg[c]);
+            const int nv = pk_add(w, jg[c]);
+#pragma unroll
+            for (int k = RC - 1; k > 0; --k) rc_[k][c] = rc_[k - 1][c];
+            rc_[0][c] = nv;
             const int j0 = c * 128 + 2 * lane;
-            if (j0 < cols) Hw[(i * hs + j0) >> 1] = prev[c];
+            if (j0 < cols) Hw[(i * hs + j0) >> 1] = nv;
             if (use_dirs && c < nch) {
                 int ce = 3, co = 3;
                 if (np == 1) {
-                    const int xd = prev[c] ^ dgv[c], xu = prev[c] ^ upv[c];
+                    const int xd = nv ^ dgv[c], xu = nv ^ upv[c];
                     ce = (j0 > 0 && (xd & 0xFFFF) == 0) ? 0 : ((xu & 0xFFFF) == 0) ? 1 : 2;
                     co = (((unsigned)xd >> 16) == 0u) ? 0 : (((unsigned)xu >> 16) == 0u) ? 1 : 2;
                 }
