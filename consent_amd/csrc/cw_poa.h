@@ -158,7 +158,7 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
         for (int q = 0; q < np; ++q) {
-            const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
+            const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
             const int dist = i - prow;
             int up[NCH];
             if (dist <= RC) {
@@ -281,7 +281,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) { v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK; }
         for (int q = 0; q < np; ++q) {
-            const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
+            const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
             int up[NCH2];
             const int dist = i - prow;
             if (dist <= RC) {
@@ -359,7 +359,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
 
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
-        const int L = pm.len;
+        const int L = __builtin_amdgcn_readfirstlane((int)pm.len); /* sizes steer every loop below: keep them in scalar registers */
+        n = __builtin_amdgcn_readfirstlane(n); ne = __builtin_amdgcn_readfirstlane(ne);
         if ((uint32_t)L > M.l_cap) return 2;
         {
             const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
@@ -444,7 +445,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o);
                 if (os > bs || (os == bs && orr < br)) { bs = os; br = orr; }
             }
-            bi = br + 1;
+            bi = __builtin_amdgcn_readfirstlane(br) + 1; /* wave-uniform from here on */
         }
 
         /* ---- traceback (wave-uniform); records seqrank[j] = rank aligned to sequence position j ---- */
@@ -551,6 +552,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                    hold the row's metadata, lanes with tr == 0 the sequence base of the column. */
                 const int tr = lane >> 3, tc = lane & 7;
                 while (i > 0) {
+                    i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
                     int ch[8];
                     ch[0] = i;
 #pragma unroll
