@@ -346,6 +346,50 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
     cw_wave_sync();
 }
 
+/* One traceback step at a node with several predecessors (or whose step the direction words left open), decided from the cell
+ * values in the order of preference of cw_policy.h: diagonal through the in-edges in order, then vertical through them, then
+ * horizontal.  Lanes = in-edges: every candidate cell is requested at once, one memory round trip for the whole step.
+ * Returns false when no move explains the cell (capacity/overflow paths report it). */
+template <typename HT>
+__device__ __forceinline__ bool poa_slow_step(const PoaMem<HT>& M, const int i, const int j, const int hs, const int pr0, const int lane,
+                                              int* pi_out, int* pj_out) {
+    const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
+    const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.rmeta[i - 1]);
+    const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+    int pi = i, pj = j;
+    bool found = false;
+    if (np <= 64) {
+        const bool mine = lane < np;
+        const int pr = mine ? ((np == 1) ? pr0 : (int)M.plist[off + lane]) : 0;
+        int hd = CW_NEG * 2, hv = CW_NEG * 2;
+        if (mine) { hv = (int)M.H[pr * hs + j]; if (j != 0) hd = (int)M.H[pr * hs + j - 1]; }
+        const int h = (int)M.H[i * hs + j];
+        const int hh = j != 0 ? (int)M.H[i * hs + j - 1] : CW_NEG * 2;
+        const int sx = (j != 0 && (int)M.sq[j - 1] == base) ? MS : XS;
+        const unsigned long long bd = __ballot(mine && j != 0 && h == hd + sx);
+        const unsigned long long bv = __ballot(mine && h == hv + G);
+        if (bd) { pi = __builtin_amdgcn_readlane(pr, __builtin_amdgcn_readfirstlane(__ffsll((long long)bd) - 1)); pj = j - 1; found = true; }
+        else if (bv) { pi = __builtin_amdgcn_readlane(pr, __builtin_amdgcn_readfirstlane(__ffsll((long long)bv) - 1)); pj = j; found = true; }
+        else if (__builtin_amdgcn_readfirstlane((j != 0 && h == hh + G) ? 1 : 0)) { pi = i; pj = j - 1; found = true; }
+    } else { /* more in-edges than lanes: one at a time */
+        const int h = M.H[i * hs + j];
+        if (j != 0) {
+            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
+            for (int q = 0; q < np && !found; ++q) {
+                const int pr = (int)M.plist[off + q];
+                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
+            }
+        }
+        for (int q = 0; q < np && !found; ++q) {
+            const int pr = (int)M.plist[off + q];
+            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
+        }
+        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
+    }
+    *pi_out = pi; *pj_out = pj;
+    return found;
+}
+
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
 template <typename HT, bool PK>
 __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
@@ -475,24 +519,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                         j -= run;
                     } else if (code0 == 3) {
                         /* several predecessors: decide from the cell values (same order of preference) */
-                        const uint32_t meta = M.rmeta[i - 1];
-                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                        const int h = M.H[i * hs + j];
-                        int pi = i, pj = j;
-                        bool found = false;
-                        if (j != 0) {
-                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
-                            for (int q = 0; q < np && !found; ++q) {
-                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
-                            }
-                        }
-                        for (int q = 0; q < np && !found; ++q) {
-                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
-                        }
-                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
-                        if (!found) return 3;
+                        int pi, pj;
+                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     } else if (pr0 != i - 1) {
@@ -523,24 +551,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     } else if (code == 2) {
                         j--;
                     } else {
-                        const uint32_t meta = M.rmeta[i - 1];
-                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                        const int h = M.H[i * hs + j];
-                        int pi = i, pj = j;
-                        bool found = false;
-                        if (j != 0) {
-                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
-                            for (int q = 0; q < np && !found; ++q) {
-                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
-                            }
-                        }
-                        for (int q = 0; q < np && !found; ++q) {
-                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
-                        }
-                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
-                        if (!found) return 3;
+                        int pi, pj;
+                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     }
@@ -598,25 +610,9 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     if (slow && i > 0) {
                         /* a node with several predecessors, or one whose predecessor is not the previous rank: one step
                            decided from direct reads (same order of preference) */
-                        const uint32_t meta = M.rmeta[i - 1];
-                        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                        const int pr0 = M.rpred0[i - 1];
-                        const int h = M.H[i * hs + j];
-                        int pi = i, pj = j;
-                        bool found = false;
-                        if (j != 0) {
-                            const int sx = ((int)M.sq[j - 1] == base) ? MS : XS;
-                            for (int q = 0; q < np && !found; ++q) {
-                                const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                                if (h == (int)M.H[pr * hs + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
-                            }
-                        }
-                        for (int q = 0; q < np && !found; ++q) {
-                            const int pr = (np == 1) ? pr0 : (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * hs + j] + G) { pi = pr; pj = j; found = true; }
-                        }
-                        if (!found && j != 0 && h == (int)M.H[i * hs + j - 1] + G) { pi = i; pj = j - 1; found = true; }
-                        if (!found) return 3;
+                        const int pr0 = __builtin_amdgcn_readfirstlane((int)M.rpred0[i - 1]);
+                        int pi, pj;
+                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     }
