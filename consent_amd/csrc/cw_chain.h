@@ -18,6 +18,7 @@
 
 #include "cw_device.h"
 #include "cw_index.h"
+#include "cw_poa.h" /* tier capacities for the routing rule */
 
 #define CW_CH_WAVES 4
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
@@ -199,9 +200,9 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                        and typically ends at 1.4-1.6x that; a task that still outgrows its tier is redone in the next one */
                     const uint32_t est = (e_mx * 17u + 9u) / 10u;
                     const uint32_t tier = !poa ? 0xFFu
-                                          : ((est + 1) * (e_mx + 1) <= 4096u && est <= 160u) ? 0u
-                                          : (est <= 256u && e_mx <= 255u)                   ? 1u
-                                          : (est <= 512u && e_mx <= 511u)                   ? 2u
+                                          : ((est + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est <= (uint32_t)CW_POA_NC) ? 0u
+                                          : (est <= (uint32_t)CW_POAM1_NC && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
+                                          : (est <= (uint32_t)CW_POAM2_NC && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long pm = __ballot(poa);

@@ -56,10 +56,16 @@
 
 /* bytes of the graph part of a slab (everything but H) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
+/* slab tiers: the arrays only the merge touches (aligned-node lists, the scratch of the rank placement, in-edge tails, the per-
+   position results of the merge passes) live in the wave's global slab, so that more waves fit a CU's LDS during the fill and the
+   traceback, which is where the time goes (M1: 12 -> 16 waves per CU) */
+#define CW_POA_HOT_BYTES(NC, EC, LC) (((NC) * 19 + (EC) * 6 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_COLD_BYTES(NC, LC) (((NC) * 10 + 4 * ((LC) + 1) + 255) / 256 * 256)
 #define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
-#define CW_POA_SLAB_TOTAL(NC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + (CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
+#define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
+#define CW_POA_SLAB_TOTAL(NC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD_BYTES(NC, LC))
 
 template <typename HT>
 struct PoaMem {
@@ -92,9 +98,10 @@ struct PoaMem {
 
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
-                                                HT* h_ext = nullptr, unsigned long long* d_ext = nullptr) {
+                                                HT* h_ext = nullptr, unsigned long long* d_ext = nullptr, uint8_t* cold = nullptr) {
     PoaMem<HT> M;
     uint8_t* p = base;
+    uint8_t* pc = cold; /* merge-only arrays: in the slab when given, else with the rest */
     if (h_ext) M.H = h_ext;
     else { M.H = (HT*)p; p += (size_t)hc * sizeof(HT); }
     if (d_ext) M.dirs = d_ext;
@@ -105,16 +112,16 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.enext = (uint16_t*)p; p += 2 * ec;
     M.rpred0 = (uint16_t*)p; p += 2 * nc;
     M.ncov = (uint16_t*)p; p += 2 * nc;
-    M.nal = (uint16_t*)p; p += 6 * nc;
+    if (pc) { M.nal = (uint16_t*)pc; pc += 6 * nc; } else { M.nal = (uint16_t*)p; p += 6 * nc; }
     M.in_head = (uint16_t*)p; p += 2 * nc;
-    M.in_tail = (uint16_t*)p; p += 2 * nc;
+    if (pc) { M.in_tail = (uint16_t*)pc; pc += 2 * nc; } else { M.in_tail = (uint16_t*)p; p += 2 * nc; }
     M.indeg = (uint16_t*)p; p += 2 * nc;
     M.r2n = (uint16_t*)p; p += 2 * nc;
     M.n2r = (uint16_t*)p; p += 2 * nc;
-    M.rtmp = (uint16_t*)p; p += 2 * nc;
+    if (pc) { M.rtmp = (uint16_t*)pc; pc += 2 * nc; } else { M.rtmp = (uint16_t*)p; p += 2 * nc; }
     M.seqrank = (uint16_t*)p; p += 2 * (lc + 1);
-    M.pcur = (uint16_t*)p; p += 2 * (lc + 1);
-    M.pat = (uint16_t*)p; p += 2 * (lc + 1);
+    if (pc) { M.pcur = (uint16_t*)pc; pc += 2 * (lc + 1); M.pat = (uint16_t*)pc; pc += 2 * (lc + 1); }
+    else { M.pcur = (uint16_t*)p; p += 2 * (lc + 1); M.pat = (uint16_t*)p; p += 2 * (lc + 1); }
     M.nbase = p; p += nc;
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
@@ -877,8 +884,9 @@ __global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, Dev
     uint8_t* my_slab = sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER];
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
-    constexpr uint32_t slab = CW_POA_GRAPH_BYTES(NC, EC, LC);
-    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab);
+    uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
+    constexpr uint32_t slab = CW_POA_HOT_BYTES(NC, EC, LC);
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold);
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
