@@ -336,9 +336,16 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t wd = w_beg + r;
                 const uint32_t v = tab[wd];
                 if (v == 0) continue;
-                for (uint32_t q = 0; q < keys_per_word; ++q) {
+                /* nibbles that can be solid, all eight at once: (nibble + 16 - t) carries into bit 4 of its byte iff nibble >= t,
+                   t = min(solid, 15) (a saturated nibble is decided by its exact count below) */
+                const uint32_t add = (16u - (prm.solid < 15u ? prm.solid : 15u)) * 0x01010101u;
+                uint32_t cand = ((((v & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 4) | (((((v >> 4) & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 3);
+                if (keys_per_word < 8) cand &= (1u << (8 * ((keys_per_word + 1) / 2))) - 1u;
+                while (cand) {
+                    const uint32_t bpos = (uint32_t)__ffs((int)cand) - 1u; /* bit 8*byte + (odd nibble) : ascending = key order */
+                    cand &= cand - 1u;
+                    const uint32_t q = (bpos >> 3) * 2u + (bpos & 1u);
                     const uint32_t nib = (v >> (4 * q)) & 15u;
-                    if (!nib) continue;
                     const uint32_t key = wd * 8 + q;
                     uint32_t c = nib;
                     if (nib == 15u) {

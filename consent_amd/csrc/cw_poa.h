@@ -877,7 +877,8 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES) cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
+__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 4 : 1) /* M1: four waves per SIMD, i.e. at most 128 VGPRs */
+cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = blockIdx.x * WAVES + wave; /* the grid never exceeds the slots */
