@@ -19,7 +19,8 @@
 #define CW_FIN_CB 3072        /* string capacity per buffer              */
 #define CW_FIN_VIS_WORDS 1024 /* visited bitmap: up to 32768 solid k-mers */
 #define CW_FIN_FRAMES 56
-#define CW_FIN_SLAB (3 * CW_FIN_CB + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256)
+#define CW_FIN_SKEYS 1024     /* solid keys staged in LDS (every lookup of the polish is a binary search in them) */
+#define CW_FIN_SLAB (3 * CW_FIN_CB + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256 + 4 * CW_FIN_SKEYS + 16)
 
 struct FinOut {
     char* cons;
@@ -34,6 +35,8 @@ struct FinOut {
 struct FinCtx {
     const uint32_t* skey; /* window's solid keys (ascending) */
     const uint32_t* scnt;
+    const uint16_t* scnt16; /* counts staged in LDS (all <= 65535), or NULL */
+    bool staged;            /* skey points into LDS and holds at most CW_FIN_SKEYS keys */
     uint32_t n_solid;
     uint32_t k, solid, kmask;
     /* pile, for exact recounts */
@@ -63,10 +66,34 @@ __device__ __forceinline__ int fin_find(const FinCtx& c, uint32_t key) {
     return -1;
 }
 
+/* Four keys at once when the table is staged in LDS (n_solid <= CW_FIN_SKEYS, 16-byte aligned): lanes 16g..16g+15 look up key_g.
+ * Two dependent LDS reads instead of the ten of a binary search: 16 pivots (every 64th key) pick the 64-key bucket, then every lane
+ * of the group compares four consecutive keys of it.  Returns the index for the lane's group, or -1. */
+__device__ __forceinline__ int fin_find4(const FinCtx& c, uint32_t key_g, int lane) {
+    const int g = lane >> 4, l = lane & 15;
+    const uint32_t n = c.n_solid;
+    const uint32_t pv = (uint32_t)l * 64u;
+    const bool ge = pv < n && key_g >= c.skey[pv];
+    const uint32_t bits = (uint32_t)(__ballot(ge) >> (16 * g)) & 0xFFFFu;
+    int mine = -1;
+    if (bits) {
+        const uint32_t base = ((uint32_t)__popc(bits) - 1u) * 64u + (uint32_t)l * 4u;
+        if (base < n) {
+            const uint4 kk = *(const uint4*)(c.skey + base); /* the staging area is padded to a multiple of four words */
+            mine = kk.x == key_g ? (int)base : (base + 1 < n && kk.y == key_g) ? (int)base + 1 : (base + 2 < n && kk.z == key_g) ? (int)base + 2
+                   : (base + 3 < n && kk.w == key_g) ? (int)base + 3 : -1;
+        }
+    }
+    const uint32_t hit = (uint32_t)(__ballot(mine >= 0) >> (16 * g)) & 0xFFFFu;
+    const int src = hit ? 16 * g + (__ffs((int)hit) - 1) : lane;
+    const int got = __shfl(mine, src);
+    return hit ? got : -1;
+}
+
 /* exact pile-wide count of any k-mer (wave-wide; uniform result) */
 __device__ uint32_t fin_count_exact(const FinCtx& c, uint32_t key, int lane) {
     int idx = fin_find(c, key);
-    if (idx >= 0) return c.scnt[idx];
+    if (idx >= 0) return c.scnt16 ? (uint32_t)c.scnt16[idx] : c.scnt[idx];
     uint32_t n = 0;
     for (uint32_t s = 0; s < c.N; ++s) {
         const uint32_t len = c.b->seq_len[c.s0 + s];
@@ -85,13 +112,23 @@ __device__ uint32_t fin_count_exact(const FinCtx& c, uint32_t key, int lane) {
  */
 __device__ int fin_neighbours(const FinCtx& c, uint32_t key, int left, uint32_t* nbk, uint32_t* nbi, int lane) {
     uint32_t cand = 0;
-    if (lane < 4) {
-        if (!left) cand = ((key << 2) & c.kmask) | (uint32_t)lane;
-        else cand = ((uint32_t)(3 - lane) << (2 * (c.k - 1))) | (key >> 2);
-    }
     int idx = -1;
     uint32_t cnt = 0;
-    if (lane < 4) { idx = fin_find(c, cand); if (idx >= 0) cnt = c.scnt[idx]; }
+    if (c.staged) {
+        /* candidate g is looked up by lanes 16g..16g+15; lanes 0..3 then pick up result g */
+        const uint32_t gq = (uint32_t)(lane >> 4);
+        const uint32_t cg = !left ? (((key << 2) & c.kmask) | gq) : (((3u - gq) << (2 * (c.k - 1))) | (key >> 2));
+        const int ig = fin_find4(c, cg, lane);
+        idx = __shfl(ig, (lane & 3) * 16);
+        cand = (uint32_t)__shfl((int)cg, (lane & 3) * 16);
+        if (lane < 4 && idx >= 0) cnt = c.scnt16 ? (uint32_t)c.scnt16[idx] : c.scnt[idx];
+        if (lane >= 4) idx = -1;
+    } else if (lane < 4) {
+        if (!left) cand = ((key << 2) & c.kmask) | (uint32_t)lane;
+        else cand = ((uint32_t)(3 - lane) << (2 * (c.k - 1))) | (key >> 2);
+        idx = fin_find(c, cand);
+        if (idx >= 0) cnt = c.scnt[idx];
+    }
     const bool ok = lane < 4 && idx >= 0; /* table holds exactly the k-mers with count >= solid */
     const unsigned long long bal = __ballot(ok);
     int rank = 0;
@@ -377,6 +414,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
     M.f_dist = M.f_meta + CW_FIN_FRAMES;
     M.f_key = M.f_dist + CW_FIN_FRAMES;
     M.tmp = M.f_key + CW_FIN_FRAMES; /* 64 words */
+    uint32_t* skey_lds = M.tmp + 64; /* CW_FIN_SKEYS words */
 
     for (;;) {
         uint32_t w = 0;
@@ -424,6 +462,22 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                 if ((uint32_t)len >= prm.k) { /* correctionMSA.cpp:43-46 */
                     FinCtx c;
                     c.skey = sc.solid_key + wi.solid_base; c.scnt = sc.solid_cnt + wi.solid_base; c.n_solid = wi.n_solid;
+                    c.scnt16 = nullptr; c.staged = false;
+                    if (wi.n_solid <= CW_FIN_SKEYS) { /* the usual case: searches run at LDS latency */
+                        /* the visited bitmap needs 32 words for that many k-mers: the counts go behind it, as u16 when they all fit */
+                        uint16_t* cnt_lds = (uint16_t*)(M.vis + 64);
+                        bool big = false;
+                        for (uint32_t q = lane; q < wi.n_solid; q += 64) {
+                            skey_lds[q] = c.skey[q];
+                            const uint32_t cv = c.scnt[q];
+                            big = big || cv > 0xFFFFu;
+                            cnt_lds[q] = (uint16_t)cv;
+                        }
+                        if (lane < 4) skey_lds[wi.n_solid + lane] = 0xFFFFFFFFu; /* padding read by the 4-key compares (never matched: index >= n) */
+                        c.skey = skey_lds; c.staged = true;
+                        if (__ballot(big) == 0ull) c.scnt16 = cnt_lds;
+                        cw_wave_sync();
+                    }
                     c.k = prm.k; c.solid = prm.solid; c.kmask = (prm.k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * prm.k)) - 1u);
                     c.b = &b; c.s0 = s0; c.N = wi.n_seqs;
                     /* weightConsensus: case[p] = solid(k-mer at min(p, len-k)) */
