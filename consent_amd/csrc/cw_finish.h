@@ -91,9 +91,14 @@ __device__ __forceinline__ int fin_find4(const FinCtx& c, uint32_t key_g, int la
 }
 
 /* exact pile-wide count of any k-mer (wave-wide; uniform result) */
+__device__ uint32_t fin_count_scan(const FinCtx& c, uint32_t key, int lane);
 __device__ uint32_t fin_count_exact(const FinCtx& c, uint32_t key, int lane) {
     int idx = fin_find(c, key);
     if (idx >= 0) return c.scnt16 ? (uint32_t)c.scnt16[idx] : c.scnt[idx];
+    return fin_count_scan(c, key, lane);
+}
+/* a k-mer below the solidity threshold is not in the table: count it in the pile */
+__device__ uint32_t fin_count_scan(const FinCtx& c, uint32_t key, int lane) {
     uint32_t n = 0;
     for (uint32_t s = 0; s < c.N; ++s) {
         const uint32_t len = c.b->seq_len[c.s0 + s];
@@ -304,7 +309,19 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
             uint32_t ks[4], kd[4];
             for (int q = 0; q < 4; ++q) { ks[q] = fin_key_at(M.s, (uint32_t)src_beg + q, k); kd[q] = fin_key_at(M.s, (uint32_t)dst_beg + q, k); }
             uint32_t cs[4], cd[4];
-            for (int q = 0; q < 4; ++q) { cs[q] = fin_count_exact(c, ks[q], lane); cd[q] = fin_count_exact(c, kd[q], lane); }
+            if (c.staged) { /* the eight table lookups as two grouped ones (lanes 16g..16g+15 take k-mer g of each zone) */
+                const int g = lane >> 4;
+                const uint32_t ksg = g == 0 ? ks[0] : g == 1 ? ks[1] : g == 2 ? ks[2] : ks[3];
+                const uint32_t kdg = g == 0 ? kd[0] : g == 1 ? kd[1] : g == 2 ? kd[2] : kd[3];
+                const int is = fin_find4(c, ksg, lane), id = fin_find4(c, kdg, lane);
+                for (int q = 0; q < 4; ++q) {
+                    const int iq = __builtin_amdgcn_readlane(is, q * 16), jq = __builtin_amdgcn_readlane(id, q * 16);
+                    cs[q] = iq >= 0 ? (c.scnt16 ? (uint32_t)c.scnt16[iq] : c.scnt[iq]) : fin_count_scan(c, ks[q], lane);
+                    cd[q] = jq >= 0 ? (c.scnt16 ? (uint32_t)c.scnt16[jq] : c.scnt[jq]) : fin_count_scan(c, kd[q], lane);
+                }
+            } else {
+                for (int q = 0; q < 4; ++q) { cs[q] = fin_count_exact(c, ks[q], lane); cd[q] = fin_count_exact(c, kd[q], lane); }
+            }
             if (lane < 16) {
                 uint32_t sk = 0, dk = 0, sc_ = 0, dc_ = 0;
                 int so = 0, dof = 0;
