@@ -201,8 +201,8 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     const uint32_t est = (e_mx * 17u + 9u) / 10u;
                     const uint32_t tier = !poa ? 0xFFu
                                           : ((est + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est <= (uint32_t)CW_POA_NC) ? 0u
-                                          : (est <= (uint32_t)CW_POAM1_NC && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
-                                          : (est <= (uint32_t)CW_POAM2_NC && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
+                                          : (est <= (uint32_t)CW_POAM1_ROUTE && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
+                                          : (est <= (uint32_t)CW_POAM2_ROUTE && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long pm = __ballot(poa);

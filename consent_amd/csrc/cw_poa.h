@@ -40,10 +40,12 @@
 #define CW_POAM1_EC 640
 #define CW_POAM1_LC 255
 #define CW_POAM1_WAVES 4
+#define CW_POAM1_ROUTE 208 /* tasks expected to grow beyond this many nodes go to M2 at once (fewer late hand-overs) */
 #define CW_POAM2_NC 512
 #define CW_POAM2_EC 1280
 #define CW_POAM2_LC 511
 #define CW_POAM2_WAVES 2
+#define CW_POAM2_ROUTE CW_POAM2_NC
 #define CW_POAL_NC 1536
 #define CW_POAL_EC 4096
 #define CW_POAL_LC 1023
