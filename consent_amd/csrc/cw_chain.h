@@ -199,8 +199,11 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     /* route by the expected graph size: the graph has at least max_len nodes once its longest member is in
                        and typically ends at 1.4-1.6x that; a task that still outgrows its tier is redone in the next one */
                     const uint32_t est = (e_mx * 17u + 9u) / 10u;
+                    /* deep piles grow wider graphs: the smallest tier is only worth trying when the graph will very likely stay in it
+                       (a task that outgrows tier S is redone in tier L, the scarcest one) */
+                    const uint32_t est_s = (e_mx * (15u + e_n / 5u) + 9u) / 10u;
                     const uint32_t tier = !poa ? 0xFFu
-                                          : ((est + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est <= (uint32_t)CW_POA_NC) ? 0u
+                                          : ((est_s + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est_s <= (uint32_t)CW_POA_NC) ? 0u
                                           : (est <= (uint32_t)CW_POAM1_ROUTE && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
                                           : (est <= (uint32_t)CW_POAM2_ROUTE && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;

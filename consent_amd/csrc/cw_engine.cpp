@@ -223,7 +223,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
-    sc.producer_wgs = (uint32_t)cus * 2 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
+    sc.producer_wgs = (uint32_t)cus * 3 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
     for (int t = 1; t < CW_TIERS; ++t) {
         sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
         sc.over_list[t] = (uint32_t*)(base + p.over[t]);
@@ -278,7 +278,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     cw_poa_slab_kernel<M1_ARGS, 0><<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
     sid = stage_begin(e, st, "poa");
-    cw_poa_kernel<<<cus * 2, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
+    cw_poa_kernel<<<cus * 3, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 12.3 KiB per wave: three work-groups per CU */
     stage_end(e, st, sid);
     for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */

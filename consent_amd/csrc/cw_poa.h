@@ -28,11 +28,11 @@
 #include "cw_device.h"
 
 /* tier S: graph and DP matrix in LDS (per wave) */
-#define CW_POA_NC 160   /* nodes            */
-#define CW_POA_EC 448   /* edges            */
-#define CW_POA_LC 255   /* member length    */
-#define CW_POA_HC 4096  /* DP cells (int16) */
-#define CW_POA_DC 160   /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
+#define CW_POA_NC 128   /* nodes            */
+#define CW_POA_EC 384   /* edges            */
+#define CW_POA_LC 127   /* member length    */
+#define CW_POA_HC 2048  /* DP cells (int16) */
+#define CW_POA_DC 96    /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
 #define CW_POA_WAVES 4
 /* tiers M1 / M2 / L: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2 / Infinity-Cache
    resident.  Direction words are off there: they cost more occupancy than they save (measured). */
