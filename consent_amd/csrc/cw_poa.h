@@ -400,7 +400,11 @@ __device__ __forceinline__ bool poa_slow_step(const PoaMem<HT>& M, const int i, 
 }
 
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
-template <typename HT, bool PK>
+/* PK: 0 = one column per lane (int32 tier G); 1 = two columns per lane in packed int16 for rows wider than 64 columns (tiers S, M1,
+   M2, whose capacities keep every score far inside int16); 2 = the same for tier L while nodes + columns <= CW_POA_PK_SPAN, i.e.
+   while |score| <= 8 * span stays clear of the packed "minus infinity" even after the per-column gap offsets are taken out. */
+#define CW_POA_PK_SPAN 2600
+template <typename HT, int PK>
 __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
                        unsigned long long (&acc)[6]) {
     unsigned long long _pt = __builtin_readcyclecounter();
@@ -435,7 +439,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             continue;
         }
         const int cols = L + 1;
-        const bool packed = PK && cols > 64;                 /* two columns per lane (int16 tiers, wide rows) */
+        const bool packed = PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN); /* two columns per lane (int16 tiers, wide rows) */
         const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
         if ((uint32_t)((n + 1) * hs) > M.h_cap) return 2;
 
@@ -471,11 +475,20 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         cw_wave_sync();
         const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
         const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
-        if constexpr (PK) {
-            if (!packed) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+        if constexpr (PK != 0) {
+            if (!packed) {
+                if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+                else if constexpr (PK == 2) { /* a very large graph in tier L: one column per lane */
+                    if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
+                    else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
+                    else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
+                    else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
+                }
+            }
             else if (cols <= 128) poa_fill_pk<1>(M, n, cols, hs, lane, use_dirs);
             else if (cols <= 256) poa_fill_pk<2>(M, n, cols, hs, lane, use_dirs);
-            else poa_fill_pk<4>(M, n, cols, hs, lane, use_dirs);
+            else if (cols <= 512) poa_fill_pk<4>(M, n, cols, hs, lane, use_dirs);
+            else if constexpr (PK == 2) poa_fill_pk<8>(M, n, cols, hs, lane, use_dirs);
         } else {
             if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
             else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
@@ -894,7 +907,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int16_t, (TIER < 3)>(M, t, b, sc, lane, acc); /* packed columns where n+len stays in int16 headroom */
+        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2)>(M, t, b, sc, lane, acc);
         if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
     };
