@@ -967,6 +967,47 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     if (PASS == 0 && TIER < 3) poa_producer_done(sc);
 }
 
+/* ---- largest tasks first ---------------------------------------------------------------------------
+ * Tiers M2 and L hold few, long tasks, and a task that outgrows M2 is redone in L: if that happens late, tier L finishes long
+ * after everything else (depth 150: the last hand-overs used to land when M1/M2 were nearly done).  One work-group per tier sorts
+ * that tier's routed list by estimated cost (members x longest member squared), largest first, so that whatever is going to
+ * outgrow its tier does so early.  Lists beyond CW_SORT_MAX entries are left as they are. */
+#define CW_SORT_MAX 16384
+__global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sort_key[];
+    const int tier = 2 + (int)blockIdx.x;
+    const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
+    if (n < 2 || n > CW_SORT_MAX) return;
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    uint32_t* list = sc.tier_list[tier];
+    for (uint32_t x = threadIdx.x; x < np2; x += 1024) {
+        unsigned long long kv = 0ull; /* padding sorts last */
+        if (x < n) {
+            const uint32_t ti = list[x];
+            const PoaTask t = sc.tasks[ti];
+            const unsigned long long cost = (unsigned long long)t.n_members * t.max_len * t.max_len + 1ull;
+            kv = ((cost > 0xFFFFFFFFull ? 0xFFFFFFFFull : cost) << 32) | (unsigned long long)(0xFFFFFFFFu - ti); /* ties: smaller task id first */
+        }
+        sort_key[x] = kv;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t x = threadIdx.x; x < np2; x += 1024) {
+                const uint32_t y = x ^ j2;
+                if (y > x) {
+                    const unsigned long long ax = sort_key[x], ay = sort_key[y];
+                    const bool desc = (x & k2) == 0;
+                    if ((ax < ay) == desc) { sort_key[x] = ay; sort_key[y] = ax; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = 0xFFFFFFFFu - (uint32_t)(sort_key[x] & 0xFFFFFFFFull);
+}
+
 /* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch b, DevScratch sc) {
     const int lane = threadIdx.x & 63;
