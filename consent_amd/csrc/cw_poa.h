@@ -904,6 +904,10 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     constexpr uint32_t slab = CW_POA_HOT_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold);
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
+    /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
+       or tier L is still running long after the others have finished (depth 150) */
+    if (TIER == 3) __builtin_amdgcn_s_setprio(3);
+    else if (TIER == 2) __builtin_amdgcn_s_setprio(1);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
