@@ -21,8 +21,8 @@
 #define CW_ST_WAVES 4
 #define CW_ST_QMAX 2048 /* consensus length */
 #define CW_ST_RMAX 2048 /* aligned slice of the read: window_size + 2*window_overlap */
-#define CW_ST_DIR_BYTES (256u << 10) /* banded traceback directions, per wave, in global memory */
-#define CW_ST_MAX_WGS 512
+#define CW_ST_DIR_BYTES (1u << 20) /* banded traceback scratch (directions, and the rows when they outgrow LDS), per wave, global */
+#define CW_ST_MAX_WGS 256
 #define CW_ST_ROWS_BYTES 4096u /* banded traceback rows: 3 x (2*band + 3) int32 -> band <= 169 */
 /* per wave: slice codes | current consensus | previous consensus | traceback rows | query codes forward, reversed */
 #define CW_ST_SLAB (CW_ST_RMAX + 2 * CW_ST_QMAX + CW_ST_ROWS_BYTES + 2 * CW_ST_QMAX)
@@ -58,6 +58,14 @@ __device__ __forceinline__ int st_code(uint8_t c) {
 __device__ __forceinline__ uint8_t st_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 __device__ __forceinline__ bool st_is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
 
+/* Ordering point for LDS *and* global traffic between the lanes of one wave: the read under construction lives in global memory
+   (gap buffer) and is written and read back by different lanes. */
+__device__ __forceinline__ void st_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 /* the read under construction: logical string = buf[0, L) + buf[cap-R, cap) */
 struct GapBuf {
     uint8_t* buf;
@@ -74,9 +82,9 @@ __device__ __forceinline__ void st_gap_to(GapBuf& g, uint32_t pos, int lane) {
             const uint32_t x = base + lane;
             uint8_t v = 0;
             if (x < n) v = g.buf[g.cap - g.R + x];
-            cw_wave_sync();
+            st_mem_sync();
             if (x < n) g.buf[g.L + x] = v;
-            cw_wave_sync();
+            st_mem_sync();
         }
         g.L += n; g.R -= n;
     } else if (pos < g.L) { /* push the end of the left part to the front of the right part; highest first (ranges may overlap) */
@@ -85,13 +93,13 @@ __device__ __forceinline__ void st_gap_to(GapBuf& g, uint32_t pos, int lane) {
             const uint32_t x = base + lane;
             uint8_t v = 0;
             if (x < n) v = g.buf[g.L - 1 - x];
-            cw_wave_sync();
+            st_mem_sync();
             if (x < n) g.buf[g.cap - g.R - 1 - x] = v;
-            cw_wave_sync();
+            st_mem_sync();
         }
         g.L -= n; g.R += n;
     }
-    cw_wave_sync();
+    st_mem_sync();
 }
 
 /* Everything that steers control flow is wave-uniform; telling the compiler so (scalar registers, scalar branches) keeps
@@ -200,31 +208,40 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
 }
 
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
-    m = st_uni(m);
-    if (m <= 512) return st_sweep_pk<4>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 1024) return st_sweep_pk<8>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    return st_sweep_pk<16>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    /* one instantiation for every query length (chunks beyond the query are skipped by a scalar branch): with 4-, 8- and 16-chunk
+       variants side by side the 8-chunk one returned garbage rows on gfx950 (ROCm 7.2 hipcc), each of them alone is correct --
+       tests/test_gpu_stitch.py::test_stitch_long_consensuses_use_the_wide_sweeps keeps an eye on it */
+    return st_sweep_pk<CW_ST_QMAX / 128>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
 }
 
 /* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
  * (lane 0 walks the band; rare: only when two overlapping windows disagree and the earlier one wins).
  * rows: int32 h_b/e_b/h_c (3*width) in LDS; dir: the direction bytes (width_d*readLen*3) in this wave's global scratch. */
 __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen, const uint8_t* read, int readLen, int score, uint8_t* rows, uint32_t rows_bytes,
-                                 int8_t* dir, uint32_t dir_bytes, unsigned* ins, unsigned* del, int lane) {
+                                 int8_t* dir_all, uint32_t dir_bytes, unsigned* ins, unsigned* del, int lane) {
     const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
     *ins = 0; *del = 0;
     refLen = st_uni(refLen); readLen = st_uni(readLen); score = st_uni(score);
     if (refLen <= 0 || readLen <= 0) return true;
     int band = abs(refLen - readLen) + 1;
-    int width_d = 0;
+    int8_t* dir_cur = dir_all;
+    int width_d = 0, stride_d = 0;
     for (;;) {
         const int width = band * 2 + 3;
         width_d = band * 2 + 1;
-        if ((size_t)width * 12 > rows_bytes || (size_t)width_d * readLen * 3 > dir_bytes) return false;
-        int* h_b = (int*)rows; int* e_b = h_b + width; int* h_c = e_b + width;
-        if (lane == 0) for (int x = 0; x < width; ++x) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
-        for (int x = lane; x < width_d * readLen * 3; x += 64) dir[x] = 0; /* cells outside the band read as "stop" */
-        cw_wave_sync();
+        /* a band wider than the matrix only ever touches refLen + 1 cells per row: store that much (the reference allocates the full
+           band; which cell holds what is unchanged) */
+        const int w_rows = width < refLen + 3 ? width : refLen + 3;
+        stride_d = width_d < refLen + 1 ? width_d : refLen + 1;
+        const size_t rows_need = (size_t)w_rows * 12, dir_need = (size_t)stride_d * readLen * 3;
+        const bool rows_in_lds = rows_need <= rows_bytes;
+        if (dir_need + (rows_in_lds ? 0 : ((rows_need + 15) & ~(size_t)15)) > dir_bytes) return false;
+        int* h_b = rows_in_lds ? (int*)rows : (int*)dir_all; int* e_b = h_b + w_rows; int* h_c = e_b + w_rows;
+        int8_t* dir = dir_all + (rows_in_lds ? 0 : ((rows_need + 15) & ~(size_t)15));
+        if (lane == 0) for (int x = 0; x < w_rows; ++x) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
+        for (int x = lane; x < stride_d * readLen * 3; x += 64) dir[x] = 0; /* cells outside the band read as "stop" */
+        dir_cur = dir;
+        st_mem_sync();
         int mx = 0;
         if (lane == 0) {
             for (int i = 0; i < readLen; ++i) {
@@ -234,7 +251,7 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
                 const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
                 int f = 0;
                 h_b[0] = e_b[0] = h_b[edge] = e_b[edge] = h_c[0] = 0;
-                int8_t* line = dir + (size_t)width_d * i * 3;
+                int8_t* line = dir + (size_t)stride_d * i * 3;
                 for (j = beg; j <= end; ++j) {
                     int x;
 #define ST_SET_U(res, ii, jj) do { x = (ii) - band; x = x > 0 ? x : 0; (res) = (jj) - x + 1; } while (0)
@@ -264,7 +281,7 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
         }
         mx = cw_lane_value(mx, 0);
         __threadfence_block();
-        cw_wave_sync();
+        st_mem_sync();
         if (mx >= score || band > refLen + readLen) break;
         band *= 2;
     }
@@ -272,7 +289,7 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
     if (lane == 0) {
         int i = readLen - 1, j = refLen - 1, state = 2;
         while (i > 0 && j >= 0) {
-            const int8_t* line = dir + (size_t)width_d * i * 3;
+            const int8_t* line = dir_cur + (size_t)stride_d * i * 3;
             int x = i - band; x = x > 0 ? x : 0; x = j - x;
             const int idx = x * 3 + state;
             if (idx < 0 || idx >= width_d * 3) break;
@@ -305,7 +322,7 @@ __device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* 
     a.ref_end = fw.col; a.query_end = fw.row;
     const int pm = fw.row + 1;
     for (int x = lane; x < pm; x += 64) qrv[x] = qfw[fw.row - x];
-    cw_wave_sync();
+    st_mem_sync();
     const StSweep bw = st_sweep_any(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
@@ -356,7 +373,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
         /* outSequence = lower-case read (:56-57), everything in the right part: the gap starts at 0 */
         for (uint32_t x = lane; x < n_fill; x += 64) g.buf[g.cap - rlen + x] = "acgt"[cw_base_at(rwords, x)];
         g.L = 0; g.R = n_fill;
-        cw_wave_sync();
+        st_mem_sync();
 
         int cur_pos = jb.win_count ? st_uni((int)a.win_pos[2 * jb.win_first]) : 0;   /* startPos = pilesPos[0].first (CONSENT-correction.cpp:47) */
         uint32_t old_end = 0, old_len = 0, old_w = 0;
@@ -377,7 +394,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                 const uint32_t* tw = a.batch.bases + a.batch.seq_word_off[ts];
                 for (uint32_t x = lane; x < clen; x += 64) cur[x] = "ACGT"[cw_base_at(tw, x)];
             }
-            cw_wave_sync();
+            st_mem_sync();
             const int al_pos = max(0, cur_pos - (int)a.window_overlap);                                    /* :83 */
             const uint32_t tot = g.len();
             int size_al;
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
             if (size_al > CW_ST_RMAX) { status = 2; break; }
             for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
-            cw_wave_sync();
+            st_mem_sync();
             const StAlign al = st_align(qfw, (int)clen, qrv, refc, size_al, lane);                   /* :90 */
             if (a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
@@ -403,9 +420,9 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                     const uint32_t x = base + lane;
                     uint8_t v = 0;
                     if (x < cl) v = cur[al.query_begin + x];
-                    cw_wave_sync();
+                    st_mem_sync();
                     if (x < cl) cur[x] = v;
-                    cw_wave_sync();
+                    st_mem_sync();
                 }
             }
             bool emptied = false;
@@ -428,7 +445,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                         if (s1 > s2) {                                                                      /* :109-119 */
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
-                            cw_wave_sync();
+                            st_mem_sync();
                             const StAlign sub = st_align(qfw, (int)overlap, qrv, refc, (int)overlap, lane);
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
@@ -441,10 +458,10 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                                 if (nl > CW_ST_QMAX) { status = 2; break; }
                                 /* build in qrv (free now), then copy back */
                                 for (uint32_t x = lane; x < nl; x += 64) qrv[x] = x < overlap ? seq1[x] : cur[cut + (x - overlap)];
-                                cw_wave_sync();
+                                st_mem_sync();
                                 for (uint32_t x = lane; x < nl; x += 64) cur[x] = qrv[x];
                                 cl = nl;
-                                cw_wave_sync();
+                                st_mem_sync();
                             } else {
                                 emptied = true;                                                             /* :117 */
                             }
@@ -460,7 +477,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                     g.L = beg;
                     for (uint32_t x = lane; x < cl; x += 64) g.buf[g.L + x] = st_upper(cur[x]);
                     g.L += cl;
-                    cw_wave_sync();
+                    st_mem_sync();
                 }
                 if (wi + 1 < jb.win_count) {                                                                /* :130-135 */
                     const long long np = (long long)cur_pos + (long long)st_uni(a.win_pos[2 * (w + 1)]) - (long long)st_uni(a.win_pos[2 * w]) - (long long)(end - beg + 1) + (long long)cl;
@@ -468,7 +485,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                     for (uint32_t x = lane; x < cl; x += 64) old[x] = cur[x];
                     old_len = cl; old_w = w; have_old = true;
                     old_end = beg + cl - 1;
-                    cw_wave_sync();
+                    st_mem_sync();
                 }
             }
         }
@@ -490,15 +507,15 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                     const uint32_t x = base + lane;
                     uint8_t v = 0;
                     if (x < flen) v = g.buf[fbeg + x];
-                    cw_wave_sync();
+                    st_mem_sync();
                     if (x < flen) g.buf[x] = v;
-                    cw_wave_sync();
+                    st_mem_sync();
                 }
             }
         }
         flen = st_uni(flen); status = st_uni(status);
         if (lane == 0) { a.out_len[ri] = flen; a.read_status[ri] = (uint8_t)status; }
-        cw_wave_sync();
+        st_mem_sync();
     }
 }
 

@@ -468,7 +468,7 @@ class Engine:
                                                    int(bool(do_trim)), t_out.data_ptr(), t_ooff.data_ptr(), t_olen.data_ptr(), t_ost.data_ptr(), None), "cw_stitch_device")
         torch.cuda.synchronize()
         out, olen, ost = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy()
-        return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode(), int(ost[i])) for i in range(len(jb))]
+        return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode("latin-1"), int(ost[i])) for i in range(len(jb))]
 
     def timings(self):
         ms = (C.c_float * 16)()

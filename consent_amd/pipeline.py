@@ -6,11 +6,15 @@ output order is the PAF order, as the reference's futures ring keeps it (:96-133
 This module only marshals buffers; it computes nothing itself and needs the HIP library and a GPU.
 """
 import ctypes as C
+import os
 import sys
 
 import numpy as np
 
 from .engine import Batch, Engine, EngineError, PafReader, Params, ReadIndex, ReadSet, Result, _check, window_positions
+
+
+_DEBUG = os.environ.get("CW_PIPE_DEBUG", "")
 
 
 class _DeviceReads:
@@ -82,6 +86,9 @@ def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=
             _check(lib, lib.cw_extract_piles_device(eng.handle, C.byref(reads_dev.struct), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), n_win, mer_size, b_wfs.data_ptr(),
                                                      b_len.data_ptr(), b_off.data_ptr(), b_bases.data_ptr(), ns.value, nw.value, C.byref(ns), C.byref(nw), None),
                    "cw_extract_piles_device")
+            if "e" in _DEBUG:
+                torch.cuda.synchronize()
+                print(f"[pipeline] extraction done: {n_win} windows, jobs {jb.tolist()[:4]}", file=sys.stderr, flush=True)
             batch = Batch(n_win, ns.value, nw.value, b_wfs.data_ptr(), b_len.data_ptr(), b_off.data_ptr(), b_bases.data_ptr())
             wl, wd = np.array(win_len, np.int64), np.array(win_depth, np.int64)
             cons_off = np.zeros(n_win + 1, np.uint64)
@@ -97,6 +104,9 @@ def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=
             res = Result(r_cons.data_ptr(), t_coff.data_ptr(), r_clen.data_ptr(), r_st.data_ptr(), r_sol.data_ptr(), t_soff.data_ptr(), r_slen.data_ptr())
             torch.cuda.synchronize()
             eng.run_device(batch, res)
+            if "c" in _DEBUG:
+                torch.cuda.synchronize()
+                print(f"[pipeline] consensus done: {n_win} windows, {ns.value} sequences", file=sys.stderr, flush=True)
             sj = np.array(stitch_jobs, np.uint32).reshape(-1, 3)
             cap = 2 * index.seq_len[sj[:, 0]].astype(np.int64) + 1024
             out_off = np.zeros(len(sj) + 1, np.uint64)
@@ -128,6 +138,8 @@ def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=
             if tpl_len != int(index.seq_len[tpl]):
                 raise EngineError(f"PAF states length {tpl_len} for {index.names[tpl]}, the read file has {int(index.seq_len[tpl])}")
             wins = window_positions(tpl_len, ov, min_support, window_size, window_overlap)
+            if not wins:
+                continue  # processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25): no output for this read
             pending.append((tpl, ov, wins))
             n_pending_windows += len(wins)
             if n_pending_windows >= windows_per_batch:

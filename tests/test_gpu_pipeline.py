@@ -1,6 +1,7 @@
 """GPU: the whole read-correction loop through the library (host feeders -> device extraction -> consensus -> re-assembly,
 consent_amd/pipeline.py) against the same loop assembled from the oracle's pieces.  FASTA text must be identical."""
 import io
+import os
 import random
 
 import numpy as np
@@ -182,3 +183,24 @@ def test_polishing_mode_contigs_as_templates(tmp_path):
         want.append((ix.names[tpl], final))
     assert got == want and len(got) == 2
     assert all(len(s) > 2000 for _, s in got)
+
+
+def test_reads_without_windows_are_not_emitted_even_untrimmed(tmp_path):
+    """processRead returns an empty result when getAlignmentWindowsPositions finds nothing (CONSENT-correction.cpp:22-25): with
+    trimming off such a read must not come back as its own lower-cased copy."""
+    fa, paf = make_dataset(tmp_path, 377473700, n_reads=24, glen=7000, rate=0.16)
+    prm = dict(min_support=3, max_support=20, window_size=500, mer_size=8, common_kmers=8, min_anchors=2, solid_thresh=2, window_overlap=20, max_msa=10)
+    got = correct_reads(fa, paf, None, do_trim=False, windows_per_batch=64, **prm)
+    want = oracle_pipeline(fa, paf, do_trim=False, **prm)
+    assert got == want and len(got) == 23
+
+
+def test_short_random_run_of_the_pipeline_fuzzer(monkeypatch, capsys):
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_pipeline
+
+    monkeypatch.setattr(sys, "argv", ["fuzz_pipeline.py", "25", "99"])
+    assert fuzz_pipeline.main() == 0
+    assert "0 differences" in capsys.readouterr().out

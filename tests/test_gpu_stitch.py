@@ -146,6 +146,32 @@ def test_stitch_other_window_geometry_and_k():
     run_case(make_reads(107, 3, 16, rate=0.15), window_size=700, window_overlap=80, prm=ca.Params(11, 3, 6, 2, 150))
 
 
+def test_stitch_long_consensuses_use_the_wide_sweeps():
+    """Consensuses of 600-1024 and of more than 1024 bases (junk around the true window sequence): the 8- and 16-chunk sweeps."""
+    rng = random.Random(9)
+
+    rep = 0
+
+    def mutate(res, piles):
+        for w in range(len(piles)):
+            o, n = int(res.cons_off[w]), int(res.cons_len[w])
+            cap = int(res.cons_off[w + 1]) - o
+            extra = [0, 150, 600, 700][w % 4]
+            if n + extra > cap or extra == 0:
+                continue
+            s = res.cons[o : o + n].tobytes()
+            left = [extra // 2, extra, 0][rep % 3]  # the true part in the middle, at the far end, at the start
+            junk_l = "".join(rng.choice("ACGT") for _ in range(left)).encode()
+            junk_r = "".join(rng.choice("ACGT") for _ in range(extra - left)).encode()
+            t = junk_l + s + junk_r
+            res.cons[o : o + len(t)] = np.frombuffer(t, np.uint8)
+            res.cons_len[w] = len(t)
+
+    for rep in range(6):
+        run_case(make_reads(109 + rep, 5, 14), mutate=mutate)
+    assert rep == 5
+
+
 def test_stitch_many_reads_in_one_launch():
     got, n_up = run_case(make_reads(108, 40, 10, lo=600, hi=1800))
     assert len(got) == 40 and n_up > 0

@@ -1,0 +1,49 @@
+"""Randomised end-to-end differential test on the GPU box: consent_amd.pipeline.correct_reads vs the same loop assembled from the
+oracle (tests/test_gpu_pipeline.py::oracle_pipeline) on random small data sets and parameters.  Exit code 1 on any difference."""
+import os
+import pathlib
+import random
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from consent_amd.pipeline import correct_reads  # noqa: E402
+from test_gpu_pipeline import make_dataset, oracle_pipeline  # noqa: E402
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    t_end = time.time() + seconds
+    n = bad = n_cap = 0
+    while time.time() < t_end:
+        d = pathlib.Path(tempfile.mkdtemp())
+        seed = rng.getrandbits(30)
+        rate = rng.choice([0.03, 0.08, 0.12, 0.12, 0.16])
+        fa, paf = make_dataset(d, seed, n_reads=rng.choice([12, 24, 36]), glen=rng.choice([4000, 7000]), rate=rate)
+        prm = dict(min_support=rng.choice([2, 3, 4]), max_support=rng.choice([5, 20, 1000]), window_size=rng.choice([300, 500, 500, 700]),
+                   mer_size=rng.choice([7, 8, 9, 9, 10]), common_kmers=rng.choice([4, 8]), min_anchors=rng.choice([2, 10]),
+                   solid_thresh=rng.choice([2, 4]), window_overlap=rng.choice([20, 50, 80]), max_msa=rng.choice([10, 50, 150]))
+        trim = rng.random() < 0.7
+        wpb = rng.choice([1, 64, 100000])
+        print(f"next: seed={seed} rate={rate} trim={trim} wpb={wpb} {prm}", flush=True)
+        try:
+            got = correct_reads(fa, paf, None, do_trim=trim, windows_per_batch=wpb, **prm)
+        except Exception as ex:  # a documented capacity is not a wrong answer, but worth a look
+            print(f"   -> {type(ex).__name__}: {ex}", flush=True)
+            n_cap += 1
+            continue
+        want = oracle_pipeline(fa, paf, do_trim=trim, **prm)
+        ok = got == want
+        n += 1
+        bad += 0 if ok else 1
+        print(f"seed={seed} rate={rate} trim={trim} {prm} reads_out={len(got)} {'ok' if ok else 'DIFF'}", flush=True)
+    print(f"{n} data sets, {bad} differences, {n_cap} stopped by a capacity")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
