@@ -29,12 +29,14 @@ class _DeviceReads:
 
 def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=1000, window_size=500, mer_size=9, common_kmers=8,
                   min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150, do_trim=True, proof_path=None, windows_per_batch=8192,
-                  device=0):
+                  device=0, on_capacity="raise"):
     """Corrects every read that has a pile in `paf_path`; writes FASTA (">name\\nsequence\\n", upper case = corrected) to `out`
     (a text file object; None = collect) and returns the list of (name, sequence) in PAF order.  Reads whose corrected
     sequence is empty -- no window, or dropped by the 10 % rule -- are skipped, as CONSENT-correction.cpp:101-103 does.
     With `proof_path` (assembly polishing, or correction against proof reads) that file is indexed into the same read set and the
-    result is neither trimmed nor dropped (CONSENT-correction.cpp:69-73, CONSENT-polishing.cpp:112-116)."""
+    result is neither trimmed nor dropped (CONSENT-correction.cpp:69-73, CONSENT-polishing.cpp:112-116).
+    `on_capacity`: a read whose re-assembly (or one of whose windows) exceeded a documented capacity of the engine either stops the run
+    ("raise", the default: nothing is silently different from the reference) or is left out of the output and reported on stderr ("skip")."""
     import torch
 
     dev = torch.device("cuda", device)
@@ -121,10 +123,18 @@ def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=
                    "cw_stitch_device")
             torch.cuda.synchronize()
             h_out, h_len, h_st, h_wst = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy(), r_st.cpu().numpy()
-            if (h_wst == 2).any() or (h_st == 2).any():
-                raise EngineError(f"capacity exceeded: {int((h_wst == 2).sum())} windows, {int((h_st == 2).sum())} reads")
+            over_reads = set(int(i) for i in np.nonzero(h_st == 2)[0])
+            for i in range(len(sj)):  # a window without a consensus taints its read
+                if (h_wst[int(sj[i, 1]) : int(sj[i, 1]) + int(sj[i, 2])] == 2).any():
+                    over_reads.add(i)
+            if over_reads:
+                names = ", ".join(index.names[int(sj[i, 0])] for i in sorted(over_reads))
+                if on_capacity != "skip":
+                    raise EngineError(f"capacity exceeded: {int((h_wst == 2).sum())} windows, {int((h_st == 2).sum())} reads ({names})")
+                print(f"[consent_amd] left out (engine capacity): {names}", file=sys.stderr)
             for i in range(len(sj)):
-                out_strings[i] = h_out[int(out_off[i]) : int(out_off[i]) + int(h_len[i])].tobytes().decode()
+                if i not in over_reads:
+                    out_strings[i] = h_out[int(out_off[i]) : int(out_off[i]) + int(h_len[i])].tobytes().decode()
         for (tpl, _, _), s in zip(piles, out_strings):
             if s:
                 results.append((index.names[tpl], s))
