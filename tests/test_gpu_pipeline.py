@@ -129,6 +129,25 @@ def test_other_parameters_and_max_support_cut(tmp_path):
     assert got == want and len(got) > 5
 
 
+def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, monkeypatch, capsys):
+    """With the banded-traceback scratch shrunk some reads cannot be re-assembled: the default raises, "skip" leaves exactly those
+    out (named on stderr) and every other read is still identical."""
+    fa, paf = make_dataset(tmp_path, 35, n_reads=24)
+    prm = dict(PRM, do_trim=False)
+    full = correct_reads(fa, paf, None, **prm)
+    monkeypatch.setenv("CW_STITCH_DIR_BYTES", "64")
+    with pytest.raises(ca.EngineError, match="capacity"):
+        correct_reads(fa, paf, None, **prm)
+    part = correct_reads(fa, paf, None, on_capacity="skip", **prm)
+    err = capsys.readouterr().err
+    assert 0 < len(part) < len(full)
+    fd = dict(full)
+    for n, s in part:
+        assert fd[n] == s
+    for n in set(fd) - set(n for n, _ in part):
+        assert n in err
+
+
 def test_polishing_mode_contigs_as_templates(tmp_path):
     """CONSENT-polishing: the templates come from a second file (-R), nothing is trimmed or dropped (CONSENT-polishing.cpp:112-116)."""
     rng = random.Random(34)
