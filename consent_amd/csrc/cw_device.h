@@ -153,14 +153,26 @@ __device__ __forceinline__ int cw_wave_sum(int v) {
  * With bound_ctrl = false a lane without a source keeps `old`, which is the identity of the reduction. */
 #define CW_DPP(old, src, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xF, false)
 
-/* inclusive prefix max over the 64 lanes: 4 row shifts + 2 row broadcasts, all VALU (no LDS crossbar) */
+/* inclusive prefix max over the 64 lanes: 4 row shifts + 2 row broadcasts, all VALU (no LDS crossbar).  The fill value of the
+   shifts is the identity of the operation (INT_MIN / 0), which lets the compiler fold each shift into its max: one v_max_*_dpp per
+   step instead of move + shift + max */
 __device__ __forceinline__ int cw_wave_scan_max(int v) {
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x111, 0xF));
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x112, 0xF));
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x114, 0xF));
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x118, 0xF));
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x142, 0xA));
-    v = max(v, CW_DPP(CW_NEG * 2, v, 0x143, 0xC));
+    const int I = (int)0x80000000;
+    v = max(v, CW_DPP(I, v, 0x111, 0xF));
+    v = max(v, CW_DPP(I, v, 0x112, 0xF));
+    v = max(v, CW_DPP(I, v, 0x114, 0xF));
+    v = max(v, CW_DPP(I, v, 0x118, 0xF));
+    v = max(v, CW_DPP(I, v, 0x142, 0xA));
+    v = max(v, CW_DPP(I, v, 0x143, 0xC));
+    return v;
+}
+__device__ __forceinline__ unsigned cw_wave_scan_max_u32(unsigned v) {
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x111, 0xF));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x112, 0xF));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x114, 0xF));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x118, 0xF));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x142, 0xA));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x143, 0xC));
     return v;
 }
 /* inclusive prefix sum over the 64 lanes (same DPP ladder, identity 0) */

@@ -227,6 +227,14 @@ __device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(
 __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (cw_s2)(__builtin_bit_cast(cw_s2, a) - __builtin_bit_cast(cw_s2, b))); }
 __device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_s2, a), __builtin_bit_cast(cw_s2, b))); }
 __device__ __forceinline__ int pk_make(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
+__device__ __forceinline__ int pk_splat_lo(int a) { return __builtin_amdgcn_perm(a, a, 0x05040504); } /* (lo, lo) */
+/* x = (base codes of two columns) ^ (the node's base in both halves): MATCH where a half is zero, MISMATCH elsewhere */
+__device__ __forceinline__ int pk_score(int x) {
+    typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));
+    const cw_u2 m = __builtin_elementwise_min(__builtin_bit_cast(cw_u2, x), (cw_u2)(1)); /* 0 = match, 1 = mismatch */
+    const cw_s2 r = __builtin_bit_cast(cw_s2, m) * (cw_s2)(CW_POA_MISMATCH - CW_POA_MATCH) + (cw_s2)(CW_POA_MATCH);
+    return __builtin_bit_cast(int, r);
+}
 #define CW_NEG16 (-30000)
 #define CW_NEGPK ((int)0x8AD08AD0) /* (CW_NEG16, CW_NEG16) */
 
@@ -261,11 +269,11 @@ __device__ __forceinline__ int poa_dir_code(const unsigned long long* dirs, int 
 template <int NCH2>
 __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int n, const int cols, const int hs, const int lane,
                                             const bool use_dirs) {
-    const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
+    const int G = CW_POA_GAP;
     const int GPK = pk_make(G, G);
     const int nch = (cols + 127) >> 7;
     constexpr int RC = NCH2 <= 2 ? 3 : NCH2 <= 4 ? 2 : 1; /* rows kept in registers, rc_[0] = the previous one (see poa_fill) */
-    int rc_[RC][NCH2], jg[NCH2], amask[NCH2], sc_[NCH2][4];
+    int rc_[RC][NCH2], jg[NCH2], amask[NCH2], qpk[NCH2];
     int* Hw = (int*)M.H;
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
@@ -275,8 +283,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         for (int k = 0; k < RC; ++k) rc_[k][c] = jg[c]; /* row 0 */
         amask[c] = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
         const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) sc_[c][bb] = pk_make(q0 == bb ? MS : XS, q1 == bb ? MS : XS);
+        qpk[c] = pk_make(q0, q1); /* base codes of the lane's two columns (0xFFFF: none, never equal to a node's base) */
     }
     uint32_t meta_n = M.rmeta[0];
     uint32_t pr0_n = M.rpred0[0];
@@ -286,9 +293,13 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
         if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-        int v[NCH2], dgv[NCH2], upv[NCH2];
+        int v[NCH2], dgv[NCH2], upv[NCH2], srow[NCH2];
+        const int bpk = base * 0x00010001;
 #pragma unroll
-        for (int c = 0; c < NCH2; ++c) { v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK; }
+        for (int c = 0; c < NCH2; ++c) {
+            v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK;
+            srow[c] = pk_score(qpk[c] ^ bpk); /* the row's substitution scores, branch-free: (match ? MS : XS) per half */
+        }
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
             int up[NCH2];
@@ -314,23 +325,23 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
                 const int sh = CW_DPP(carry_in, up[c], 0x138, 0xF);       /* lane l-1's pair; lane 0: last pair of the chunk before */
                 carry_in = cw_lane_value(up[c], 63);
                 const int dg = __builtin_amdgcn_alignbit(up[c], sh, 16);   /* (col 2l-1, col 2l) of the row above */
-                const int s = base == 0 ? sc_[c][0] : base == 1 ? sc_[c][1] : base == 2 ? sc_[c][2] : sc_[c][3];
-                dgv[c] = pk_add(dg, s); upv[c] = pk_add(up[c], GPK);
+                dgv[c] = pk_add(dg, srow[c]); upv[c] = pk_add(up[c], GPK);
                 v[c] = pk_max(v[c], pk_max(dgv[c], upv[c]));
             }
         }
-        int carry = CW_NEGPK;
+        unsigned carry = 0u; /* biased (value + 32768): 0 is "nothing yet" */
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
             int w = pk_sub(v[c], jg[c]);
             w = (w & amask[c]) | (CW_NEGPK & ~amask[c]);
             w = pk_max(w, (w << 16) | 0x8AD0);                                   /* odd column sees the even one of its lane */
-            const int tot = __builtin_amdgcn_perm(w, w, 0x07060706);             /* (hi, hi): the lane's running max */
-            const int inc = pk_wave_scan_max(tot);
-            int ex = CW_DPP(carry, inc, 0x138, 0xF);                              /* exclusive: lanes before this one (+ chunks before) */
-            ex = pk_max(ex, carry);
-            w = pk_max(w, ex);
-            carry = cw_lane_value(pk_max(inc, carry), 63);
+            /* the lane's running max (its high half) as a biased unsigned number: the prefix max over the lanes is then six fused
+               v_max_u32_dpp (VOP3P has no DPP form, and 0 is both the fill value of a shift and the identity of the max) */
+            const unsigned inc = cw_wave_scan_max_u32(((unsigned)w >> 16) ^ 0x8000u);
+            unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x138, 0xF);              /* exclusive: lanes before this one ... */
+            if (c > 0) ex = max(ex, carry);                                        /* ... and the chunks before */
+            w = pk_max(w, pk_splat_lo((int)(ex ^ 0x8000u)));
+            if (c + 1 < NCH2) carry = max(carry, (unsigned)cw_lane_value((int)inc, 63));
             const int nv = pk_add(w, jg[c]);
 #pragma unroll
             for (int k = RC - 1; k > 0; --k) rc_[k][c] = rc_[k - 1][c];
@@ -897,12 +908,15 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = blockIdx.x * WAVES + wave; /* the grid never exceeds the slots */
-    uint8_t* my_slab = sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER];
+    /* the slab is global memory: say so, or every access to the DP matrix is a flat_* instruction (both wait counters, aperture check) */
+    typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
+    uint8_t* my_slab = (uint8_t*)(cw_gptr)(sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER]);
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
     constexpr uint32_t slab = CW_POA_HOT_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold);
+    M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */

@@ -118,6 +118,14 @@ struct StSweep { int score, col, row; };
  * holding it, the smallest position among those.  A reverse sweep stops at the first column holding `terminate` (-1: never).
  * NCH2 = chunks of 128 query positions.
  */
+/* x = (query letters of two positions) ^ (the reference letter in both halves): +MATCH where a half is zero, -MISMATCH elsewhere */
+__device__ __forceinline__ int st_score(int x) {
+    typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
+    const st_u2 m = __builtin_elementwise_min(__builtin_bit_cast(st_u2, x), (st_u2)(1));
+    const cw_s2 r = __builtin_bit_cast(cw_s2, m) * (cw_s2)(-CW_SSW_MISMATCH - CW_SSW_MATCH) + (cw_s2)(CW_SSW_MATCH);
+    return __builtin_bit_cast(int, r);
+}
+
 template <int NCH2>
 __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate,
                                                int lane) {
@@ -125,23 +133,23 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), FADJ = pk_make(GE - GO, GE - GO);
     m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
     const int TERMPK = pk_make(terminate, terminate);
-    int hprev[NCH2], ee[NCH2], jg[NCH2], amask[NCH2], scq[NCH2][4], bestv[NCH2], bce[NCH2], bco[NCH2];
+    int hprev[NCH2], ee[NCH2], jg[NCH2], amask[NCH2], qpk[NCH2], qok[NCH2], bestv[NCH2], bce[NCH2], bco[NCH2];
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
         const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
         jg[c] = pk_make(j0 * GE, j1 * GE);
         amask[c] = (j0 < m ? 0xFFFF : 0) | (j1 < m ? (int)0xFFFF0000 : 0);
         const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-            scq[c][bb] = pk_make(q0 == 4 ? 0 : (q0 == bb ? CW_SSW_MATCH : -CW_SSW_MISMATCH), q1 == 4 ? 0 : (q1 == bb ? CW_SSW_MATCH : -CW_SSW_MISMATCH));
+        qpk[c] = pk_make(q0, q1);
+        qok[c] = (q0 < 4 ? 0xFFFF : 0) | (q1 < 4 ? (int)0xFFFF0000 : 0);
         hprev[c] = 0; ee[c] = 0; bestv[c] = 0; bce[c] = -1; bco[c] = -1;
     }
     int hit_col = -1;
     for (int i = r_first; i != r_last_excl; i += step) {
         const int rc = st_uni((int)r[i]);
         int carry_pair = 0;      /* H of the previous column at rows (.., 128c - 1) */
-        int carry_f = CW_NEGPK;  /* running max of h'[t] + t*GE over the rows of this column so far, in both halves */
+        unsigned carry_f = (unsigned)(CW_NEG16 + 32768); /* running max of h'[t] + t*GE over the rows of this column so far (biased by 32768) */
+        const int rcpk = rc * 0x00010001, rc_ok = rc <= 3 ? -1 : 0;
         unsigned long long hit = 0ull;
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
@@ -152,16 +160,16 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
                 const int sh = CW_DPP(carry_pair, hp_, 0x138, 0xF);
                 carry_pair = cw_lane_value(hp_, 63);
                 const int dg = __builtin_amdgcn_alignbit(hp_, sh, 16);          /* rows (2l-1, 2l) of the previous column */
-                const int sv = rc == 0 ? scq[c][0] : rc == 1 ? scq[c][1] : rc == 2 ? scq[c][2] : rc == 3 ? scq[c][3] : 0;
+                const int sv = st_score(qpk[c] ^ rcpk) & qok[c] & rc_ok; /* positions past the query and letters other than ACGT score 0 */
                 const int hp = pk_max(pk_max(pk_add(dg, sv), e), 0);
                 /* F[j] = max_{t<j}(h'[t] + t*GE) - GO - (j-1)*GE: exclusive prefix max in position order */
                 const int w = pk_add(hp, jg[c]);
                 const int tot = pk_max(w, __builtin_amdgcn_perm(w, w, 0x01000302)); /* both halves = the lane's larger key */
-                const int inc = pk_wave_scan_max(tot);
-                int ex = CW_DPP(carry_f, inc, 0x138, 0xF);
-                ex = pk_max(ex, carry_f);
-                carry_f = pk_max(carry_f, cw_lane_value(inc, 63));
-                const int pre = pk_max(ex, (w << 16) | (CW_NEGPK & 0xFFFF));        /* the odd position also sees the even one of its lane */
+                /* prefix max over the lanes on biased unsigned keys: six fused v_max_u32_dpp (see poa_fill_pk) */
+                const unsigned inc = cw_wave_scan_max_u32(((unsigned)tot & 0xFFFFu) ^ 0x8000u);
+                const unsigned ex = max((unsigned)CW_DPP(0, (int)inc, 0x138, 0xF), carry_f);
+                carry_f = max(carry_f, (unsigned)cw_lane_value((int)inc, 63));
+                const int pre = pk_max(pk_splat_lo((int)(ex ^ 0x8000u)), (w << 16) | (CW_NEGPK & 0xFFFF)); /* the odd position also sees the even one of its lane */
                 const int f = pk_max(pk_add(pk_sub(pre, jg[c]), FADJ), 0);
                 const int h = pk_max(hp, f);
                 hprev[c] = h; ee[c] = e;
