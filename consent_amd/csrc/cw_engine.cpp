@@ -29,9 +29,9 @@ size_t big_slab_bytes() {
 
 void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
     t[0] = {0, 0};
-    t[1] = {(uint32_t)cus * 4 * CW_POAM1_WAVES, CW_POA_SLAB_TOTAL(CW_POAM1_NC, CW_POAM1_LC)};
-    t[2] = {(uint32_t)cus * 4 * CW_POAM2_WAVES, CW_POA_SLAB_TOTAL(CW_POAM2_NC, CW_POAM2_LC)};
-    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_SLAB_TOTAL(CW_POAL_NC, CW_POAL_LC)};
+    t[1] = {(uint32_t)cus * 5 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
+    t[2] = {(uint32_t)cus * 4 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
+    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
     t[4] = {big_slots, big_slab_bytes()};
 }
 
@@ -144,17 +144,17 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
         delete e;
         return CW_E_NO_DEVICE;
@@ -239,9 +239,9 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
 #define M1_ARGS CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1
 #define M2_ARGS CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2
 #define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
-    const size_t lds_m1 = CW_POA_HOT_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
-    const size_t lds_m2 = CW_POA_HOT_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
-    const size_t lds_l = CW_POA_HOT_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
+    const size_t lds_m1 = CW_POA_HOT2_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
+    const size_t lds_m2 = CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
+    const size_t lds_l = CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
@@ -262,7 +262,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
         cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
-    cw_sort_tier_kernel<<<2, 1024, CW_SORT_MAX * 8, st>>>(sc); /* tiers M2 and L: largest tasks first */
+    cw_sort_tier_kernel<<<3, 1024, CW_SORT_MAX * 8, st>>>(sc); /* tiers M2, L and M1: largest tasks first */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     CW_HIP(hipEventRecord(e->ev_fork, st));

@@ -44,7 +44,7 @@
 #define CW_POAM2_NC 512
 #define CW_POAM2_EC 1280
 #define CW_POAM2_LC 511
-#define CW_POAM2_WAVES 2
+#define CW_POAM2_WAVES 3
 #define CW_POAM2_ROUTE CW_POAM2_NC
 #define CW_POAL_NC 1536
 #define CW_POAL_EC 4096
@@ -68,6 +68,12 @@
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
 #define CW_POA_SLAB_TOTAL(NC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD_BYTES(NC, LC))
+/* the slab tiers also keep the in-edge lists and the coverage counts in the slab: only the rank bookkeeping before a fill and the merge
+   walk them, a few dependent reads per node.  M1: 9.5 -> 6.4 KB per wave (five work-groups per CU), M2: 18.9 -> 12.9 KB (a third wave in
+   the same 38 KB), L: 57 -> 37 KB (fits the holes the other tiers leave: it used to wait for 76 KB to fall free) */
+#define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
+#define CW_POA_SLAB2_TOTAL(NC, EC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD2_BYTES(NC, EC, LC))
 
 template <typename HT>
 struct PoaMem {
@@ -100,7 +106,8 @@ struct PoaMem {
 
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
-                                                HT* h_ext = nullptr, unsigned long long* d_ext = nullptr, uint8_t* cold = nullptr) {
+                                                HT* h_ext = nullptr, unsigned long long* d_ext = nullptr, uint8_t* cold = nullptr,
+                                                bool cold_edges = false) {
     PoaMem<HT> M;
     uint8_t* p = base;
     uint8_t* pc = cold; /* merge-only arrays: in the slab when given, else with the rest */
@@ -110,10 +117,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     else { M.dirs = (unsigned long long*)p; p += (size_t)dc * 16; }
     M.rmeta = (uint32_t*)p; p += 4 * nc;
     M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
-    M.efrom = (uint16_t*)p; p += 2 * ec;
-    M.enext = (uint16_t*)p; p += 2 * ec;
+    if (!(pc && cold_edges)) { M.efrom = (uint16_t*)p; p += 2 * ec; M.enext = (uint16_t*)p; p += 2 * ec; }
     M.rpred0 = (uint16_t*)p; p += 2 * nc;
-    M.ncov = (uint16_t*)p; p += 2 * nc;
+    if (!(pc && cold_edges)) { M.ncov = (uint16_t*)p; p += 2 * nc; }
     if (pc) { M.nal = (uint16_t*)pc; pc += 6 * nc; } else { M.nal = (uint16_t*)p; p += 6 * nc; }
     M.in_head = (uint16_t*)p; p += 2 * nc;
     if (pc) { M.in_tail = (uint16_t*)pc; pc += 2 * nc; } else { M.in_tail = (uint16_t*)p; p += 2 * nc; }
@@ -124,6 +130,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.seqrank = (uint16_t*)p; p += 2 * (lc + 1);
     if (pc) { M.pcur = (uint16_t*)pc; pc += 2 * (lc + 1); M.pat = (uint16_t*)pc; pc += 2 * (lc + 1); }
     else { M.pcur = (uint16_t*)p; p += 2 * (lc + 1); M.pat = (uint16_t*)p; p += 2 * (lc + 1); }
+    if (pc && cold_edges) { M.efrom = (uint16_t*)pc; pc += 2 * ec; M.enext = (uint16_t*)pc; pc += 2 * ec; M.ncov = (uint16_t*)pc; pc += 2 * nc; }
     M.nbase = p; p += nc;
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
@@ -592,9 +599,11 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 }
             } else {
                 /* no direction words (matrix lives in the slab): walk 8x8 tiles of the matrix held one cell per lane, so
-                   that up to 8 steps cost one memory round trip.  The tile's rows are the first-predecessor chain
-                   i, p(i), p(p(i)), ...; lane (tr,tc) = (lane>>3, lane&7) holds H[chain[tr]][j-tc]; lanes with tc == 0 also
-                   hold the row's metadata, lanes with tr == 0 the sequence base of the column. */
+                   that up to 14 steps cost one memory round trip.  The tile's rows are the first-predecessor chain
+                   i, p(i), p(p(i)), ...; lane (tr,tc) = (lane>>3, lane&7) holds H[chain[tr]][j-tc].  Every lane decides the move
+                   out of its own cell from its three neighbours in the tile (same order of preference as everywhere: diagonal
+                   through the first predecessor, other predecessors, vertical, horizontal); the path is then three ballots
+                   followed on the scalar unit. */
                 const int tr = lane >> 3, tc = lane & 7;
                 while (i > 0) {
                     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
@@ -608,41 +617,37 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     const int col = j - tc;
                     const bool valid = row >= 0 && col >= 0;
                     const int hv = valid ? (int)M.H[row * hs + col] : 0;
-                    const int meta_l = (tc == 0 && row >= 1) ? (int)M.rmeta[row - 1] : 0;
-                    const int sq_l = (tr == 0 && col >= 1) ? (int)M.sq[col - 1] : 255;
-                    int ti = 0, tj = 0, ci = i;
-                    bool slow = false;
+                    const int meta_r = row >= 1 ? (int)M.rmeta[row - 1] : 0; /* the 8 lanes of a tile row read one word */
+                    const int sq_c = col >= 1 ? (int)M.sq[col - 1] : 255;
+                    const int av = __shfl_down(hv, 9), bv = __shfl_down(hv, 8), lv = __shfl_down(hv, 1); /* (tr+1,tc+1), (tr+1,tc), (tr,tc+1) */
+                    /* 0 diagonal, 1 vertical, 2 horizontal; 3 several predecessors, 4 no move explains the cell, 5 neighbours outside
+                       the tile, 6 the virtual start row */
+                    int code;
+                    if (row <= 0) code = 6;
+                    else if (tr == 7 || (tc == 7 && col > 0)) code = 5;
+                    else if (col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS)) code = 0;
+                    else if (((meta_r >> 2) & 0x3FFF) != 1) code = 3;
+                    else if (hv == bv + G) code = 1;
+                    else if (col > 0 && hv == lv + G) code = 2;
+                    else code = 4;
+                    const unsigned long long m_d = __ballot(code == 0), m_v = __ballot(code == 1), m_h = __ballot(code == 2);
+                    int pos = 0;
+                    unsigned long long on_diag = 0ull;
                     for (;;) {
-                        const int cj = j - tj;
-                        if (ci == 0) break;
-                        if (ti == 7 || (tj == 7 && cj > 0)) break; /* neighbours outside the tile: fetch the next one */
-                        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(meta_l, ti * 8);
-                        const int np = (int)((meta >> 2) & 0x3FFFu), base = (int)(meta & 3u);
-                        const int up = __builtin_amdgcn_readlane(row, (ti + 1) * 8); /* first predecessor's row */
-                        const int h = __builtin_amdgcn_readlane(hv, ti * 8 + tj);
-                        const int bv = __builtin_amdgcn_readlane(hv, (ti + 1) * 8 + tj);
-                        bool moved = false;
-                        if (cj > 0) {
-                            const int sx = (__builtin_amdgcn_readlane(sq_l, tj) == base) ? MS : XS;
-                            const int av = __builtin_amdgcn_readlane(hv, (ti + 1) * 8 + tj + 1);
-                            if (h == av + sx) { /* diagonal through the first predecessor: first in the order of preference */
-                                if (lane == 0) M.seqrank[cj - 1] = (uint16_t)(ci - 1);
-                                ti++; tj++; ci = up; moved = true;
-                            }
-                        }
-                        if (!moved) {
-                            if (np != 1) { slow = true; break; } /* other predecessors come before the vertical move */
-                            if (h == bv + G) { ti++; ci = up; }
-                            else if (cj > 0 && h == __builtin_amdgcn_readlane(hv, ti * 8 + tj + 1) + G) { tj++; }
-                            else return 3;
-                        }
+                        const unsigned long long bit = 1ull << pos;
+                        if (m_d & bit) { on_diag |= bit; pos += 9; }
+                        else if (m_v & bit) pos += 8;
+                        else if (m_h & bit) pos += 1;
+                        else break;
                     }
-                    i = ci;
-                    (void)ti;
-                    j -= tj;
-                    if (slow && i > 0) {
-                        /* a node with several predecessors, or one whose predecessor is not the previous rank: one step
-                           decided from direct reads (same order of preference) */
+                    if ((on_diag >> lane) & 1ull) M.seqrank[col - 1] = (uint16_t)(row - 1);
+                    const int end_code = __builtin_amdgcn_readlane(code, pos);
+                    i = __builtin_amdgcn_readlane(row, pos);
+                    j -= pos & 7;
+                    if (end_code == 4) return 3;
+                    if (end_code == 6) i = 0;
+                    if (end_code == 3) {
+                        /* a node with several predecessors: one step decided from direct reads (same order of preference) */
                         const int pr0 = __builtin_amdgcn_readfirstlane((int)M.rpred0[i - 1]);
                         int pi, pj;
                         if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
@@ -903,7 +908,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 4 : 1) /* M1: four waves per SIMD, i.e. at most 128 VGPRs */
+__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 5 : 1) /* M1: five waves per SIMD (96 VGPRs, a few spills in the merge): measured +7 % over four */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -914,8 +919,9 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
-    constexpr uint32_t slab = CW_POA_HOT_BYTES(NC, EC, LC);
-    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold);
+    constexpr uint32_t slab = CW_POA_HOT2_BYTES(NC, EC, LC);
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
+                                           true);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
@@ -986,13 +992,45 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
 }
 
 /* ---- largest tasks first ---------------------------------------------------------------------------
- * Tiers M2 and L hold few, long tasks, and a task that outgrows M2 is redone in L: if that happens late, tier L finishes long
- * after everything else (depth 150: the last hand-overs used to land when M1/M2 were nearly done).  One work-group per tier sorts
- * that tier's routed list by estimated cost (members x longest member squared), largest first, so that whatever is going to
- * outgrow its tier does so early.  Lists beyond CW_SORT_MAX entries are left as they are. */
+ * Tiers M2 and L hold few, long tasks, and a task that outgrows a tier is redone in tier L: if that happens late, tier L finishes long
+ * after everything else (depth 150: the last hand-overs used to land when M1/M2 were nearly done).  One work-group per tier orders
+ * that tier's routed list by estimated cost, largest first, so that whatever is going to outgrow its tier does so early.
+ * M2 and L: a bitonic sort on members x longest member squared (lists beyond CW_SORT_MAX entries are left as they are).
+ * M1 (tens of thousands of tasks): a counting sort into 16 classes of the depth-aware graph-size estimate, through the (otherwise
+ * unused) hand-over list of tier 1. */
 #define CW_SORT_MAX 16384
+#define CW_SORT_CLASSES 16
+__device__ __forceinline__ uint32_t cw_sort_class(const PoaTask& t) {
+    const uint32_t est = (t.max_len * (15u + t.n_members / 5u) + 9u) / 10u;
+    const uint32_t c = est >> 5;
+    return (CW_SORT_CLASSES - 1) - (c < CW_SORT_CLASSES ? c : CW_SORT_CLASSES - 1); /* class 0 = the largest estimates */
+}
 __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sort_key[];
+    if (blockIdx.x == 2) {
+        const uint32_t n = min(sc.ctr->n_tier[1], sc.list_cap);
+        uint32_t* cnt = (uint32_t*)sort_key;
+        uint32_t* list = sc.tier_list[1];
+        uint32_t* tmp = sc.over_list[1];
+        if (n < 2) return;
+        if (threadIdx.x < CW_SORT_CLASSES) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < n; x += 1024) atomicAdd(&cnt[cw_sort_class(sc.tasks[list[x]])], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int c = 0; c < CW_SORT_CLASSES; ++c) { const uint32_t k = cnt[c]; cnt[c] = run; run += k; }
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < n; x += 1024) {
+            const uint32_t ti = list[x];
+            tmp[atomicAdd(&cnt[cw_sort_class(sc.tasks[ti])], 1u)] = ti;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = tmp[x];
+        return;
+    }
     const int tier = 2 + (int)blockIdx.x;
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
     if (n < 2 || n > CW_SORT_MAX) return;
