@@ -287,7 +287,7 @@ def main():
         }
     if rank == 0 and os.environ.get("CW_PROFILE"):
         ctr, prof = eng.profile()
-        names = ["idx.count", "idx.exact", "idx.export", "idx.support", "idx.cand+P", "idx.chain", "idx.segments", "-"]
+        names = ["idx.count", "idx.exact", "idx.export", "idx.support", "idx.cand+P", "idx.chain", "idx.segments", "idx.tplhash"]
         for tname in ("S", "M1", "M2", "L", "G"):
             names += [f"{tname}.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
         print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier", ctr[6:11].tolist(), "outgrew into tier", ctr[16:21].tolist(), file=sys.stderr)

@@ -26,6 +26,13 @@
 #define CW_TMAX 1024 /* template k-mer slots */
 #define CW_EX_SLOTS 2048
 #define CW_TH_SLOTS 2048
+/* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
+   lengths, word offsets and the 2-bit words themselves, so that the four passes over the pile's k-mers read LDS instead of walking
+   seq_len -> seq_word_off -> bases in global memory (three dependent round trips per sequence and pass, with all 16 waves waiting
+   at the same time) */
+#define CW_IDX_STAGE_OFF 147968
+#define CW_IDX_STAGE_N 256
+#define CW_IDX_STAGE_WORDS ((CW_IDX_LDS_BYTES - CW_IDX_STAGE_OFF - 16 - CW_IDX_STAGE_N * 8) / 4)
 
 /* ------------------------------------------------------------------------------------------------ */
 /* anchor block of one window (index kernel -> chain kernel): sizes in bytes, everything 16-byte aligned */
@@ -158,7 +165,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     uint16_t* chain = (uint16_t*)(lds + 35856);
     uint32_t* misc = (uint32_t*)(lds + 37904);                                /* 64 words                */
     uint16_t* const P_lds = (uint16_t*)(lds + 38400);
-    const uint32_t p_cap = (CW_IDX_LDS_BYTES - 38400) / 2;
+    const uint32_t p_cap = (CW_IDX_STAGE_OFF - 38400) / 2;
+    uint32_t* st_hdr = (uint32_t*)(lds + CW_IDX_STAGE_OFF);                    /* [0] words staged          */
+    uint32_t* s_len = st_hdr + 4;                                             /* CW_IDX_STAGE_N            */
+    uint32_t* s_off = s_len + CW_IDX_STAGE_N;                                 /* CW_IDX_STAGE_N            */
+    uint32_t* s_words = s_off + CW_IDX_STAGE_N;                               /* CW_IDX_STAGE_WORDS        */
     /* position matrix: in LDS when it fits next to the presence bitsets, else in this work-group's global slot
        (high-identity deep piles: every template k-mer is an anchor).  Accessors pick the address space with a
        block-uniform branch so that the common case keeps ds_ instructions. */
@@ -168,7 +179,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) misc[63] = atomicAdd(&sc.ctr->next_window, 1u);
+        if (tid == 0) { misc[63] = atomicAdd(&sc.ctr->next_window, 1u); st_hdr[0] = 0; }
         __syncthreads();
         const uint32_t w = misc[63];
         if (w >= b.n_windows) break;
@@ -177,6 +188,69 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const uint32_t s0 = b.win_first_seq[w];
         const uint32_t N = wi->n_seqs;
         const uint32_t L0 = wi->tpl_len;
+        /* stage the pile (see CW_IDX_STAGE_OFF): stm = lengths and offsets are in LDS, stw = the words too */
+        const bool stm = N <= CW_IDX_STAGE_N;
+        bool stw = false;
+        if (stm) {
+            const uint64_t base_off = b.seq_word_off[s0];
+            for (uint32_t s = tid; s < N; s += CW_IDX_THREADS) {
+                const uint32_t len = b.seq_len[s0 + s];
+                const uint64_t rel = b.seq_word_off[s0 + s] - base_off; /* piles are packed front to back; anything else does not fit */
+                s_len[s] = len;
+                s_off[s] = (uint32_t)rel;
+                atomicMax(&st_hdr[0], rel > 0xFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rel + ((len + 15u) >> 4));
+            }
+            __syncthreads();
+            const uint32_t n_stage = st_hdr[0];
+            stw = n_stage <= CW_IDX_STAGE_WORDS;
+            if (stw) {
+                const uint32_t* src = b.bases + base_off;
+                for (uint32_t i = tid; i < n_stage; i += CW_IDX_THREADS) s_words[i] = src[i];
+            }
+            /* the barrier behind the table clears below orders these writes before the first pass */
+        }
+/* sequence s for the whole wave, four consecutive k-mers per lane (see CW_IDX_KMERS4): BODY sees p and key */
+#define CW_IDX_KMERS4_WAVE(...)                                                                                         \
+                const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;                                \
+                for (uint32_t p0 = (uint32_t)lane * 4u; p0 < nk; p0 += 256u) {                                          \
+                    const uint32_t wi_ = p0 >> 4;                                                                       \
+                    uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);               \
+                    x_ <<= 2u * (p0 & 15u);                                                                             \
+                    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4u; ++q_, x_ <<= 2) {                                  \
+                        const uint32_t p = p0 + q_;                                                                     \
+                        if (p >= nk) break;                                                                             \
+                        const uint32_t key = (uint32_t)(x_ >> (64u - 2u * k));                                          \
+                        __VA_ARGS__                                                                                     \
+                    }                                                                                                   \
+                }
+#define CW_IDX_PASS_SEQ(...)                                                                                            \
+        if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS4_WAVE(__VA_ARGS__) } \
+        else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                                 \
+               const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS4_WAVE(__VA_ARGS__) }
+/* one pass over the pile, work-group wide: eight sequences at a time, 128 threads each, four consecutive k-mers per thread out of one
+   64-bit window of the packed bases; BODY sees s, p and key (a `continue` in BODY goes to the next k-mer) */
+#define CW_IDX_KMERS4(...)                                                                                              \
+                const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;                                \
+                for (uint32_t p0 = ((uint32_t)tid & 127u) * 4u; p0 < nk; p0 += 512u) {                                  \
+                    const uint32_t wi_ = p0 >> 4;                                                                       \
+                    uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);               \
+                    x_ <<= 2u * (p0 & 15u);                                                                             \
+                    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4u; ++q_, x_ <<= 2) {                                  \
+                        const uint32_t p = p0 + q_;                                                                     \
+                        if (p >= nk) break;                                                                             \
+                        const uint32_t key = (uint32_t)(x_ >> (64u - 2u * k));                                          \
+                        __VA_ARGS__                                                                                     \
+                    }                                                                                                   \
+                }
+#define CW_IDX_PASS_BLOCK(...)                                                                                          \
+        for (uint32_t sp = 0; sp < N; sp += 8) {                                                                        \
+            const uint32_t s = sp + ((uint32_t)tid >> 7);                                                               \
+            if (s < N) {                                                                                                \
+                if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS4(__VA_ARGS__) } \
+                else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
+                       const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS4(__VA_ARGS__) }           \
+            }                                                                                                           \
+        }
 
         CW_PROF_T0();
         /* ================= phase A: counts ================= */
@@ -194,28 +268,19 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             for (uint32_t pass = 0; pass < P_; ++pass) {
                 for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) hs_tab[i] = 0ull;
                 __syncthreads();
-                for (uint32_t sp = 0; sp < N; sp += 2) {
-                    const uint32_t s = sp + (tid >> 9);
-                    if (s < N) {
-                        const uint32_t len = b.seq_len[s0 + s];
-                        const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
-                        const uint32_t nk = len >= k ? len - k + 1 : 0;
-                        for (uint32_t p = tid & 511; p < nk; p += 512) {
-                            const uint32_t key = cw_kmer_at(words, p, k);
-                            const uint32_t h = cw_hash32(key ^ 0x9E3779B9u);
-                            if ((uint32_t)(((unsigned long long)h * P_) >> 32) != pass) continue;
-                            uint32_t slot = cw_hash32(key) >> (32 - 14);
-                            const unsigned long long fresh = ((unsigned long long)key << 32) | 1ull;
-                            for (uint32_t probe = 0;; ++probe) {
-                                if (probe >= HS) { flags[0] = 1; break; }
-                                const unsigned long long cur = atomicCAS(&hs_tab[slot], 0ull, fresh);
-                                if (cur == 0ull) break;
-                                if ((uint32_t)(cur >> 32) == key) { atomicAdd(&hs_tab[slot], 1ull); break; }
-                                slot = (slot + 1) & (HS - 1);
-                            }
-                        }
+                CW_IDX_PASS_BLOCK({
+                    const uint32_t h = cw_hash32(key ^ 0x9E3779B9u);
+                    if ((uint32_t)(((unsigned long long)h * P_) >> 32) != pass) continue;
+                    uint32_t slot = cw_hash32(key) >> (32 - 14);
+                    const unsigned long long fresh = ((unsigned long long)key << 32) | 1ull;
+                    for (uint32_t probe = 0;; ++probe) {
+                        if (probe >= HS) { flags[0] = 1; break; }
+                        const unsigned long long cur = atomicCAS(&hs_tab[slot], 0ull, fresh);
+                        if (cur == 0ull) break;
+                        if ((uint32_t)(cur >> 32) == key) { atomicAdd(&hs_tab[slot], 1ull); break; }
+                        slot = (slot + 1) & (HS - 1);
                     }
-                }
+                })
                 __syncthreads();
                 uint32_t mine = 0;
                 for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) mine += ((uint32_t)hs_tab[i] >= prm.solid) ? 1u : 0u;
@@ -271,49 +336,31 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
-        for (uint32_t sp = 0; sp < N; sp += 2) {
-            const uint32_t s = sp + (tid >> 9);
-            if (s < N) {
-                const uint32_t len = b.seq_len[s0 + s];
-                const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
-                const uint32_t nk = len >= k ? len - k + 1 : 0;
-                for (uint32_t p = tid & 511; p < nk; p += 512) {
-                    const uint32_t key = cw_kmer_at(words, p, k);
-                    const uint32_t wd = key >> 3, sh = (key & 7) * 4;
-                    uint32_t old = tab[wd];
-                    for (;;) {
-                        if (((old >> sh) & 15u) == 15u) break;
-                        uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));
-                        if (prev == old) break;
-                        old = prev;
-                    }
-                }
+        CW_IDX_PASS_BLOCK({
+            const uint32_t wd = key >> 3, sh = (key & 7) * 4;
+            uint32_t old = tab[wd];
+            for (;;) {
+                if (((old >> sh) & 15u) == 15u) break;
+                uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));
+                if (prev == old) break;
+                old = prev;
             }
-        }
+        })
         __syncthreads();
         CW_PROF(sc.ctr, 0, tid == 0);
         /* exact counts for the keys whose 4-bit counter saturated */
-        for (uint32_t sp = 0; sp < N; sp += 2) {
-            const uint32_t s = sp + (tid >> 9);
-            if (s < N) {
-                const uint32_t len = b.seq_len[s0 + s];
-                const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
-                const uint32_t nk = len >= k ? len - k + 1 : 0;
-                for (uint32_t p = tid & 511; p < nk; p += 512) {
-                    const uint32_t key = cw_kmer_at(words, p, k);
-                    if (((tab[key >> 3] >> ((key & 7) * 4)) & 15u) != 15u) continue;
-                    uint32_t slot = cw_hash32(key) >> (32 - 11);
-                    const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;
-                    for (uint32_t probe = 0;; ++probe) {
-                        if (probe >= CW_EX_SLOTS) { flags[0] = 1; break; }
-                        unsigned long long cur = atomicCAS(&ex[slot], 0ull, fresh);
-                        if (cur == 0ull) break;
-                        if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&ex[slot], 1ull); break; }
-                        slot = (slot + 1) & (CW_EX_SLOTS - 1);
-                    }
-                }
+        CW_IDX_PASS_BLOCK({
+            if (((tab[key >> 3] >> ((key & 7) * 4)) & 15u) != 15u) continue;
+            uint32_t slot = cw_hash32(key) >> (32 - 11);
+            const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;
+            for (uint32_t probe = 0;; ++probe) {
+                if (probe >= CW_EX_SLOTS) { flags[0] = 1; break; }
+                unsigned long long cur = atomicCAS(&ex[slot], 0ull, fresh);
+                if (cur == 0ull) break;
+                if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&ex[slot], 1ull); break; }
+                slot = (slot + 1) & (CW_EX_SLOTS - 1);
             }
-        }
+        })
         __syncthreads();
         CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than the exact table holds */
@@ -330,9 +377,10 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             const uint32_t w_beg = min(nib_words, (uint32_t)tid * wpt), w_cnt = min(nib_words, w_beg + wpt) - w_beg;
             uint32_t lk[8], lc[8];
             uint32_t mine = 0;
+            const uint32_t r0 = w_cnt ? (uint32_t)tid % w_cnt : 0u; /* one division per thread, not one per word */
             for (uint32_t i = 0; i < w_cnt; ++i) {
-                uint32_t r = i + (uint32_t)tid;
-                r = r >= w_cnt ? r % w_cnt : r;
+                uint32_t r = i + r0;
+                r = r >= w_cnt ? r - w_cnt : r;
                 const uint32_t wd = w_beg + r;
                 const uint32_t v = tab[wd];
                 if (v == 0) continue;
@@ -419,8 +467,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
         for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; lvl_head[i] = -1; }
         if (tid == 0) lvl_head[CW_TMAX] = -1;
-        const uint32_t* tpl_words = b.bases + b.seq_word_off[s0];
-        if ((uint32_t)tid < nk0) tkey[tid] = cw_kmer_at(tpl_words, tid, k);
+        if ((uint32_t)tid < nk0) tkey[tid] = stw ? cw_kmer_at(s_words, tid, k) : cw_kmer_at(b.bases + b.seq_word_off[s0], tid, k);
         __syncthreads();
         if ((uint32_t)tid < nk0) {
             const uint32_t key = tkey[tid];
@@ -433,22 +480,20 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 7, tid == 0);
         /* support + repeat detection: one wave per sequence */
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
             uint32_t* my_seen = seen + wave * 32;
             if (lane < 32) my_seen[lane] = 0;
             cw_wave_sync();
-            const uint32_t len = b.seq_len[s0 + s];
-            const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
-            const uint32_t nk = len >= k ? len - k + 1 : 0;
-            for (uint32_t p = lane; p < nk; p += 64) {
-                const int e = cw_tpl_lookup(th, tkey, cw_kmer_at(words, p, k));
+            CW_IDX_PASS_SEQ({
+                const int e = cw_tpl_lookup(th, tkey, key);
                 if (e < 0) continue;
                 const uint32_t bit = 1u << (e & 31);
                 const uint32_t old = atomicOr(&my_seen[e >> 5], bit);
                 if (old & bit) trep[e] = 1;
                 else atomicAdd(&tsup[e], 1u);
-            }
+            })
             cw_wave_sync();
         }
         __syncthreads();
@@ -480,15 +525,12 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
         __syncthreads();
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
-            const uint32_t len = b.seq_len[s0 + s];
-            const uint32_t* words = b.bases + b.seq_word_off[s0 + s];
-            const uint32_t nk = len >= k ? len - k + 1 : 0;
-            for (uint32_t p = lane; p < nk; p += 64) {
-                const int e = cw_tpl_lookup(th, tkey, cw_kmer_at(words, p, k));
+            CW_IDX_PASS_SEQ({
+                const int e = cw_tpl_lookup(th, tkey, key);
                 if (e < 0) continue;
                 const int a = tcand[e];
                 if (a >= 0) PWR((uint32_t)a * Np + s, p);
-            }
+            })
         }
         __syncthreads();
 
@@ -499,7 +541,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available) */
         unsigned long long* pres = (unsigned long long*)(P_lds + (pg ? 0 : (((size_t)A * Np + 3u) & ~(size_t)3u))); /* A x Nw, 8-byte aligned */
         uint16_t* dirty = (uint16_t*)(pres + (size_t)A * Nw);          /* up to N ids */
-        const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_LDS_BYTES);
+        const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_STAGE_OFF);
         if (use_bits) {
             for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
                 int run = -1;
@@ -581,5 +623,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 
 #undef PRD
 #undef PWR
+#undef CW_IDX_PASS_SEQ
+#undef CW_IDX_PASS_BLOCK
+#undef CW_IDX_KMERS4
+#undef CW_IDX_KMERS4_WAVE
 
 #endif
