@@ -464,6 +464,16 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
+        /* P is anchor-major, P[a * Np + s]; Np is even with Np/2 odd so that rows read as u32 pairs by consecutive
+           lanes fall on distinct banks */
+        uint32_t Np = (N + 1u) & ~1u;
+        if (((Np >> 1) & 1u) == 0u) Np += 2u;
+        const uint32_t Nw = (N + 63u) >> 6;
+        /* When a matrix with one row per TEMPLATE k-mer fits (every 500-base window up to depth ~100), the support pass records the hit
+           positions as it goes and the anchors' rows are simply picked out of it afterwards: the second pass over the pile (one more
+           table lookup per k-mer) is not needed.  Otherwise the matrix has one row per anchor and is filled by that second pass. */
+        const bool tfit = (uint64_t)nk0 * Np * 2 + (uint64_t)nk0 * Nw * 8 + (uint64_t)N * 2 + 16 <= (uint64_t)p_cap * 2;
+        if (tfit) for (uint32_t i = tid; i < nk0 * Np; i += CW_IDX_THREADS) P_lds[i] = (uint16_t)CW_NONE16;
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
         for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; lvl_head[i] = -1; }
         if (tid == 0) lvl_head[CW_TMAX] = -1;
@@ -493,6 +503,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t old = atomicOr(&my_seen[e >> 5], bit);
                 if (old & bit) trep[e] = 1;
                 else atomicAdd(&tsup[e], 1u);
+                if (tfit) P_lds[(uint32_t)e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
             })
             cw_wave_sync();
         }
@@ -510,36 +521,35 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (ok) { tcand[tid] = (int16_t)off; cand_tp[off] = (uint16_t)tid; }
         }
         __syncthreads();
-        /* P is anchor-major, P[a * Np + s]; Np is even with Np/2 odd so that rows read as u32 pairs by consecutive
-           lanes fall on distinct banks */
-        uint32_t Np = (N + 1u) & ~1u;
-        if (((Np >> 1) & 1u) == 0u) Np += 2u;
-        const uint32_t Nw = (N + 63u) >> 6;
         /* LDS needs: the matrix (A*Np u16) + presence bitsets (A*Nw u64) + dirty list (N u16) */
-        const bool pg = (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
+        const bool pg = !tfit && (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
         if (pg && (uint64_t)A * Np > sc.p_fallback_elems) {
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
-        for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
-        __syncthreads();
-        for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
-            CW_IDX_PASS_SEQ({
-                const int e = cw_tpl_lookup(th, tkey, key);
-                if (e < 0) continue;
-                const int a = tcand[e];
-                if (a >= 0) PWR((uint32_t)a * Np + s, p);
-            })
+/* matrix row of anchor a */
+#define PROW(a) (tfit ? (uint32_t)cand_tp[a] : (uint32_t)(a))
+        if (!tfit) {
+            for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
+            __syncthreads();
+            for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
+                CW_IDX_PASS_SEQ({
+                    const int e = cw_tpl_lookup(th, tkey, key);
+                    if (e < 0) continue;
+                    const int a = tcand[e];
+                    if (a >= 0) PWR((uint32_t)a * Np + s, p);
+                })
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
         /* A sequence whose anchor positions increase with the anchor index ("clean") satisfies pos(a) < pos(b) for every
            pair a < b it holds, so its contribution to score(a,b) is one bit of presence(a) & presence(b); only the few
            sequences with an out-of-order (spurious) anchor hit need their positions compared.  Exact, and ~20x cheaper
            than comparing positions for all N sequences. */
         uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available) */
-        unsigned long long* pres = (unsigned long long*)(P_lds + (pg ? 0 : (((size_t)A * Np + 3u) & ~(size_t)3u))); /* A x Nw, 8-byte aligned */
+        unsigned long long* pres = (unsigned long long*)(P_lds + (pg ? 0 : (((size_t)(tfit ? nk0 : A) * Np + 3u) & ~(size_t)3u))); /* A x Nw, 8-byte aligned */
         uint16_t* dirty = (uint16_t*)(pres + (size_t)A * Nw);          /* up to N ids */
         const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_STAGE_OFF);
         if (use_bits) {
@@ -548,7 +558,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 bool bad = false;
                 for (uint32_t a0 = 0; a0 < A; a0 += 64) {
                     const uint32_t a = a0 + lane;
-                    const uint32_t pv = a < A ? PRD(a * Np + s) : (uint32_t)CW_NONE16;
+                    const uint32_t pv = a < A ? PRD(PROW(a) * Np + s) : (uint32_t)CW_NONE16;
                     const int v = pv != CW_NONE16 ? (int)pv : -1;
                     const int inc = cw_wave_scan_max(v);
                     int before = cw_wave_shr1(inc, -1);
@@ -563,7 +573,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
                 for (uint32_t w = 0; w < Nw; ++w) {
                     const uint32_t s = w * 64 + lane;
-                    const bool on = s < N && PRD(a * Np + s) != CW_NONE16 && clean[s];
+                    const bool on = s < N && PRD(PROW(a) * Np + s) != CW_NONE16 && clean[s];
                     const unsigned long long bal = __ballot(on);
                     if (lane == 0) pres[(size_t)a * Nw + w] = bal;
                 }
@@ -608,11 +618,17 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 for (uint32_t i = tid; i < A * Nw; i += CW_IDX_THREADS) gpres[i] = pres[i];
                 for (uint32_t i = tid; i < n_dirty; i += CW_IDX_THREADS) gdirty[i] = dirty[i];
             }
-            {   /* rows are Np (even) u16: copy as u32 pairs */
+            {   /* rows are Np (even) u16: copy as u32 pairs, row by row (the rows of the anchors when the matrix is per template k-mer) */
                 const uint32_t* src = (const uint32_t*)(pg ? P_glb : P_lds);
                 uint32_t* dst = (uint32_t*)gP;
-                const uint32_t n2 = (A * Np) >> 1;
-                for (uint32_t i = tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
+                const uint32_t half = Np >> 1;
+                if (tfit) {
+                    for (uint32_t a = wave; a < A; a += CW_IDX_WAVES)
+                        for (uint32_t j = lane; j < half; j += 64) dst[a * half + j] = src[(uint32_t)cand_tp[a] * half + j];
+                } else {
+                    const uint32_t n2 = A * half;
+                    for (uint32_t i = tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
+                }
             }
             /* no flag, no fence: every early exit above changes wi->status, so "still CW_WIN_CONSENSUS when the kernel has ended"
                means the block is complete, and the kernel boundary makes it visible to cw_chain_kernel */
@@ -622,6 +638,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 }
 
 #undef PRD
+#undef PROW
 #undef PWR
 #undef CW_IDX_PASS_SEQ
 #undef CW_IDX_PASS_BLOCK
