@@ -336,21 +336,19 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
+        /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in the small hash table ex[] (key + 1 in the
+           high half, the overflow count in the low half), so that a key's exact count is its nibble, plus its overflow when the nibble is 15 */
         CW_IDX_PASS_BLOCK({
             const uint32_t wd = key >> 3, sh = (key & 7) * 4;
             uint32_t old = tab[wd];
+            bool sat = false;
             for (;;) {
-                if (((old >> sh) & 15u) == 15u) break;
+                if (((old >> sh) & 15u) == 15u) { sat = true; break; }
                 uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));
                 if (prev == old) break;
                 old = prev;
             }
-        })
-        __syncthreads();
-        CW_PROF(sc.ctr, 0, tid == 0);
-        /* exact counts for the keys whose 4-bit counter saturated */
-        CW_IDX_PASS_BLOCK({
-            if (((tab[key >> 3] >> ((key & 7) * 4)) & 15u) != 15u) continue;
+            if (!sat) continue;
             uint32_t slot = cw_hash32(key) >> (32 - 11);
             const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;
             for (uint32_t probe = 0;; ++probe) {
@@ -362,6 +360,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         })
         __syncthreads();
+        CW_PROF(sc.ctr, 0, tid == 0);
         CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than the exact table holds */
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
@@ -398,8 +397,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     uint32_t c = nib;
                     if (nib == 15u) {
                         uint32_t slot = cw_hash32(key) >> (32 - 11);
-                        while ((uint32_t)(ex[slot] >> 32) != key + 1) slot = (slot + 1) & (CW_EX_SLOTS - 1);
-                        c = (uint32_t)ex[slot];
+                        unsigned long long xe = ex[slot];
+                        while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
+                        c = 15u + (uint32_t)xe; /* exactly 15 occurrences leave no entry */
                     }
                     if (c < prm.solid) continue;
 #pragma unroll
@@ -424,8 +424,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                         uint32_t c = nib;
                         if (nib == 15u) {
                             uint32_t slot = cw_hash32(key) >> (32 - 11);
-                            while ((uint32_t)(ex[slot] >> 32) != key + 1) slot = (slot + 1) & (CW_EX_SLOTS - 1);
-                            c = (uint32_t)ex[slot];
+                            unsigned long long xe = ex[slot];
+                            while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
+                            c = 15u + (uint32_t)xe;
                         }
                         if (c >= prm.solid) { sc.solid_key[o] = key; sc.solid_cnt[o] = c; o++; }
                     }
