@@ -376,16 +376,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             const uint32_t w_beg = min(nib_words, (uint32_t)tid * wpt), w_cnt = min(nib_words, w_beg + wpt) - w_beg;
             uint32_t lk[8], lc[8];
             uint32_t mine = 0;
-            const uint32_t r0 = w_cnt ? (uint32_t)tid % w_cnt : 0u; /* one division per thread, not one per word */
-            for (uint32_t i = 0; i < w_cnt; ++i) {
-                uint32_t r = i + r0;
-                r = r >= w_cnt ? r - w_cnt : r;
-                const uint32_t wd = w_beg + r;
-                const uint32_t v = tab[wd];
-                if (v == 0) continue;
+            const uint32_t add = (16u - (prm.solid < 15u ? prm.solid : 15u)) * 0x01010101u;
+            auto scan_word = [&](const uint32_t v, const uint32_t wd) {
+                if (v == 0) return;
                 /* nibbles that can be solid, all eight at once: (nibble + 16 - t) carries into bit 4 of its byte iff nibble >= t,
                    t = min(solid, 15) (a saturated nibble is decided by its exact count below) */
-                const uint32_t add = (16u - (prm.solid < 15u ? prm.solid : 15u)) * 0x01010101u;
                 uint32_t cand = ((((v & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 4) | (((((v >> 4) & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 3);
                 if (keys_per_word < 8) cand &= (1u << (8 * ((keys_per_word + 1) / 2))) - 1u;
                 while (cand) {
@@ -405,6 +400,25 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 #pragma unroll
                     for (int z = 0; z < 8; ++z) if ((uint32_t)z == mine) { lk[z] = key; lc[z] = c; }
                     mine++;
+                }
+            };
+            if (w_cnt && (w_cnt & 3u) == 0u) {
+                /* four words per LDS read (most of the table is empty); the rotation spreads a wave's reads over the banks */
+                const uint32_t nq = w_cnt >> 2, q0 = (uint32_t)tid % nq; /* one division per thread */
+                for (uint32_t i = 0; i < nq; ++i) {
+                    uint32_t r = i + q0;
+                    r = r >= nq ? r - nq : r;
+                    const uint32_t wd = w_beg + 4u * r;
+                    const uint4 v4 = *(const uint4*)&tab[wd];
+                    if ((v4.x | v4.y | v4.z | v4.w) == 0u) continue;
+                    scan_word(v4.x, wd); scan_word(v4.y, wd + 1u); scan_word(v4.z, wd + 2u); scan_word(v4.w, wd + 3u);
+                }
+            } else {
+                const uint32_t r0 = w_cnt ? (uint32_t)tid % w_cnt : 0u;
+                for (uint32_t i = 0; i < w_cnt; ++i) {
+                    uint32_t r = i + r0;
+                    r = r >= w_cnt ? r - w_cnt : r;
+                    scan_word(tab[w_beg + r], w_beg + r);
                 }
             }
             if (mine > 8) flags[1] = 1; /* more than the register slots hold: the whole block re-walks in key order */
