@@ -140,8 +140,8 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
     for (int i = 0; i < CW_MAX_STAGES && ok; ++i) ok = hipEventCreate(&e->ev0[i]) == hipSuccess && hipEventCreate(&e->ev1[i]) == hipSuccess;
     if (!ok) { delete e; return CW_E_NO_DEVICE; }
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_MAX * 8) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
@@ -262,7 +262,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
         cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
-    cw_sort_tier_kernel<<<3, 1024, CW_SORT_MAX * 8, st>>>(sc); /* tiers M2, L and M1: largest tasks first */
+    cw_sort_tier_kernel<<<3, 1024, CW_SORT_LDS_CLS, st>>>(sc); /* tiers M2, L and M1: largest tasks first */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     CW_HIP(hipEventRecord(e->ev_fork, st));

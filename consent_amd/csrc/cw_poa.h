@@ -992,76 +992,89 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
 }
 
 /* ---- largest tasks first ---------------------------------------------------------------------------
- * Tiers M2 and L hold few, long tasks, and a task that outgrows a tier is redone in tier L: if that happens late, tier L finishes long
- * after everything else (depth 150: the last hand-overs used to land when M1/M2 were nearly done).  One work-group per tier orders
- * that tier's routed list by estimated cost, largest first, so that whatever is going to outgrow its tier does so early.
- * M2 and L: a bitonic sort on members x longest member squared (lists beyond CW_SORT_MAX entries are left as they are).
- * M1 (tens of thousands of tasks): a counting sort into 16 classes of the depth-aware graph-size estimate, through the (otherwise
- * unused) hand-over list of tier 1. */
-#define CW_SORT_MAX 16384
-#define CW_SORT_CLASSES 16
-__device__ __forceinline__ uint32_t cw_sort_class(const PoaTask& t) {
-    const uint32_t est = (t.max_len * (15u + t.n_members / 5u) + 9u) / 10u;
-    const uint32_t c = est >> 5;
-    return (CW_SORT_CLASSES - 1) - (c < CW_SORT_CLASSES ? c : CW_SORT_CLASSES - 1); /* class 0 = the largest estimates */
+ * A task that outgrows a tier is redone in tier L, and tiers M2 and L hold few, long tasks: whatever is going to take long or to outgrow
+ * its tier has to start early, or tier L finishes long after everything else (depth 150: the last hand-overs used to land when M1/M2
+ * were nearly done).  One work-group per tier orders that tier's routed list by estimated cost, largest first: a counting sort into 64
+ * classes (quarter octaves of members x longest member squared for M2 and L, steps of the depth-aware graph-size estimate for M1;
+ * the order inside a class does not matter), with per-wave counters so that the LDS atomics of one wave do not queue behind the
+ * other fifteen.  The second buffer is the tier's hand-over list, which nothing uses before the tier kernels run (tier L's is
+ * re-initialised afterwards by the kernel itself). */
+#define CW_SORT_CLASSES 128
+#define CW_SORT_LDS_CLS 131072 /* classes of the first so many list entries are kept in LDS between the two passes */
+__device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t max_len, int tier) {
+    uint32_t c;
+    if (tier == 1) {
+        c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;
+    } else {
+        const unsigned long long cost = (unsigned long long)n_members * max_len * max_len + 1ull;
+        const int lg = 63 - __clzll((long long)cost);                                   /* floor(log2) */
+        const uint32_t frac = lg >= 3 ? (uint32_t)((cost >> (lg - 3)) & 7ull) : 0u;     /* next three bits: eighths of an octave */
+        const int q = lg * 8 + (int)frac - 8 * 13;                                      /* costs below 2^13 share the last class */
+        c = q < 0 ? 0u : (uint32_t)q;
+    }
+    return (CW_SORT_CLASSES - 1) - (c < CW_SORT_CLASSES ? c : CW_SORT_CLASSES - 1); /* class 0 = the largest */
 }
 __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sort_key[];
-    if (blockIdx.x == 2) {
-        const uint32_t n = min(sc.ctr->n_tier[1], sc.list_cap);
-        uint32_t* cnt = (uint32_t*)sort_key;
-        uint32_t* list = sc.tier_list[1];
-        uint32_t* tmp = sc.over_list[1];
-        if (n < 2) return;
-        if (threadIdx.x < CW_SORT_CLASSES) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t x = threadIdx.x; x < n; x += 1024) atomicAdd(&cnt[cw_sort_class(sc.tasks[list[x]])], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int c = 0; c < CW_SORT_CLASSES; ++c) { const uint32_t k = cnt[c]; cnt[c] = run; run += k; }
-        }
-        __syncthreads();
-        for (uint32_t x = threadIdx.x; x < n; x += 1024) {
-            const uint32_t ti = list[x];
-            tmp[atomicAdd(&cnt[cw_sort_class(sc.tasks[ti])], 1u)] = ti;
-        }
-        __threadfence_block();
-        __syncthreads();
-        for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = tmp[x];
-        return;
-    }
-    const int tier = 2 + (int)blockIdx.x;
+    __shared__ uint32_t cnt[16][CW_SORT_CLASSES];
+    __shared__ uint32_t tot_c[CW_SORT_CLASSES];
+    extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* CW_SORT_LDS_CLS bytes */
+    const int tier = 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
-    if (n < 2 || n > CW_SORT_MAX) return;
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
     uint32_t* list = sc.tier_list[tier];
-    for (uint32_t x = threadIdx.x; x < np2; x += 1024) {
-        unsigned long long kv = 0ull; /* padding sorts last */
-        if (x < n) {
-            const uint32_t ti = list[x];
-            const PoaTask t = sc.tasks[ti];
-            const unsigned long long cost = (unsigned long long)t.n_members * t.max_len * t.max_len + 1ull;
-            kv = ((cost > 0xFFFFFFFFull ? 0xFFFFFFFFull : cost) << 32) | (unsigned long long)(0xFFFFFFFFu - ti); /* ties: smaller task id first */
+    uint32_t* tmp = sc.over_list[tier];
+    if (n < 2) return;
+    for (uint32_t x = threadIdx.x; x < 16 * CW_SORT_CLASSES; x += 1024) (&cnt[0][0])[x] = 0;
+    __syncthreads();
+    /* every wave owns a contiguous slice of the list in both passes; eight entries per lane in flight (two dependent global reads each) */
+    const uint32_t per = (n + 15u) / 16u, lo = min(n, (uint32_t)wave * per), hi = min(n, lo + per);
+    for (uint32_t x0 = lo; x0 < hi; x0 += 512) {
+        uint32_t ti[8];
+        uint2 nm[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane; ti[j] = x < hi ? list[x] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nm[j] = ti[j] != 0xFFFFFFFFu ? *(const uint2*)&sc.tasks[ti[j]].n_members : make_uint2(0, 0); /* n_members, max_len */
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane;
+            if (ti[j] != 0xFFFFFFFFu) {
+                const uint32_t c = cw_sort_class(nm[j].x, nm[j].y, tier);
+                atomicAdd(&cnt[wave][c], 1u);
+                if (x < CW_SORT_LDS_CLS) cls_lds[x] = (uint8_t)c;
+            }
         }
-        sort_key[x] = kv;
     }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
-        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (uint32_t x = threadIdx.x; x < np2; x += 1024) {
-                const uint32_t y = x ^ j2;
-                if (y > x) {
-                    const unsigned long long ax = sort_key[x], ay = sort_key[y];
-                    const bool desc = (x & k2) == 0;
-                    if ((ax < ay) == desc) { sort_key[x] = ay; sort_key[y] = ax; }
-                }
+    if (threadIdx.x < CW_SORT_CLASSES) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += cnt[w][threadIdx.x]; tot_c[threadIdx.x] = t; }
+    __syncthreads();
+    if (threadIdx.x < CW_SORT_CLASSES) { /* class-major, then wave: exclusive offsets */
+        uint32_t before = 0;
+        for (uint32_t c = 0; c < threadIdx.x; ++c) before += tot_c[c];
+        for (int w = 0; w < 16; ++w) { const uint32_t k = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = before; before += k; }
+    }
+    __syncthreads();
+    for (uint32_t x0 = lo; x0 < hi; x0 += 512) {
+        uint32_t ti[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane; ti[j] = x < hi ? list[x] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane;
+            if (ti[j] != 0xFFFFFFFFu) {
+                uint32_t c;
+                if (x < CW_SORT_LDS_CLS) c = cls_lds[x];
+                else { const uint2 v = *(const uint2*)&sc.tasks[ti[j]].n_members; c = cw_sort_class(v.x, v.y, tier); }
+                tmp[atomicAdd(&cnt[wave][c], 1u)] = ti[j];
             }
-            __syncthreads();
         }
     }
-    for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = 0xFFFFFFFFu - (uint32_t)(sort_key[x] & 0xFFFFFFFFull);
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = tmp[x];
+    if (tier == 3) { /* the live queue of tier L: an entry is its own flag */
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < n; x += 1024) tmp[x] = 0xFFFFFFFFu;
+    }
 }
 
 /* ---- tier G: everything in this wave's global slab (int32 cells) -------------------------------- */
