@@ -93,6 +93,106 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             cw_wave_sync();
 
             /* ================= phase C: chain ================= */
+            /* The recurrence is serial over the anchors, so its cost is the latency of one step.  In the usual case (presence bitsets in
+               LDS, at most 256 sequences) the 64 nearest successors of the current anchor -- all that is looked at unless the early stop
+               fails -- are a register window: lane l holds length, score and presence of anchor a+1+l, shifted by one lane per step
+               (DPP), so that a step neither waits for lane 0's LDS writes of the step before nor re-reads what it already had. */
+            const bool narrow = (uint64_t)A * N < (1ull << 21) && A < 2047u; /* (length + 1, score) fit 11 + 21 bits: a chain's score is at most its length x N */
+            auto wave_best = [&](unsigned long long key, uint32_t b0) -> unsigned long long {
+                if (!narrow) return cw_wave_max_u64(key);
+                const uint32_t hi = key ? (((uint32_t)(key >> 48) << 21) | (uint32_t)((key >> 16) & 0x1FFFFFull)) : 0u;
+                const uint32_t mx = (uint32_t)cw_lane_value((int)cw_wave_scan_max_u32(hi), 63); /* one fused 32-bit prefix max */
+                if (!mx) return 0ull;
+                const unsigned long long who = __ballot(hi == mx); /* the first lane holding it = the smallest b */
+                const uint32_t fb = b0 + (uint32_t)(__ffsll((long long)who) - 1);
+                return ((unsigned long long)(mx >> 21) << 48) | ((unsigned long long)(mx & 0x1FFFFFu) << 16) | (unsigned long long)(0xFFFFu - fb);
+            };
+            if (use_bits && pres_lds && Nw <= 4u) {
+                int r_len = 0, r_sc = 0, sm_run = -1;
+                unsigned long long r_p[4] = {0ull, 0ull, 0ull, 0ull};
+                for (int a = (int)A - 1; a >= 0; --a) {
+                    unsigned long long pa[4];
+#pragma unroll
+                    for (uint32_t x = 0; x < 4; ++x) pa[x] = x < Nw ? lpres[(size_t)a * Nw + x] : 0ull;
+                    unsigned long long best = 0ull;
+                    bool stop = false;
+                    {   /* successors a+1 .. a+64: from the window */
+                        const uint32_t b0 = (uint32_t)a + 1u, bb = b0 + (uint32_t)lane;
+                        unsigned long long key = 0ull;
+                        if (bb < A) {
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t x = 0; x < 4; ++x) cnt += (uint32_t)__popcll(pa[x] & r_p[x]);
+                            if (pd_lds) {
+                                for (uint32_t d = 0; d < n_dirty; ++d) {
+                                    const uint32_t pa_ = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
+                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
+                                }
+                            } else {
+                                for (uint32_t d = 0; d < n_dirty; ++d) {
+                                    const uint32_t sd = gdirty[d];
+                                    const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
+                                }
+                            }
+                            if ((int)cnt >= sup_min)
+                                key = ((unsigned long long)((uint32_t)r_len + 1u) << 48) | ((unsigned long long)((uint32_t)r_sc + cnt) << 16) |
+                                      (unsigned long long)(0xFFFFu - bb);
+                        }
+                        best = wave_best(key, b0);
+                        if (best != 0ull && b0 + 64 < A) stop = (int)smax[b0 + 64] < (int)(best >> 48) - 1;
+                        stop = ch_uni(stop ? 1 : 0) != 0u;
+                    }
+                    if (!stop) {
+                        for (uint32_t b0 = (uint32_t)a + 65u; b0 < A; b0 += 64) { /* farther successors: from LDS (written at least 64 steps ago) */
+                            const uint32_t bb = b0 + (uint32_t)lane;
+                            unsigned long long key = 0ull;
+                            if (bb < A) {
+                                uint32_t cnt = 0;
+                                for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(pa[x < 4 ? x : 0] & lpres[(size_t)bb * Nw + x]);
+                                if (pd_lds) {
+                                    for (uint32_t d = 0; d < n_dirty; ++d) {
+                                        const uint32_t pa_ = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
+                                        cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
+                                    }
+                                } else {
+                                    for (uint32_t d = 0; d < n_dirty; ++d) {
+                                        const uint32_t sd = gdirty[d];
+                                        const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                        cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
+                                    }
+                                }
+                                if ((int)cnt >= sup_min)
+                                    key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
+                                          (unsigned long long)(0xFFFFu - bb);
+                            }
+                            key = wave_best(key, b0);
+                            best = key > best ? key : best;
+                            bool st2 = false;
+                            if (best != 0ull && b0 + 64 < A) st2 = (int)smax[b0 + 64] < (int)(best >> 48) - 1;
+                            if (ch_uni(st2 ? 1 : 0)) break;
+                        }
+                    }
+                    const int la = best == 0ull ? 0 : (int)(best >> 48); /* stored length + 1 of b == length of a */
+                    const int sca = best == 0ull ? 0 : (int)((best >> 16) & 0xFFFFFFFFull);
+                    sm_run = la > sm_run ? la : sm_run;
+                    if (lane == 0) {
+                        clen[a] = (int16_t)la; csc[a] = sca;
+                        cnxt[a] = best == 0ull ? (int16_t)-1 : (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
+                        smax[a] = (int16_t)sm_run;
+                    }
+                    /* slide the window: lane l takes lane l-1, lane 0 takes anchor a */
+                    r_len = cw_wave_shr1(r_len, la);
+                    r_sc = cw_wave_shr1(r_sc, sca);
+#pragma unroll
+                    for (uint32_t x = 0; x < 4; ++x) {
+                        const int lo_ = cw_wave_shr1((int)(uint32_t)r_p[x], (int)(uint32_t)pa[x]);
+                        const int hi_ = cw_wave_shr1((int)(uint32_t)(r_p[x] >> 32), (int)(uint32_t)(pa[x] >> 32));
+                        r_p[x] = ((unsigned long long)(uint32_t)hi_ << 32) | (uint32_t)lo_;
+                    }
+                }
+                cw_wave_sync();
+            } else
             for (int a = (int)A - 1; a >= 0; --a) {
                 unsigned long long best = 0ull;
                 const uint32_t* pa_row = (const uint32_t*)(P + (uint32_t)a * Np);
