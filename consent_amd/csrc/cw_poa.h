@@ -235,11 +235,11 @@ __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(
 __device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_s2, a), __builtin_bit_cast(cw_s2, b))); }
 __device__ __forceinline__ int pk_make(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
 __device__ __forceinline__ int pk_splat_lo(int a) { return __builtin_amdgcn_perm(a, a, 0x05040504); } /* (lo, lo) */
-/* x = (base codes of two columns) ^ (the node's base in both halves): MATCH where a half is zero, MISMATCH elsewhere */
-__device__ __forceinline__ int pk_score(int x) {
-    typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));
-    const cw_u2 m = __builtin_elementwise_min(__builtin_bit_cast(cw_u2, x), (cw_u2)(1)); /* 0 = match, 1 = mismatch */
-    const cw_s2 r = __builtin_bit_cast(cw_s2, m) * (cw_s2)(CW_POA_MISMATCH - CW_POA_MATCH) + (cw_s2)(CW_POA_MATCH);
+/* emask holds, per half, one bit per base the column's sequence position could match (bit b of the half: its base is b); the row's
+   substitution scores are then a shift by the node's base, a mask and one packed multiply-add: MATCH where the bit is set, MISMATCH elsewhere */
+__device__ __forceinline__ int pk_score(int emask, int base) {
+    const int t = (int)(((unsigned)emask >> base) & 0x00010001u);
+    const cw_s2 r = __builtin_bit_cast(cw_s2, t) * (cw_s2)(CW_POA_MATCH - CW_POA_MISMATCH) + (cw_s2)(CW_POA_MISMATCH);
     return __builtin_bit_cast(int, r);
 }
 #define CW_NEG16 (-30000)
@@ -290,7 +290,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         for (int k = 0; k < RC; ++k) rc_[k][c] = jg[c]; /* row 0 */
         amask[c] = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
         const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
-        qpk[c] = pk_make(q0, q1); /* base codes of the lane's two columns (0xFFFF: none, never equal to a node's base) */
+        qpk[c] = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* see pk_score */
     }
     uint32_t meta_n = M.rmeta[0];
     uint32_t pr0_n = M.rpred0[0];
@@ -301,11 +301,10 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
         const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
         int v[NCH2], dgv[NCH2], upv[NCH2], srow[NCH2];
-        const int bpk = base * 0x00010001;
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
             v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK;
-            srow[c] = pk_score(qpk[c] ^ bpk); /* the row's substitution scores, branch-free: (match ? MS : XS) per half */
+            srow[c] = pk_score(qpk[c], base); /* the row's substitution scores, branch-free */
         }
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
