@@ -56,23 +56,20 @@
 #define CW_POAB_LC 1023
 #define CW_POAB_HC ((CW_POAB_NC + 1) * (CW_POAB_LC + 1))
 
-/* bytes of the graph part of a slab (everything but H) */
+/* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
-/* slab tiers: the arrays only the merge touches (aligned-node lists, the scratch of the rank placement, in-edge tails, the per-
-   position results of the merge passes) live in the wave's global slab, so that more waves fit a CU's LDS during the fill and the
-   traceback, which is where the time goes (M1: 12 -> 16 waves per CU) */
-#define CW_POA_HOT_BYTES(NC, EC, LC) (((NC) * 19 + (EC) * 6 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_COLD_BYTES(NC, LC) (((NC) * 10 + 4 * ((LC) + 1) + 255) / 256 * 256)
 #define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
+/* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
+   predecessors, rank <-> node maps, in-edge heads and degrees, bases, sequence ranks); what only the rank bookkeeping before a fill
+   and the merge touch -- aligned-node lists, in-edge lists (source, next) and tails, coverage counts, the scratch of the rank placement,
+   the per-position results of the merge passes -- lives in the wave's global slab ("cold"), a few dependent reads per node there.
+   That is what lets more waves share a CU's LDS where the time goes: M1 6.4 KB per wave (five work-groups per CU), M2 12.9 KB (three
+   waves in 38 KB), L 37 KB (it fits the holes the other tiers leave). */
+#define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
-#define CW_POA_SLAB_TOTAL(NC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD_BYTES(NC, LC))
-/* the slab tiers also keep the in-edge lists and the coverage counts in the slab: only the rank bookkeeping before a fill and the merge
-   walk them, a few dependent reads per node.  M1: 9.5 -> 6.4 KB per wave (five work-groups per CU), M2: 18.9 -> 12.9 KB (a third wave in
-   the same 38 KB), L: 57 -> 37 KB (fits the holes the other tiers leave: it used to wait for 76 KB to fall free) */
-#define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
 #define CW_POA_SLAB2_TOTAL(NC, EC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD2_BYTES(NC, EC, LC))
 
 template <typename HT>
@@ -244,17 +241,6 @@ __device__ __forceinline__ int pk_score(int emask, int base) {
 }
 #define CW_NEG16 (-30000)
 #define CW_NEGPK ((int)0x8AD08AD0) /* (CW_NEG16, CW_NEG16) */
-
-/* inclusive prefix max over lanes of a packed pair (both halves scanned independently) */
-__device__ __forceinline__ int pk_wave_scan_max(int v) {
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x111, 0xF));
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x112, 0xF));
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x114, 0xF));
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x118, 0xF));
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x142, 0xA));
-    v = pk_max(v, CW_DPP(CW_NEGPK, v, 0x143, 0xC));
-    return v;
-}
 
 /* direction-word addressing: unpacked rows hold 2 words per 64 columns; packed rows 4 words per 128 columns
    (even columns, odd columns) x (low bit, high bit), bit = lane that owns the column pair */
@@ -946,7 +932,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         }
     }
     if (TIER == 3 && (PASS == 1 || blockIdx.x < sc.linger_wgs)) {
-        /* Live queue (only the first few work-groups stay for it: a lingering tier-L work-group holds 76 KiB of LDS that
+        /* Live queue (only the first few work-groups stay for it: a lingering tier-L work-group holds 37 KB of LDS that
            the other tiers could use): tasks that outgrow tiers S/M1/M2 while those kernels are still running on their own streams are
            picked up here at once instead of waiting for a later pass.  An entry is its own flag (0xFFFFFFFF = not yet
            written); we stop when every producing work-group has signed off and the queue is drained.  Every wait is

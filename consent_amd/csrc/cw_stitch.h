@@ -16,7 +16,7 @@
 #define CW_STITCH_H
 
 #include "cw_device.h"
-#include "cw_poa.h" /* packed int16 helpers (pk_add, pk_max, pk_wave_scan_max, ...) */
+#include "cw_poa.h" /* packed int16 helpers (pk_add, pk_max, pk_splat_lo, ...) */
 
 #define CW_ST_WAVES 4
 #define CW_ST_QMAX 2048 /* consensus length */
