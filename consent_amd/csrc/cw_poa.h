@@ -182,7 +182,8 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
                     for (int k = 1; k < RC; ++k) up[c] = (dist == k + 1) ? rc_[k][c] : up[c];
                 }
             } else {
-                cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
+                /* no fence: a lane reads back only the columns it wrote itself (program order of one work-item), and a fence here
+                   would wait for the store of the row just finished before the load could even be issued */
                 const int pr = prow * cols;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -304,7 +305,8 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
                     for (int k = 1; k < RC; ++k) up[c] = (dist == k + 1) ? rc_[k][c] : up[c];
                 }
             } else {
-                cw_wave_sync(); /* rows written by other lanes of this wave must have landed */
+                /* no fence: a lane reads back only the columns it wrote itself (program order of one work-item), and a fence here
+                   would wait for the store of the row just finished before the load could even be issued */
 #pragma unroll
                 for (int c = 0; c < NCH2; ++c) {
                     const int j0 = c * 128 + 2 * lane;
