@@ -66,6 +66,7 @@
    That is what lets more waves share a CU's LDS where the time goes: M1 6.4 KB per wave (five work-groups per CU), M2 12.9 KB (three
    waves in 38 KB), L 37 KB (it fits the holes the other tiers leave). */
 #define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16) /* + the chain tables p2/p4 (tier M1) */
 #define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
@@ -79,6 +80,8 @@ struct PoaMem {
                                  1 vertical through the first predecessor, 2 horizontal, 3 = compare cell values */
     uint32_t* rmeta;    /* rank -> base | n_pred << 2 | csr offset << 16 (n_pred counts the virtual start as 1) */
     uint16_t* rpred0;   /* rank -> DP row of its first predecessor (0 = virtual start)                           */
+    uint16_t* p2;       /* rank -> DP row two / four steps up the first-predecessor chain, CW_NONE16 beyond the start */
+    uint16_t* p4;       /* (only where the traceback walks matrix tiles: tier M1; else NULL)                      */
     uint16_t* plist;    /* predecessor DP rows in in-edge order (CSR); doubles as a u32 histogram during merges  */
     uint16_t* ncov;     /* node -> sequences through it                                                          */
     uint16_t* nal;      /* node -> 3 aligned node ids                                                            */
@@ -104,7 +107,7 @@ struct PoaMem {
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
                                                 HT* h_ext = nullptr, unsigned long long* d_ext = nullptr, uint8_t* cold = nullptr,
-                                                bool cold_edges = false) {
+                                                bool cold_edges = false, bool chain_tabs = false) {
     PoaMem<HT> M;
     uint8_t* p = base;
     uint8_t* pc = cold; /* merge-only arrays: in the slab when given, else with the rest */
@@ -116,6 +119,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
     if (!(pc && cold_edges)) { M.efrom = (uint16_t*)p; p += 2 * ec; M.enext = (uint16_t*)p; p += 2 * ec; }
     M.rpred0 = (uint16_t*)p; p += 2 * nc;
+    if (chain_tabs) { M.p2 = (uint16_t*)p; p += 2 * nc; M.p4 = (uint16_t*)p; p += 2 * nc; } else { M.p2 = nullptr; M.p4 = nullptr; }
     if (!(pc && cold_edges)) { M.ncov = (uint16_t*)p; p += 2 * nc; }
     if (pc) { M.nal = (uint16_t*)pc; pc += 6 * nc; } else { M.nal = (uint16_t*)p; p += 6 * nc; }
     M.in_head = (uint16_t*)p; p += 2 * nc;
@@ -471,6 +475,18 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             }
             meta_ok = true;
             cw_wave_sync();
+            if (M.p2) { /* two and four steps up the first-predecessor chain: a traceback tile gets its eight rows in three reads, not seven */
+                for (int r = lane; r < n; r += 64) {
+                    const int a = M.rpred0[r];
+                    M.p2[r] = a > 0 ? M.rpred0[a - 1] : CW_NONE16;
+                }
+                cw_wave_sync();
+                for (int r = lane; r < n; r += 64) {
+                    const uint32_t b2 = M.p2[r];
+                    M.p4[r] = (b2 != CW_NONE16 && b2 > 0) ? M.p2[b2 - 1] : CW_NONE16;
+                }
+                cw_wave_sync();
+            }
         }
         POA_PROF(0);
 
@@ -594,13 +610,19 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 const int tr = lane >> 3, tc = lane & 7;
                 while (i > 0) {
                     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
-                    int ch[8];
-                    ch[0] = i;
+                    int row = i;
+                    if (M.p2) { /* tr steps up the chain: 4 + 2 + 1 */
+                        if (tr & 4) { const uint32_t v = M.p4[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; }
+                        if (tr & 2) { if (row > 0) { const uint32_t v = M.p2[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; } else row = -1; }
+                        if (tr & 1) row = row > 0 ? (int)M.rpred0[row - 1] : -1;
+                    } else {
+                        int ch[8];
+                        ch[0] = i;
 #pragma unroll
-                    for (int q = 1; q < 8; ++q) ch[q] = ch[q - 1] > 0 ? (int)M.rpred0[ch[q - 1] - 1] : -1;
-                    int row = ch[0];
+                        for (int q = 1; q < 8; ++q) ch[q] = ch[q - 1] > 0 ? (int)M.rpred0[ch[q - 1] - 1] : -1;
 #pragma unroll
-                    for (int q = 1; q < 8; ++q) row = (tr == q) ? ch[q] : row;
+                        for (int q = 1; q < 8; ++q) row = (tr == q) ? ch[q] : row;
+                    }
                     const int col = j - tc;
                     const bool valid = row >= 0 && col >= 0;
                     const int hv = valid ? (int)M.H[row * hs + col] : 0;
@@ -906,9 +928,9 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
-    constexpr uint32_t slab = CW_POA_HOT2_BYTES(NC, EC, LC);
+    constexpr uint32_t slab = TIER == 1 ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 2 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
-                                           true);
+                                           true, TIER == 1);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
