@@ -142,6 +142,37 @@ def test_high_identity_deep_piles_use_the_global_anchor_matrix(engines):
     assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:3])
 
 
+def test_pile_layout_in_memory_does_not_matter(engines):
+    """The index kernel stages a pile in LDS when its sequences lie front to back in `bases`; any other layout (here: sequences stored
+    in reverse order, with gaps) takes the global-memory path and must give the same results."""
+    rng = random.Random(41)
+    piles = []
+    for _ in range(6):
+        truth = rand_seq(rng, 520)
+        piles.append([truth[:500]] + [mutate(rng, truth[rng.randrange(0, 15) : 500 + rng.randrange(0, 20)], 0.12) for _ in range(24)])
+    prm = (9, 4, 8, 2, 20)
+    hb = ca.pack_piles(piles)
+    n = len(hb.seq_len)
+    words = [(int(l) + 15) // 16 for l in hb.seq_len]
+    new_off = np.zeros(n, np.uint64)
+    pos = 3
+    for s in reversed(range(n)):  # last sequence first, 5 unused words between sequences
+        new_off[s] = pos
+        pos += words[s] + 5
+    bases = np.full(pos + 1, 0xDEADBEEF, np.uint32)
+    for s in range(n):
+        o = int(hb.seq_word_off[s])
+        bases[int(new_off[s]) : int(new_off[s]) + words[s]] = hb.bases[o : o + words[s]]
+    from consent_amd.engine import HostBatch
+
+    shuffled = HostBatch(hb.win_first_seq, hb.seq_len, new_off, bases)
+    a = engines(*prm).run(hb)
+    b = engines(*prm).run(shuffled)
+    assert_same(b, a, len(piles), "layout")
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=3)
+    assert_same(a, exp, len(piles), "layout/oracle")
+
+
 def test_very_deep_piles_score_chains_without_presence_bitsets(engines):
     """More than 2048 sequences in a pile: no presence bitsets, the chain kernel compares positions row against row, and the
     segmentation loops over the pile in several 64-sequence chunks."""
