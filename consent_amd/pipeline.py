@@ -28,13 +28,15 @@ class _DeviceReads:
 
 
 def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=1000, window_size=500, mer_size=9, common_kmers=8,
-                  min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150, do_trim=True, proof_path=None, windows_per_batch=8192,
+                  min_anchors=10, solid_thresh=4, window_overlap=50, max_msa=150, do_trim=True, proof_path=None, windows_per_batch=32768,
                   device=0, on_capacity="raise"):
     """Corrects every read that has a pile in `paf_path`; writes FASTA (">name\\nsequence\\n", upper case = corrected) to `out`
     (a text file object; None = collect) and returns the list of (name, sequence) in PAF order.  Reads whose corrected
     sequence is empty -- no window, or dropped by the 10 % rule -- are skipped, as CONSENT-correction.cpp:101-103 does.
     With `proof_path` (assembly polishing, or correction against proof reads) that file is indexed into the same read set and the
     result is neither trimmed nor dropped (CONSENT-correction.cpp:69-73, CONSENT-polishing.cpp:112-116).
+    `windows_per_batch`: piles are collected until they hold this many windows, then extracted, corrected and re-assembled in one go;
+    re-assembly runs one wave per read, so a batch should hold a few thousand reads (32768 windows of 500 bases at depth 30 are ≈ 0.3 GB).
     `on_capacity`: a read whose re-assembly (or one of whose windows) exceeded a documented capacity of the engine either stops the run
     ("raise", the default: nothing is silently different from the reference) or is left out of the output and reported on stderr ("skip")."""
     import torch
