@@ -32,7 +32,7 @@
 #define CW_POA_EC 384   /* edges            */
 #define CW_POA_LC 127   /* member length    */
 #define CW_POA_HC 2048  /* DP cells (int16) */
-#define CW_POA_DC 96    /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
+#define CW_POA_DC 0     /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
 #define CW_POA_WAVES 4
 /* tiers M1 / M2 / L: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2 / Infinity-Cache
    resident.  Direction words are off there: they cost more occupancy than they save (measured). */
@@ -58,7 +58,7 @@
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
+#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + 4 * CW_POA_NC + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
    predecessors, rank <-> node maps, in-edge heads and degrees, bases, sequence ranks); what only the rank bookkeeping before a fill
    and the merge touch -- aligned-node lists, in-edge lists (source, next) and tails, coverage counts, the scratch of the rank placement,
@@ -895,7 +895,8 @@ __device__ __forceinline__ void poa_producer_done(const DevScratch& sc) {
 __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC, CW_POA_DC);
+    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC, CW_POA_DC, nullptr, nullptr, nullptr,
+                                                 false, true);
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
