@@ -146,13 +146,13 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
@@ -240,7 +240,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
 #define M2_ARGS CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2
 #define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
     const size_t lds_m1 = CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
-    const size_t lds_m2 = CW_POA_HOT2_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
+    const size_t lds_m2 = CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
     const size_t lds_l = CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
@@ -280,7 +280,7 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     cw_poa_slab_kernel<M1_ARGS, 0><<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
     sid = stage_begin(e, st, "poa");
-    cw_poa_kernel<<<cus * 3, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 12.3 KiB per wave: three work-groups per CU */
+    cw_poa_kernel<<<cus * 3, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, st, sid);
     for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
