@@ -933,7 +933,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
                                            true, TIER <= 2);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
-    M.runs = TIER >= 2; /* long graphs against short members: long vertical runs */
+    M.runs = TIER >= 3; /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
