@@ -19,6 +19,13 @@
 
 namespace {
 
+/* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
+static_assert(3 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: three work-groups per CU");
+static_assert(5 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: five work-groups per CU");
+static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
+static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
+static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct TierCfg { uint32_t slots; size_t slab_bytes; };
