@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- window-correction hot path on synthetic PacBio-profile piles (BASELINE.json configs[1] by default).
+"""bench.py -- window-correction hot path on synthetic PacBio-profile piles.
 
-One "step" = one pass of the hot path (index -> POA -> finish kernels, cw_run_device) over one batch of
-synthetic window piles that is already resident in HBM.  Rank r of N works on its own shard of windows
-(window ids disjoint by rank; no collective on the data path -- windows are independent), so scaling is weak.
-Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+Default workload = BASELINE.json configs[2], the configuration the headline metric is quoted on: depth 150, maxMSA 150, 500 bp
+windows, k=9 (`--workload pacbio_d30_msa20` = configs[1], the shallow path).
+
+One "step" = one pass of the hot path (setup -> index -> chain -> POA tiers -> finish kernels, cw_run_device) over one batch of
+synthetic window piles that is already resident in HBM.  Every step of a run works on its OWN batch of windows (window ids are
+disjoint across steps and ranks; all batches are generated on the device before the clock starts and stay resident -- 25 batches of
+depth-150 piles are 9 GB of the 288), so `steps x windows_per_step x n_gpus` distinct windows are corrected per run (20 steps =
+327 680 >= 2^18).  Rank r of N works on its own windows; there is no collective on the data path (windows are
+independent), so scaling is weak.  `python bench.py --gpus N` without a torch.distributed environment re-launches itself as N ranks.
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +30,9 @@ WORKLOADS = {
     "pacbio_d30_msa20": (30, 20, 16384),
     "pacbio_d150_msa150": (150, 150, 16384),
 }
+DEFAULT_WORKLOAD = "pacbio_d150_msa150"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MAX_RESIDENT_BATCHES = 48  # distinct input batches kept in HBM; runs with more steps than this cycle through them
 
 
 def algorithmic_bytes(seq_len, n_windows, cons_len, solid_len):
@@ -49,15 +58,33 @@ def effective_cores():
     return n
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torch.distributed: become the launcher of N ranks (one per GPU) and relay their output."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pacbio_d30_msa20", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
+    ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -86,7 +113,7 @@ def main():
         backend = None
 
     import consent_amd as ca
-    from consent_amd.engine import Batch, Result, synth_host
+    from consent_amd.engine import Batch, HostBatch, Result, alloc_results, synth_host
 
     depth, max_msa, n_win = WORKLOADS[args.workload]
     if args.windows > 0:
@@ -96,20 +123,27 @@ def main():
     lib = eng.lib
     dev = torch.device("cuda", local_rank)
 
-    # --- synthetic shard of this rank, generated on the device -------------------------------------
-    spec = ca.SynthSpec.pacbio(n_win, depth, first_window=rank * n_win)
+    # --- every step's batch, generated on the device, resident before the clock starts; window ids disjoint by (rank, step) -------
+    n_batches = min(args.warmup + args.steps, MAX_RESIDENT_BATCHES)
     ns, nw = C.c_uint32(), C.c_uint64()
-    assert lib.cw_synth_sizes(C.byref(spec), C.byref(ns), C.byref(nw)) == 0
+    spec0 = ca.SynthSpec.pacbio(n_win, depth)
+    assert lib.cw_synth_sizes(C.byref(spec0), C.byref(ns), C.byref(nw)) == 0
     n_seqs, n_words = ns.value, nw.value
-    t_wfs = torch.zeros(n_win + 1, dtype=torch.int32, device=dev)
-    t_len = torch.zeros(n_seqs, dtype=torch.int32, device=dev)
-    t_off = torch.zeros(n_seqs, dtype=torch.int64, device=dev)
-    t_bases = torch.zeros(n_words + 4, dtype=torch.int32, device=dev)
-    rc = lib.cw_synth_device(eng.handle, C.byref(spec), t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr(), None)
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-    cons_cap = 3 * spec.window_len + 256
-    solid_cap = (depth + 1) * (spec.window_len + 24) // prm.solid + 16
+    batches, keep = [], []
+    for i in range(n_batches):
+        spec = ca.SynthSpec.pacbio(n_win, depth, first_window=(rank * (args.warmup + args.steps) + i) * n_win)
+        t_wfs = torch.zeros(n_win + 1, dtype=torch.int32, device=dev)
+        t_len = torch.zeros(n_seqs, dtype=torch.int32, device=dev)
+        t_off = torch.zeros(n_seqs, dtype=torch.int64, device=dev)
+        t_bases = torch.zeros(n_words + 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        rc = lib.cw_synth_device(eng.handle, C.byref(spec), t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr(), None)
+        assert rc == 0, rc
+        keep.append((t_wfs, t_len, t_off, t_bases))
+        batches.append(Batch(n_win, n_seqs, n_words, t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr()))
+    torch.cuda.synchronize(dev)
+    cons_cap = 3 * spec0.window_len + 256
+    solid_cap = (depth + 1) * (spec0.window_len + 24) // prm.solid + 16
     t_cons = torch.zeros(n_win * cons_cap, dtype=torch.uint8, device=dev)
     t_coff = (torch.arange(n_win + 1, dtype=torch.int64, device=dev) * cons_cap)
     t_clen = torch.zeros(n_win, dtype=torch.int32, device=dev)
@@ -117,58 +151,51 @@ def main():
     t_solid = torch.zeros(n_win * solid_cap, dtype=torch.int32, device=dev)
     t_soff = (torch.arange(n_win + 1, dtype=torch.int64, device=dev) * solid_cap)
     t_slen = torch.zeros(n_win, dtype=torch.int32, device=dev)
-    b = Batch(n_win, n_seqs, n_words, t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr())
     r = Result(t_cons.data_ptr(), t_coff.data_ptr(), t_clen.data_ptr(), t_stat.data_ptr(), t_solid.data_ptr(), t_soff.data_ptr(), t_slen.data_ptr())
+    torch.cuda.synchronize(dev)
 
-    def step():
-        eng.run_device(b, r)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    for i in range(args.warmup):
+        eng.run_device(batches[i % n_batches], r)
+    torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     stage_ms = {}
+    n_over = n_tpl = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in eng.timings().items():  # HIP events on the launch stream (cw_last_timings)
+    for i in range(args.steps):
+        eng.run_device(batches[(args.warmup + i) % n_batches], r)
+        for k, v in eng.timings().items():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
             stage_ms.setdefault(k, []).append(v)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    last = (args.warmup + args.steps - 1) % n_batches
     status = t_stat.cpu().numpy()
     n_over = int((status == ca.WIN_OVERFLOW).sum())
+    n_tpl = int((status == ca.WIN_TEMPLATE).sum())
     clen = t_clen.cpu().numpy()
     slen = t_slen.cpu().numpy()
-    seq_len = t_len.cpu().numpy()
+    seq_len = keep[last][1].cpu().numpy()
     alg_bytes = algorithmic_bytes(seq_len, n_win, clen, slen)
     stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
     kern_avg = {k: v for k, v in stage_avg.items() if k != "total"}
+    # the dominant kernel is the launch that bounds the step: the longest one (the POA tier kernels run concurrently between one
+    # fork and one join, so the longest of them is what the stage waits for)
     dom = max(kern_avg, key=kern_avg.get) if kern_avg else None
-    busy_share = None
     tier_stage = ["poa", "poa_m1", "poa_m2", "poa_large"]
-    if dom in tier_stage:
-        # the four POA tier kernels run concurrently between one fork and one join, and a few work-groups of tier L stay until the
-        # others have signed off (live overflow queue), so tier L's wall time is always the longest even when it has next to no work:
-        # the dominant kernel is the longest-running tier among those that did a real share (>= 10 %) of the POA wave-cycles
-        # (per-tier cycle totals the kernels keep, last step)
-        _, prof = eng.profile()
-        busy = [float(prof[8 + 5 * t : 13 + 5 * t].sum()) for t in range(4)]
-        if sum(busy) > 0:
-            share = {tier_stage[t]: busy[t] / sum(busy) for t in range(4)}
-            real = [k for k in tier_stage if share[k] >= 0.10 and k in kern_avg]
-            if real:
-                dom = max(real, key=kern_avg.get)
-                busy_share = share[dom]
+    busy_share = None
+    _, prof = eng.profile()
+    busy = [float(prof[8 + 5 * t : 13 + 5 * t].sum()) for t in range(4)]
+    if sum(busy) > 0:
+        busy_share = {tier_stage[t]: busy[t] / sum(busy) for t in range(4)}
     total_windows = n_win * world * args.steps
     value = total_windows / dt
 
@@ -176,7 +203,7 @@ def main():
         "metric": "corrected windows/sec",
         "value": value,
         "unit": "windows/s",
-        "bases_per_sec": value * spec.window_len,
+        "bases_per_sec": value * spec0.window_len,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -189,23 +216,24 @@ def main():
         "config": {
             "workload": f"{args.workload}: synthetic PacBio-profile piles, 500 bp windows, depth {depth}, maxMSA {max_msa}, k=9, solid=4, commonKMers=8, minAnchors=2",
             "windows_per_step_per_gpu": n_win,
+            "distinct_windows_per_run": n_win * world * min(args.steps, max(1, n_batches - args.warmup)),
             "sharding": "windows by rank, no collective",
             "overflow_windows": n_over,
-            "template_fallback_windows": int((status == ca.WIN_TEMPLATE).sum()),
+            "template_fallback_windows": n_tpl,
         },
         "stage_ms": stage_avg,
     }
-    stage_kernel = {"index": "cw_index_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512", "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0>",
-                    "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
+    stage_kernel = {"index": "cw_index_kernel", "chain": "cw_chain_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512",
+                    "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0>", "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
     traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
-    if dom and os.path.exists(prof):
+    prof_json = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
+    if dom and os.path.exists(prof_json):
         try:  # HBM-side bytes of the dominant kernel from the separate --pmc passes of the same command (tools/profile_round.sh)
-            pj = json.load(open(prof))
+            pj = json.load(open(prof_json))
             if pj.get("windows_per_step") == n_win:
                 for name, k in pj["kernels"].items():
                     if stage_kernel.get(dom, "?") in name and "traffic_bytes_per_launch" in k:
-                        traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(prof, ROOT)
+                        traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(prof_json, ROOT)
         except Exception:
             pass
     if dom:
@@ -214,7 +242,8 @@ def main():
         out["roofline"] = {
             "bound": "hbm",
             "kernel": dom,
-            "kernel_busy_share_of_poa": busy_share,
+            "kernel_symbol": stage_kernel.get(dom),
+            "poa_tier_share_of_wave_cycles": busy_share,
             "achieved": ach,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -223,18 +252,62 @@ def main():
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_window": alg_bytes / n_win,
             "launch_ms": stage_avg[dom],
+            "frac_of_whole_step": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
+
+    # --- PCIe-inclusive rate: the same batches through cw_submit / cw_wait from pinned host memory, two batches in flight --------
+    if rank == 0 and world == 1 and args.pcie_steps != 0:
+        n_p = args.pcie_steps if args.pcie_steps > 0 else max(4, min(args.steps, 8))
+        n_host = min(3, n_batches)
+        host = []
+        for i in range(n_host):  # pinned copies of resident batches (generating them on the host would take minutes)
+            hw = [t.cpu().pin_memory() for t in keep[i]]
+            host.append((hw, Batch(n_win, n_seqs, n_words, hw[0].data_ptr(), hw[1].data_ptr(), hw[2].data_ptr(), hw[3].data_ptr())))
+        coff_h = (np.arange(n_win + 1, dtype=np.uint64) * cons_cap)
+        soff_h = (np.arange(n_win + 1, dtype=np.uint64) * solid_cap)
+        res_h = []
+        for _ in range(2):
+            arrs = (np.zeros(n_win * cons_cap, np.uint8), np.zeros(n_win, np.uint32), np.zeros(n_win, np.uint8), np.zeros(n_win * solid_cap, np.uint32), np.zeros(n_win, np.uint32))
+            res_h.append((arrs, Result(arrs[0].ctypes.data, coff_h.ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, soff_h.ctypes.data, arrs[4].ctypes.data)))
+
+        def submit(i):
+            t = C.c_int(-1)
+            rc_ = lib.cw_submit(eng.handle, C.byref(host[i % n_host][1]), C.byref(res_h[i % 2][1]), C.byref(t))
+            assert rc_ == 0, rc_
+            return t.value
+
+        t_prev = submit(0)  # warm-up: allocations, pinned staging
+        assert lib.cw_wait(eng.handle, t_prev) in (0, -4)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        t_prev = submit(0)
+        for i in range(1, n_p):
+            t_cur = submit(i)
+            assert lib.cw_wait(eng.handle, t_prev) in (0, -4)
+            t_prev = t_cur
+        assert lib.cw_wait(eng.handle, t_prev) in (0, -4)
+        pdt = time.perf_counter() - t1
+        in_mb = sum(t.numel() * t.element_size() for t in host[0][0]) / 1e6
+        out_mb = (int(clen.sum()) + 4 * int(slen.sum()) + 9 * n_win) / 1e6
+        out["value_pcie_inclusive"] = n_win * n_p / pdt
+        out["pcie_inclusive"] = {
+            "value": n_win * n_p / pdt, "unit": "windows/s", "batches": n_p, "ms_per_batch": pdt / n_p * 1e3,
+            "h2d_mb_per_batch": in_mb, "d2h_mb_per_batch": out_mb,
+            "path": "cw_submit/cw_wait (= cw_run in two halves), inputs in pinned host memory, two batches in flight, results compacted on the device and only the used bytes copied back, then scattered to the caller's (pageable) arrays",
+        }
+        del host, res_h
 
     # --- CPU baseline: the oracle (a scalar restatement, "port") on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import subprocess
 
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        native_dir = f"/tmp/cw_oracle_native_{os.getpid()}"  # built for THIS host's CPU, here, never shipped
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", f"OUT={native_dir}"])
+        os.environ["CW_ORACLE_LIB"] = os.path.join(native_dir, "liboracle.so")
         import oracle_lib
 
         cores = effective_cores()
-        n_s = args.cpu_sample if args.cpu_sample > 0 else max(cores * (256 if depth > 60 else 1024), 64)
+        n_s = args.cpu_sample if args.cpu_sample > 0 else max(cores * (128 if depth > 60 else 1024), 64)
         n_s = min(n_s, n_win)
         hb = synth_host(ca.SynthSpec.pacbio(n_s, depth))
         # one worker PROCESS per core, each running the scalar oracle on a contiguous slice (threads of one process
@@ -252,7 +325,7 @@ def main():
 
         ctx = mp.get_context("fork")
         go, q = ctx.Event(), ctx.Queue()
-        procs = [ctx.Process(target=_work, args=(*shard_range(n_s, r, cores), go, q)) for r in range(cores) if shard_range(n_s, r, cores)[1] > shard_range(n_s, r, cores)[0]]
+        procs = [ctx.Process(target=_work, args=(*shard_range(n_s, r_, cores), go, q)) for r_ in range(cores) if shard_range(n_s, r_, cores)[1] > shard_range(n_s, r_, cores)[0]]
         for pr in procs:
             pr.start()
         time.sleep(0.5)
@@ -263,8 +336,8 @@ def main():
         cdt = time.perf_counter() - t1
         for pr in procs:
             pr.join()
-        exp, ost = oracle_lib.oracle_run(prm, hb.slice(0, min(n_s, 256)), threads=min(cores, 32))
         n_st = min(n_s, 256)
+        exp, ost = oracle_lib.oracle_run(prm, hb.slice(0, n_st), threads=min(cores, 32))
         # secondary, interpretable rates: the path is integer DP, far from the HBM roof by construction
         out["secondary"] = {
             "poa_dp_cells_per_window": ost["dp_cells"] / n_st,
@@ -274,15 +347,15 @@ def main():
             "note": "cell and alignment counts from the oracle on the first windows of the workload; GCUPS = cells/window x windows/s",
         }
         # parity spot-check of the same windows on the GPU
-        n_chk = min(n_s, 256)
-        got = eng.run(hb.slice(0, n_chk))
-        same = all(got.consensus(w) == exp.consensus(w) and got.status[w] == exp.status[w] for w in range(n_chk))
+        got = eng.run(hb.slice(0, n_st))
+        same = all(got.consensus(w) == exp.consensus(w) and got.status[w] == exp.status[w] for w in range(n_st))
         out["cpu_baseline"] = {
             "value": n_s / cdt,
             "unit": "windows/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"first {n_s} windows of the same workload, oracle/liboracle.so, {len(procs)} single-thread worker processes (= usable cores: affinity capped by the cgroup CPU quota; the box shows {os.cpu_count()} logical CPUs), consensus stage only",
+            "simd": False,
+            "sample": f"first {n_s} windows of the same workload, oracle/liboracle.so (scalar C++ restatement, -O3 -march=native, no SIMD POA: the real reference's spoa is vectorised), {len(procs)} single-thread worker processes (= usable cores: affinity capped by the cgroup CPU quota; the box shows {os.cpu_count()} logical CPUs), consensus stage only",
             "gpu_identical_on_sample": bool(same),
         }
     if rank == 0 and os.environ.get("CW_PROFILE"):

@@ -3,6 +3,7 @@
  * host-buffer staging, per-stage timing.  C ABI declared in include/consent_amd.h.
  */
 #include "cw_internal.h"
+#include "cw_private.h"
 #include "cw_device.h"
 #include "cw_index.h"
 #include "cw_chain.h"
@@ -10,6 +11,7 @@
 #include "cw_finish.h"
 #include "cw_extract.h"
 #include "cw_stitch.h"
+#include "cw_pack.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +52,7 @@ struct ScratchPlan {
     TierCfg tier[CW_TIERS];
 };
 
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_words, int cus, uint32_t big_slots) {
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t big_slots) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
@@ -74,9 +76,10 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint64_t n_wo
     for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
-    /* anchor blocks: the position matrix is at most 2 bytes per (template k-mer, sequence) <= 8x the packed pile; the rest is
-       per template k-mer */
-    p.ablock_units = ((uint64_t)n_words * 4 * 10 + (uint64_t)n_windows * ((CW_TMAX + 16) * 16ull + 8192)) / 16 + 64;
+    /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
+       sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
+       (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
+    p.ablock_units = ((uint64_t)n_seqs * (2ull * CW_TMAX + 2 + CW_TMAX / 8) + (uint64_t)n_windows * (CW_TMAX * (4ull + 8 + 8) + 256)) / 16 + 64;
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);
@@ -96,6 +99,30 @@ int check_params(const cw_params* p) {
     if (!p) return CW_E_INVALID;
     if (p->k < 2 || p->k > 16) return CW_E_INVALID; /* k-mers are 32-bit keys; k <= 9 counts in a direct LDS table, larger k in a hashed one */
     if (p->solid < 1 || p->max_msa < 1) return CW_E_INVALID;
+    return CW_OK;
+}
+
+int set_kernel_attributes() {
+    const int lds_st = CW_ST_WAVES * CW_ST_SLAB;
+    if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess)
+        return CW_E_NO_DEVICE;
     return CW_OK;
 }
 
@@ -134,7 +161,6 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CW_E_NO_DEVICE;
     cw_engine* e = new (std::nothrow) cw_engine();
     if (!e) return CW_E_NOMEM;
-    memset(e, 0, sizeof(*e));
     e->prm = *params;
     e->device = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&e->prop, device) != hipSuccess ||
@@ -143,29 +169,16 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         return CW_E_NO_DEVICE;
     }
     bool ok = hipEventCreate(&e->ev_fork) == hipSuccess && hipEventCreate(&e->ev_begin) == hipSuccess && hipEventCreate(&e->ev_end) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&e->host_fb, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) memset(e->host_fb, 0, 64);
     for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < CW_MAX_STAGES && ok; ++i) ok = hipEventCreate(&e->ev0[i]) == hipSuccess && hipEventCreate(&e->ev1[i]) == hipSuccess;
-    if (!ok) { delete e; return CW_E_NO_DEVICE; }
-    if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess) {
-        delete e;
-        return CW_E_NO_DEVICE;
-    }
+    for (int i = 0; i < CW_SLOTS && ok; ++i)
+        ok = hipEventCreateWithFlags(&e->slot[i].ev_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->slot[i].ev_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { cw_destroy(e); return CW_E_NO_DEVICE; }
+    /* kernel attributes are per device: set them here, once per engine (not behind a process-wide flag) */
+    if (set_kernel_attributes() != CW_OK) { cw_destroy(e); return CW_E_NO_DEVICE; }
     *out = e;
     return CW_OK;
 }
@@ -173,34 +186,53 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
 void cw_destroy(cw_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    (void)hipDeviceSynchronize();
     if (e->scratch) (void)hipFree(e->scratch);
-    if (e->dev_in) (void)hipFree(e->dev_in);
-    if (e->dev_out) (void)hipFree(e->dev_out);
+    for (int i = 0; i < CW_SLOTS; ++i) {
+        cw_slot& s = e->slot[i];
+        if (s.dev_in) (void)hipFree(s.dev_in);
+        if (s.dev_out) (void)hipFree(s.dev_out);
+        if (s.pin_out) (void)hipHostFree(s.pin_out);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    }
     if (e->xscratch) (void)hipFree(e->xscratch);
     if (e->stitch_scratch) (void)hipFree(e->stitch_scratch);
+    if (e->host_fb) (void)hipHostFree(e->host_fb);
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
     for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
+    if (e->copy_out) (void)hipStreamDestroy(e->copy_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
-int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
+} // extern "C"
+
+namespace {
+
+/* the body of cw_run_device; the caller holds e->mu */
+int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
     if (!e || !batch || !res || !res->cons || !res->cons_off || !res->cons_len || !res->win_status) return CW_E_INVALID;
     if ((res->solid != nullptr) != (res->solid_off != nullptr) || (res->solid != nullptr) != (res->solid_len != nullptr)) return CW_E_INVALID;
     if (batch->n_windows == 0) return CW_OK;
     if (!batch->win_first_seq || !batch->seq_len || !batch->seq_word_off || !batch->bases) return CW_E_INVALID;
+    /* per-window offsets into the arena, the solid table and the segment table are 32-bit (WinInfo, PoaTask): a batch is
+       limited so that none of them can wrap -- split larger inputs (the library's own drivers do) */
+    if (batch->n_windows > CW_MAX_BATCH_WINDOWS) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
 
     uint32_t big_slots = 256;
     if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_words, cus, big_slots);
-    e->last_windows = batch->n_windows; e->last_words = batch->n_words; e->last_big_slots = big_slots;
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots);
+    if (p.solid_cap > 0xFFFFFFFFull || p.seg_cap > 0xFFFFFFFFull || p.arena_cap > 0xFFFFFFFFull) return CW_E_INVALID; /* see CW_MAX_BATCH_WINDOWS */
+    e->last_windows = batch->n_windows; e->last_seqs = batch->n_seqs; e->last_words = batch->n_words; e->last_big_slots = big_slots;
+    e->last_ctr_off = p.ctr;
     int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)e->scratch;
@@ -218,14 +250,12 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     sc.members = (PoaMember*)(base + p.members); sc.member_cap = p.member_cap;
     sc.ctr = (BatchCounters*)(base + p.ctr);
     sc.list_cap = p.task_cap;
-    /* how many tier-L work-groups stay on the live overflow queue: about half of what the previous batch handed over
-       (few when nothing overflows, since a lingering work-group holds LDS the other tiers could use) */
-    if (e->timings_valid && e->scratch && hipEventQuery(e->ev_end) == hipSuccess) {
-        BatchCounters c;
-        if (hipMemcpy(&c, base + p.ctr, sizeof(uint32_t) * 32, hipMemcpyDeviceToHost) == hipSuccess) {
-            uint32_t want = c.n_over[3] / 2;
-            e->linger_wgs = want < 16 ? 16 : want > 256 ? 256 : want;
-        }
+    /* how many tier-L work-groups stay on the live overflow queue: about half of what the last finished batch handed over (few when
+       nothing overflows, since a lingering work-group holds LDS the other tiers could use).  The count arrives in pinned host memory
+       by an asynchronous copy at the end of each run: nothing here waits for the device */
+    if (e->timings_valid) { /* a run has been enqueued before: its count, or that of the one before it, is there */
+        const uint32_t want = e->host_fb[0] / 2;
+        e->linger_wgs = want < 16 ? 16 : want > 256 ? 256 : want;
     }
     sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
     sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
@@ -302,6 +332,8 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
         cw_finish_kernel<<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
     }
     stage_end(e, st, sid);
+    /* feedback for the next batch's linger_wgs (pinned destination: asynchronous) */
+    CW_HIP(hipMemcpyAsync(&e->host_fb[0], &sc.ctr->n_over[3], 4, hipMemcpyDeviceToHost, st));
     CW_HIP(hipEventRecord(e->ev_end, st));
 #undef M1_ARGS
 #undef M2_ARGS
@@ -311,9 +343,20 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     return CW_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
+    if (!e) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return run_device_locked(e, batch, res, hip_stream);
+}
+
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages) {
     if (!e || !n_stages) return CW_E_INVALID;
     *n_stages = 0;
+    std::lock_guard<std::mutex> lk(e->mu);
     if (!e->timings_valid) return CW_OK;
     CW_HIP(hipSetDevice(e->device));
     CW_HIP(hipEventSynchronize(e->ev_end));
@@ -336,22 +379,25 @@ int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n
     return CW_OK;
 }
 
-/* Debug/inspection: copy the engine's per-window bookkeeping of the last run (16 u32 per window) to host. */
+/* Debug/inspection (cw_private.h): copy the engine's per-window bookkeeping of the last run (16 u32 per window) to host. */
 int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
     if (!e || !out16 || !e->scratch) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n_windows > e->last_windows) return CW_E_INVALID;
     CW_HIP(hipSetDevice(e->device));
+    CW_HIP(hipDeviceSynchronize());
     CW_HIP(hipMemcpy(out16, e->scratch, (size_t)n_windows * sizeof(WinInfo), hipMemcpyDeviceToHost));
     return CW_OK;
 }
 
-/* Debug/inspection: 26 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
+/* Debug/inspection (cw_private.h): 26 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
 int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* prof32) {
     if (!e || !e->scratch || !counters26 || !prof32) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
-    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, e->last_windows, e->last_words, cus, e->last_big_slots);
+    CW_HIP(hipDeviceSynchronize());
     BatchCounters c;
-    CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + p.ctr, sizeof(c), hipMemcpyDeviceToHost));
+    CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
     memcpy(counters26, &c, 26 * 4);
     memcpy(prof32, c.prof, sizeof(c.prof));
     return CW_OK;
@@ -365,6 +411,9 @@ int cw_window_positions(uint32_t tpl_len, const cw_overlap* overlaps, uint32_t n
                         int32_t window_overlap, uint32_t* out_beg_end, uint32_t cap_pairs, uint32_t* n_pairs) {
     if (!n_pairs || (n_overlaps && !overlaps) || (cap_pairs && !out_beg_end)) return CW_E_INVALID;
     *n_pairs = 0;
+    /* the reference loops for ever on windowOverlap >= windowSize (the rewind undoes the whole window) and indexes out of bounds on a
+       negative one: an error here */
+    if (window_size == 0 || window_overlap < 0 || (uint32_t)window_overlap >= window_size) return CW_E_INVALID;
     if (tpl_len == 0) return CW_OK;
     std::vector<uint32_t> cov;
     try { cov.assign(tpl_len, 0); } catch (...) { return CW_E_NOMEM; }
@@ -409,14 +458,15 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
     if (!e || !reads || !jobs || !n_seqs || !n_words || (n_overlaps && !overlaps) || k < 1) return CW_E_INVALID;
     *n_seqs = 0; *n_words = 0;
     if (n_jobs == 0) return CW_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     /* per-window descriptor offsets need the jobs' overlap counts: take them from the device once */
     std::vector<cw_window_job> hj;
-    try { hj.resize(n_jobs); } catch (...) { return CW_E_NOMEM; }
+    std::vector<uint64_t> doff;
+    try { hj.resize(n_jobs); doff.assign((size_t)n_jobs + 1, 0); } catch (...) { return CW_E_NOMEM; }
     CW_HIP(hipMemcpyAsync(hj.data(), jobs, (size_t)n_jobs * sizeof(cw_window_job), hipMemcpyDeviceToHost, st));
     CW_HIP(hipStreamSynchronize(st));
-    std::vector<uint64_t> doff(n_jobs + 1, 0);
     for (uint32_t w = 0; w < n_jobs; ++w) {
         if ((uint64_t)hj[w].ovl_first + hj[w].ovl_count > n_overlaps || hj[w].tpl_read >= reads->n_reads || hj[w].q_end < hj[w].q_beg) return CW_E_INVALID;
         doff[w + 1] = doff[w] + hj[w].ovl_count;
@@ -438,11 +488,14 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
     a.seq_cap = seq_cap; a.word_cap = word_cap; a.status = (uint32_t*)(base + o_st);
     cw_extract_count_kernel<<<(n_jobs + 3) / 4, 256, 0, st>>>(a);
     cw_extract_scan_kernel<<<1, 1024, 0, st>>>(a);
-    uint32_t tot_s = 0; uint64_t tot_w = 0;
+    uint32_t tot_s = 0, flags[4] = {0, 0, 0, 0}; uint64_t tot_w = 0;
     CW_HIP(hipMemcpyAsync(&tot_s, a.win_seqs + n_jobs, 4, hipMemcpyDeviceToHost, st));
     CW_HIP(hipMemcpyAsync(&tot_w, a.win_words + n_jobs, 8, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipMemcpyAsync(flags, a.status, 16, hipMemcpyDeviceToHost, st));
     CW_HIP(hipStreamSynchronize(st));
     *n_seqs = tot_s; *n_words = tot_w;
+    if (flags[2]) return CW_E_INVALID;  /* an overlap names a target read outside the read set */
+    if (flags[1]) return CW_E_CAPACITY; /* a piece longer than 65535 bases (the batch format's length limit): an error, never a silently shorter pile */
     if (tot_s > seq_cap || tot_w > word_cap || !win_first_seq || !seq_len || !seq_word_off || !bases) return CW_E_CAPACITY;
     cw_extract_fill_kernel<<<(n_jobs + 1 + 3) / 4, 256, 0, st>>>(a);
     CW_HIP(hipGetLastError());
@@ -458,6 +511,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
         !res->solid_len || !batch->win_first_seq || !batch->seq_len || !batch->seq_word_off || !batch->bases)
         return CW_E_INVALID;
     if ((uint64_t)window_size + 2ull * window_overlap > CW_ST_RMAX) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const bool want_trace = getenv("CW_STITCH_TRACE") != nullptr;
@@ -475,11 +529,6 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     a.window_size = window_size; a.window_overlap = window_overlap; a.mer_size = e->prm.k; a.do_trim = do_trim;
     a.out = out; a.out_off = out_off; a.out_len = out_len; a.read_status = read_status; a.cursor = (uint32_t*)e->xscratch;
     const size_t lds = (size_t)CW_ST_WAVES * CW_ST_SLAB;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CW_HIP(hipFuncSetAttribute((const void*)cw_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
     if (wgs > CW_ST_MAX_WGS) wgs = CW_ST_MAX_WGS;
     /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
@@ -495,72 +544,173 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
 
 int cw_debug_stitch_trace(cw_engine* e, uint32_t n_windows, uint32_t* out) {
     if (!e || !out || !e->xscratch || e->xscratch_bytes < 256 + (size_t)n_windows * 32) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
     CW_HIP(hipDeviceSynchronize());
     CW_HIP(hipMemcpy(out, (uint8_t*)e->xscratch + 256, (size_t)n_windows * 32, hipMemcpyDeviceToHost));
     return CW_OK;
 }
 
-int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
-    if (!e || !b || !r || !r->cons || !r->cons_off || !r->cons_len || !r->win_status) return CW_E_INVALID;
-    if (b->n_windows == 0) return CW_OK;
-    if (!b->win_first_seq || !b->seq_len || !b->seq_word_off || !b->bases) return CW_E_INVALID;
-    CW_HIP(hipSetDevice(e->device));
+/* ---- host batches: cw_submit / cw_wait (and cw_run = both) -------------------------------------------------------------------
+ * H2D on its own stream, the kernels on the compute stream, the results compacted on the device (cw_pack_*: only the bytes the
+ * windows actually produced cross PCIe, not the capacities the caller reserved), D2H on a third stream into pinned staging, then
+ * scattered into the caller's arrays.  With two batches in flight the copies of one overlap the kernels of the other. */
+int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) {
+    if (!e || !b || !r || !ticket || !r->cons || !r->cons_off || !r->cons_len || !r->win_status) return CW_E_INVALID;
+    *ticket = -1;
+    if (b->n_windows && (!b->win_first_seq || !b->seq_len || !b->seq_word_off || !b->bases)) return CW_E_INVALID;
+    if (b->n_windows > CW_MAX_BATCH_WINDOWS) return CW_E_INVALID;
     const uint32_t W = b->n_windows, S = b->n_seqs;
     /* light validation of the host batch */
-    if (b->win_first_seq[0] != 0 || b->win_first_seq[W] != S) return CW_E_INVALID;
-    for (uint32_t w = 0; w < W; ++w) if (b->win_first_seq[w + 1] < b->win_first_seq[w]) return CW_E_INVALID;
-    for (uint32_t s = 0; s < S; ++s)
-        if (b->seq_word_off[s] + ((uint64_t)b->seq_len[s] + 15) / 16 > b->n_words || b->seq_len[s] > 65535u) return CW_E_INVALID;
+    if (W) {
+        if (b->win_first_seq[0] != 0 || b->win_first_seq[W] != S) return CW_E_INVALID;
+        for (uint32_t w = 0; w < W; ++w) if (b->win_first_seq[w + 1] < b->win_first_seq[w]) return CW_E_INVALID;
+        for (uint32_t s = 0; s < S; ++s)
+            if (b->seq_word_off[s] + ((uint64_t)b->seq_len[s] + 15) / 16 > b->n_words || b->seq_len[s] > 65535u) return CW_E_INVALID;
+    }
     const bool want_solid = r->solid != nullptr;
     if (want_solid && (!r->solid_off || !r->solid_len)) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int si = -1;
+    for (int i = 0; i < CW_SLOTS; ++i) if (!e->slot[i].busy) { si = i; break; }
+    if (si < 0) return CW_E_INVALID; /* CW_SLOTS batches are in flight already: cw_wait one of them first */
+    cw_slot& sl = e->slot[si];
+    sl.res = *r; sl.n_windows = W; sl.want_solid = want_solid;
+    if (W == 0) { sl.busy = true; *ticket = si; return CW_OK; }
+    CW_HIP(hipSetDevice(e->device));
 
     size_t o = 0;
     auto put = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     const size_t i_wfs = put((size_t)(W + 1) * 4), i_len = put((size_t)S * 4), i_off = put((size_t)S * 8), i_bases = put((size_t)(b->n_words + 1) * 4);
     const size_t in_bytes = o;
     o = 0;
-    const uint64_t cons_total = r->cons_off[W];
-    const uint64_t solid_total = want_solid ? r->solid_off[W] : 0;
-    const size_t o_cons = put(cons_total), o_coff = put((size_t)(W + 1) * 8), o_clen = put((size_t)W * 4), o_stat = put(W),
-                 o_solid = put(solid_total * 4), o_soff = put((size_t)(W + 1) * 8), o_slen = put((size_t)W * 4);
+    sl.cons_cap = r->cons_off[W];
+    sl.solid_cap = want_solid ? r->solid_off[W] : 0;
+    const size_t o_cons = put(sl.cons_cap), o_coff = put((size_t)(W + 1) * 8);
+    sl.o_clen = put((size_t)W * 4); sl.o_stat = put(W);
+    const size_t o_solid = put(sl.solid_cap * 4), o_soff = put((size_t)(W + 1) * 8);
+    sl.o_slen = put((size_t)W * 4);
+    sl.o_pc = put(sl.cons_cap); sl.o_ps = put(sl.solid_cap * 4); /* the compacted copies */
+    const size_t o_pco = put((size_t)(W + 1) * 8), o_pso = put((size_t)(W + 1) * 8);
+    sl.o_tot = put(16);
+    sl.o_cons = o_cons; sl.o_solid = o_solid;
     const size_t out_bytes = o;
-    int rc = ensure(&e->dev_in, &e->dev_in_bytes, in_bytes);
+    int rc = ensure(&sl.dev_in, &sl.dev_in_bytes, in_bytes);
     if (rc) return rc;
-    rc = ensure(&e->dev_out, &e->dev_out_bytes, out_bytes);
+    rc = ensure(&sl.dev_out, &sl.dev_out_bytes, out_bytes);
     if (rc) return rc;
-    uint8_t* din = (uint8_t*)e->dev_in;
-    uint8_t* dout = (uint8_t*)e->dev_out;
+    uint8_t* din = (uint8_t*)sl.dev_in;
+    uint8_t* dout = (uint8_t*)sl.dev_out;
+    hipStream_t ci = e->copy_in;
+    CW_HIP(hipMemcpyAsync(din + i_wfs, b->win_first_seq, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, ci));
+    CW_HIP(hipMemcpyAsync(din + i_len, b->seq_len, (size_t)S * 4, hipMemcpyHostToDevice, ci));
+    CW_HIP(hipMemcpyAsync(din + i_off, b->seq_word_off, (size_t)S * 8, hipMemcpyHostToDevice, ci));
+    CW_HIP(hipMemcpyAsync(din + i_bases, b->bases, (size_t)b->n_words * 4, hipMemcpyHostToDevice, ci));
+    CW_HIP(hipMemsetAsync(din + i_bases + (size_t)b->n_words * 4, 0, 4, ci));
+    CW_HIP(hipMemcpyAsync(dout + o_coff, r->cons_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, ci));
+    if (want_solid) CW_HIP(hipMemcpyAsync(dout + o_soff, r->solid_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, ci));
+    CW_HIP(hipEventRecord(sl.ev_in, ci));
     hipStream_t st = e->stream;
-    CW_HIP(hipMemcpyAsync(din + i_wfs, b->win_first_seq, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
-    CW_HIP(hipMemcpyAsync(din + i_len, b->seq_len, (size_t)S * 4, hipMemcpyHostToDevice, st));
-    CW_HIP(hipMemcpyAsync(din + i_off, b->seq_word_off, (size_t)S * 8, hipMemcpyHostToDevice, st));
-    CW_HIP(hipMemcpyAsync(din + i_bases, b->bases, (size_t)b->n_words * 4, hipMemcpyHostToDevice, st));
-    CW_HIP(hipMemsetAsync(din + i_bases + (size_t)b->n_words * 4, 0, 4, st));
-    CW_HIP(hipMemcpyAsync(dout + o_coff, r->cons_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
-    if (want_solid) CW_HIP(hipMemcpyAsync(dout + o_soff, r->solid_off, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+    CW_HIP(hipStreamWaitEvent(st, sl.ev_in, 0));
 
     cw_batch db = *b;
     db.win_first_seq = (const uint32_t*)(din + i_wfs); db.seq_len = (const uint32_t*)(din + i_len);
     db.seq_word_off = (const uint64_t*)(din + i_off); db.bases = (const uint32_t*)(din + i_bases);
     cw_result dr;
-    dr.cons = (char*)(dout + o_cons); dr.cons_off = (const uint64_t*)(dout + o_coff); dr.cons_len = (uint32_t*)(dout + o_clen);
-    dr.win_status = dout + o_stat;
+    dr.cons = (char*)(dout + o_cons); dr.cons_off = (const uint64_t*)(dout + o_coff); dr.cons_len = (uint32_t*)(dout + sl.o_clen);
+    dr.win_status = dout + sl.o_stat;
     dr.solid = want_solid ? (uint32_t*)(dout + o_solid) : nullptr;
     dr.solid_off = want_solid ? (const uint64_t*)(dout + o_soff) : nullptr;
-    dr.solid_len = want_solid ? (uint32_t*)(dout + o_slen) : nullptr;
-    rc = cw_run_device(e, &db, &dr, st);
+    dr.solid_len = want_solid ? (uint32_t*)(dout + sl.o_slen) : nullptr;
+    rc = run_device_locked(e, &db, &dr, st);
     if (rc) return rc;
-    CW_HIP(hipMemcpyAsync(r->cons, dout + o_cons, cons_total, hipMemcpyDeviceToHost, st));
-    CW_HIP(hipMemcpyAsync(r->cons_len, dout + o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, st));
-    CW_HIP(hipMemcpyAsync(r->win_status, dout + o_stat, W, hipMemcpyDeviceToHost, st));
-    if (want_solid) {
-        CW_HIP(hipMemcpyAsync(r->solid, dout + o_solid, solid_total * 4, hipMemcpyDeviceToHost, st));
-        CW_HIP(hipMemcpyAsync(r->solid_len, dout + o_slen, (size_t)W * 4, hipMemcpyDeviceToHost, st));
-    }
-    CW_HIP(hipStreamSynchronize(st));
-    for (uint32_t w = 0; w < W; ++w) if (r->win_status[w] == CW_WIN_OVERFLOW) return CW_E_CAPACITY;
+    PackArgs pa;
+    pa.n_windows = W; pa.cons = dr.cons; pa.cons_off = dr.cons_off; pa.cons_len = dr.cons_len; pa.win_status = dr.win_status;
+    pa.solid = dr.solid; pa.solid_off = dr.solid_off; pa.solid_len = dr.solid_len;
+    pa.pc = (char*)(dout + sl.o_pc); pa.ps = (uint32_t*)(dout + sl.o_ps);
+    pa.pc_off = (uint64_t*)(dout + o_pco); pa.ps_off = (uint64_t*)(dout + o_pso); pa.totals = (uint64_t*)(dout + sl.o_tot);
+    cw_pack_scan_kernel<<<1, 1024, 0, st>>>(pa);
+    cw_pack_copy_kernel<<<(W + 3) / 4, 256, 0, st>>>(pa);
+    CW_HIP(hipGetLastError());
+    CW_HIP(hipEventRecord(sl.ev_done, st));
+    sl.busy = true;
+    *ticket = si;
     return CW_OK;
+}
+
+int cw_wait(cw_engine* e, int ticket) {
+    if (!e || ticket < 0 || ticket >= CW_SLOTS) return CW_E_INVALID;
+    cw_slot& sl = e->slot[ticket];
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!sl.busy) return CW_E_INVALID;
+        if (sl.n_windows == 0) { sl.busy = false; return CW_OK; }
+    }
+    /* the slot belongs to this ticket until busy is cleared; other threads may submit meanwhile */
+    if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(sl.ev_done) != hipSuccess) return CW_E_NO_DEVICE;
+    const uint32_t W = sl.n_windows;
+    const cw_result& r = sl.res;
+    uint8_t* dout = (uint8_t*)sl.dev_out;
+    hipStream_t co = e->copy_out;
+    uint64_t tot[2] = {0, 0};
+    int rc = CW_OK;
+    auto fail = [&](int code) { std::lock_guard<std::mutex> lk(e->mu); sl.busy = false; return code; };
+    if (hipMemcpyAsync(tot, dout + sl.o_tot, 16, hipMemcpyDeviceToHost, co) != hipSuccess ||
+        hipMemcpyAsync(r.cons_len, dout + sl.o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess ||
+        hipMemcpyAsync(r.win_status, dout + sl.o_stat, W, hipMemcpyDeviceToHost, co) != hipSuccess ||
+        (sl.want_solid && hipMemcpyAsync(r.solid_len, dout + sl.o_slen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess) ||
+        hipStreamSynchronize(co) != hipSuccess)
+        return fail(CW_E_NO_DEVICE);
+    if (tot[0] > sl.cons_cap || tot[1] > sl.solid_cap) return fail(CW_E_INTERNAL);
+    const size_t need = align_up(tot[0], 256) + tot[1] * 4 + 256;
+    if (sl.pin_out_bytes < need) {
+        if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+        sl.pin_out = nullptr; sl.pin_out_bytes = 0;
+        const size_t want = need + need / 4; /* some slack: the next batch is rarely exactly as large */
+        if (hipHostMalloc(&sl.pin_out, want, hipHostMallocDefault) != hipSuccess) { sl.pin_out = nullptr; return fail(CW_E_NOMEM); }
+        sl.pin_out_bytes = want;
+    }
+    char* hc = (char*)sl.pin_out;
+    uint32_t* hs = (uint32_t*)((uint8_t*)sl.pin_out + align_up(tot[0], 256));
+    if ((tot[0] && hipMemcpyAsync(hc, dout + sl.o_pc, tot[0], hipMemcpyDeviceToHost, co) != hipSuccess) ||
+        (tot[1] && hipMemcpyAsync(hs, dout + sl.o_ps, tot[1] * 4, hipMemcpyDeviceToHost, co) != hipSuccess) ||
+        hipStreamSynchronize(co) != hipSuccess)
+        return fail(CW_E_NO_DEVICE);
+    uint64_t pc = 0, ps = 0;
+    for (uint32_t w = 0; w < W; ++w) {
+        const bool ok = r.win_status[w] != CW_WIN_OVERFLOW;
+        if (!ok) rc = CW_E_CAPACITY;
+        const uint32_t cl = ok ? r.cons_len[w] : 0u;
+        if (cl) memcpy(r.cons + r.cons_off[w], hc + pc, cl);
+        pc += cl;
+        if (sl.want_solid) {
+            const uint32_t n = ok ? r.solid_len[w] : 0u;
+            if (n) memcpy(r.solid + r.solid_off[w], hs + ps, (size_t)n * 4);
+            ps += n;
+        }
+    }
+    if (pc != tot[0] || ps != tot[1]) rc = CW_E_INTERNAL;
+    return fail(rc);
+}
+
+int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
+    int t = -1;
+    const int rc = cw_submit(e, b, r, &t);
+    if (rc != CW_OK) return rc;
+    return cw_wait(e, t);
+}
+
+/* pinned host memory for batches and results: copies from and to it are real DMA transfers that overlap the kernels; plain
+   (pageable) buffers work too, but the runtime stages them through its own bounce buffers and the overlap is lost */
+int cw_host_alloc(void** ptr, size_t bytes) {
+    if (!ptr) return CW_E_INVALID;
+    *ptr = nullptr;
+    if (hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *ptr = nullptr; return CW_E_NOMEM; }
+    return CW_OK;
+}
+
+void cw_host_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 } // extern "C"

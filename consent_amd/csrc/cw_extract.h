@@ -39,12 +39,13 @@ struct ExtractArgs {
     uint32_t* bases;
     uint32_t seq_cap;
     uint64_t word_cap;
-    uint32_t* status; /* [0] = 1 when a capacity was exceeded */
+    uint32_t* status; /* [0] = 1 when an output capacity was exceeded; [1] = 1 when a piece is longer than the batch format's 65535
+                         bases (reachable through -l: reported, never dropped); [2] = 1 when an overlap names a read outside the set */
 };
 
 /* piece of one overlap for window [q_beg, q_end] -- alignmentWindows.cpp:106-141 on plain integers */
 __device__ __forceinline__ void cw_extract_piece(const cw_overlap& al, uint32_t t_len_u, uint32_t q_beg, uint32_t end, uint32_t k,
-                                                 uint32_t* src_pos, uint32_t* out_len) {
+                                                 uint32_t* src_pos, uint32_t* out_len, bool* too_long) {
     *out_len = 0;
     uint32_t t_beg = al.t_start, t_end = al.t_end;
     uint32_t length = end - q_beg + 1;
@@ -71,7 +72,8 @@ __device__ __forceinline__ void cw_extract_piece(const cw_overlap& al, uint32_t 
     const uint64_t s_len = min(want, (uint64_t)t_len_u - t_beg);
     if ((uint64_t)shift > s_len) return;                                                /* :138 would throw */
     const uint64_t p_len = min((uint64_t)length, s_len - shift);
-    if (p_len < k || p_len > 65535u) return;                                            /* :141 (and the ABI's length limit) */
+    if (p_len < k) return;                                                              /* :141 */
+    if (p_len > 65535u) { *too_long = true; return; }                                   /* the batch format's length limit: reported by the caller */
     *out_len = (uint32_t)p_len;
     /* '+': piece[y] = T[t_beg + shift + y];  '-': S = revcomp(T[t_beg, t_beg+s_len)), piece[y] = comp(T[t_beg + s_len - 1 - shift - y]) */
     *src_pos = al.strand ? (uint32_t)(t_beg + s_len - 1 - shift) : t_beg + shift;
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(256) cw_extract_count_kernel(ExtractArgs a) {
     const uint32_t tpl_len = a.reads.read_len[jb.tpl_read];
     const uint32_t length = jb.q_end - jb.q_beg + 1;
     const bool has_tpl = (uint64_t)jb.q_beg + length - 1 < tpl_len;                     /* :95-97: else an empty pile */
+    if (has_tpl && length > 65535u) { if (lane == 0) a.status[1] = 1; }
     uint32_t n_mem = has_tpl ? 1u : 0u;
     uint64_t words = has_tpl ? (length + 15) / 16 : 0;
     ExtractDesc* dd = a.desc + a.desc_off[w];
@@ -94,7 +97,12 @@ __global__ void __launch_bounds__(256) cw_extract_count_kernel(ExtractArgs a) {
         if (o < jb.ovl_count && has_tpl) {
             const cw_overlap al = a.ovl[jb.ovl_first + o];
             src = al.t_read;
-            cw_extract_piece(al, a.reads.read_len[src], jb.q_beg, jb.q_end, a.k, &pos, &len);
+            if (src >= a.reads.n_reads) { a.status[2] = 1; src = 0; }
+            else {
+                bool too_long = false;
+                cw_extract_piece(al, a.reads.read_len[src], jb.q_beg, jb.q_end, a.k, &pos, &len, &too_long);
+                if (too_long) a.status[1] = 1;
+            }
         }
         const unsigned long long bal = __ballot(len > 0);
         const uint32_t idx = n_mem + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -142,7 +150,7 @@ __global__ void __launch_bounds__(1024) cw_extract_scan_kernel(ExtractArgs a) {
 __global__ void __launch_bounds__(256) cw_extract_fill_kernel(ExtractArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w > a.n_jobs || a.status[0]) return;
+    if (w > a.n_jobs || a.status[0] || a.status[1] || a.status[2]) return;
     if (w == a.n_jobs) { if (lane == 0) a.win_first_seq[w] = a.win_seqs[w]; return; }
     const cw_window_job jb = a.jobs[w];
     const uint32_t s_base = a.win_seqs[w];

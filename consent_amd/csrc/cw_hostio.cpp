@@ -242,6 +242,10 @@ int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw
         for (size_t i = 0; i < cur.size(); ++i) {
             const int32_t t = cw_read_index_find(r->idx, cur[i].t_name.c_str());
             if (t < 0) { r->bad = true; return CW_E_INVALID; }
+            /* the reference clamps target coordinates with the PAF's tLength (alignmentWindows.cpp:121-129) and slices the indexed read;
+               downstream (cw_extract_piles_device) there is only the indexed length, so a PAF that disagrees with the read file is
+               refused here instead of being corrected differently */
+            if (cur[i].t_len != r->idx->len[(size_t)t]) { r->bad = true; return CW_E_INVALID; }
             out[i].q_start = cur[i].q_start; out[i].q_end = cur[i].q_end;
             out[i].t_read = (uint32_t)t; out[i].t_start = cur[i].t_start; out[i].t_end = cur[i].t_end;
             out[i].strand = cur[i].strand;

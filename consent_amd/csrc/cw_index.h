@@ -85,8 +85,11 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             wi.n_seqs = ns; wi.tpl_len = tl; wi.n_kmers = nk;
             uint64_t sb = run[0] + part[0][tid] - need_solid, gb = run[1] + part[1][tid] - need_seg,
                      ab = run[2] + part[2][tid] - need_arena, kb = run[3] + part[3][tid] - need_ab;
+            /* the bases are stored as 32-bit offsets: a batch whose running totals would wrap is refused window by window (the host
+               refuses such batches up front, CW_MAX_BATCH_WINDOWS; this is the second line of defence) */
             bool over = sb + need_solid > solid_total_cap || gb + need_seg > seg_total_cap || ab + need_arena > arena_total_cap ||
-                        kb + need_ab > sc.ablock_units || kb + need_ab > 0xFFFFFFFFull;
+                        kb + need_ab > sc.ablock_units || kb + need_ab > 0xFFFFFFFFull || sb + need_solid > 0xFFFFFFFFull ||
+                        gb + need_seg > 0xFFFFFFFFull || ab + need_arena > 0xFFFFFFFFull;
             wi.solid_base = (uint32_t)sb; wi.solid_cap = need_solid; wi.n_solid = 0;
             wi.seg_base = (uint32_t)gb; wi.seg_cap = need_seg; wi.n_segs = 0;
             wi.arena_base = (uint32_t)ab; wi.arena_cap = need_arena; wi.arena_used = 0;

@@ -5,39 +5,60 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/consent_amd.h"
 
-#define CW_MAX_STAGES 14
+#define CW_MAX_STAGES 16
+#define CW_SLOTS 2 /* host batches in flight through cw_submit / cw_wait */
+
+/* one host batch in flight (cw_submit .. cw_wait): its own device input/output buffers and pinned result staging; the kernels of
+   all slots share the engine's scratch and run in submission order on the compute stream */
+struct cw_slot {
+    bool busy = false;
+    void* dev_in = nullptr;
+    size_t dev_in_bytes = 0;
+    void* dev_out = nullptr;
+    size_t dev_out_bytes = 0;
+    void* pin_out = nullptr; /* pinned host staging of the compacted results */
+    size_t pin_out_bytes = 0;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    cw_result res{};         /* the caller's result arrays (host) */
+    uint32_t n_windows = 0;
+    bool want_solid = false;
+    size_t o_cons = 0, o_clen = 0, o_stat = 0, o_solid = 0, o_slen = 0, o_pc = 0, o_ps = 0, o_tot = 0; /* offsets in dev_out */
+    uint64_t cons_cap = 0, solid_cap = 0;
+};
 
 struct cw_engine {
-    cw_params prm;
-    int device;
-    hipStream_t stream;
-    hipDeviceProp_t prop;
+    std::mutex mu; /* every entry point that touches the engine takes it: one engine = one caller at a time (see consent_amd.h "Threading") */
+    cw_params prm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_in = nullptr, copy_out = nullptr; /* H2D / D2H of host batches, beside the compute stream */
+    hipDeviceProp_t prop{};
     /* growable device scratch owned by the engine (never shrinks) */
-    void* scratch;
-    size_t scratch_bytes;
-    /* staging for cw_run (host buffers) */
-    void* dev_in;
-    size_t dev_in_bytes;
-    void* dev_out;
-    size_t dev_out_bytes;
-    void* xscratch; /* pile-extraction scratch */
-    size_t xscratch_bytes;
-    void* stitch_scratch; /* banded-traceback directions of cw_stitch_device, per wave */
-    size_t stitch_scratch_bytes;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    cw_slot slot[CW_SLOTS];
+    void* xscratch = nullptr; /* pile-extraction scratch */
+    size_t xscratch_bytes = 0;
+    void* stitch_scratch = nullptr; /* banded-traceback directions of cw_stitch_device, per wave */
+    size_t stitch_scratch_bytes = 0;
+    uint32_t* host_fb = nullptr; /* pinned: [0] tasks the last finished batch handed to tier L (feeds linger_wgs), [1] its sequence number */
     /* per-stage timing of the last run */
-    hipStream_t side[3];          /* POA tiers run concurrently on their own streams */
-    hipEvent_t ev_fork, ev_join[3];
-    hipEvent_t ev0[CW_MAX_STAGES], ev1[CW_MAX_STAGES]; /* start/stop per stage, recorded on the stage's stream */
-    hipEvent_t ev_begin, ev_end;
-    int n_stages;
-    const char* stage_name[CW_MAX_STAGES];
-    float stage_ms[CW_MAX_STAGES];
-    bool timings_valid;
-    uint32_t last_windows, last_big_slots;
-    uint32_t linger_wgs; /* tier-L work-groups kept on the live overflow queue (adapted from the previous batch) */
-    uint64_t last_words;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr}; /* POA tiers run concurrently on their own streams */
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev0[CW_MAX_STAGES] = {}, ev1[CW_MAX_STAGES] = {}; /* start/stop per stage, recorded on the stage's stream */
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    int n_stages = 0;
+    const char* stage_name[CW_MAX_STAGES] = {};
+    float stage_ms[CW_MAX_STAGES] = {};
+    bool timings_valid = false;
+    uint32_t last_windows = 0, last_big_slots = 0, last_seqs = 0;
+    uint32_t linger_wgs = 0; /* tier-L work-groups kept on the live overflow queue (adapted from the previous batch) */
+    uint64_t last_words = 0;
+    size_t last_ctr_off = 0; /* where the last run's BatchCounters sit in scratch */
 };
 
 #define CW_HIP(expr)                                   \

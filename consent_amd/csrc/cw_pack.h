@@ -1,0 +1,74 @@
+/*
+ * cw_pack.h -- result compaction for host batches (cw_submit / cw_wait).
+ *
+ * The caller of cw_run reserves a capacity per window (cw_result.cons_off / solid_off); the windows use a fraction of it
+ * (a consensus is ~550 of 1756 reserved bytes, a solid set a few percent of its worst case).  Copying the capacities back
+ * over PCIe made the copy as long as the kernels.  These two kernels pack what was produced front to back, so that the
+ * D2H transfer is the used bytes only; the host scatters them to the caller's offsets.
+ *   cw_pack_scan_kernel : exclusive prefix sums of cons_len / solid_len over the windows (one work-group)
+ *   cw_pack_copy_kernel : one wave per window copies its consensus bytes and solid k-mers to the packed arrays
+ * HBM-bound by construction (each produced byte read once, written once).
+ */
+#ifndef CW_PACK_H
+#define CW_PACK_H
+
+#include "cw_device.h"
+
+struct PackArgs {
+    uint32_t n_windows;
+    const char* cons;
+    const uint64_t* cons_off;
+    const uint32_t* cons_len;
+    const uint8_t* win_status;
+    const uint32_t* solid; /* may be NULL */
+    const uint64_t* solid_off;
+    const uint32_t* solid_len;
+    char* pc;          /* packed consensus bytes */
+    uint32_t* ps;      /* packed solid k-mers    */
+    uint64_t* pc_off;  /* [n_windows + 1]        */
+    uint64_t* ps_off;  /* [n_windows + 1]        */
+    uint64_t* totals;  /* [0] consensus bytes, [1] solid k-mers */
+};
+
+__global__ void __launch_bounds__(1024) cw_pack_scan_kernel(PackArgs a) {
+    __shared__ unsigned long long pa[1024], pb[1024];
+    __shared__ unsigned long long run[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) run[tid] = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < a.n_windows; w0 += 1024) {
+        const uint32_t w = w0 + tid;
+        const bool live = w < a.n_windows && a.win_status[w] != CW_WIN_OVERFLOW;
+        const unsigned long long c = live ? a.cons_len[w] : 0, s = (live && a.solid) ? a.solid_len[w] : 0;
+        pa[tid] = c; pb[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            unsigned long long va = 0, vb = 0;
+            if (tid >= o) { va = pa[tid - o]; vb = pb[tid - o]; }
+            __syncthreads();
+            pa[tid] += va; pb[tid] += vb;
+            __syncthreads();
+        }
+        if (w < a.n_windows) { a.pc_off[w] = run[0] + pa[tid] - c; a.ps_off[w] = run[1] + pb[tid] - s; }
+        __syncthreads();
+        if (tid == 0) { run[0] += pa[1023]; run[1] += pb[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { a.pc_off[a.n_windows] = run[0]; a.ps_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; }
+}
+
+__global__ void __launch_bounds__(256) cw_pack_copy_kernel(PackArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= a.n_windows) return;
+    const uint64_t c0 = a.pc_off[w], c1 = a.pc_off[w + 1];
+    const char* src = a.cons + a.cons_off[w];
+    for (uint64_t i = lane; i < c1 - c0; i += 64) a.pc[c0 + i] = src[i];
+    if (a.solid) {
+        const uint64_t s0 = a.ps_off[w], s1 = a.ps_off[w + 1];
+        const uint32_t* ss = a.solid + a.solid_off[w];
+        for (uint64_t i = lane; i < s1 - s0; i += 64) a.ps[s0 + i] = ss[i];
+    }
+}
+
+#endif

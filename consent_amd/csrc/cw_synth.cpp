@@ -1,6 +1,7 @@
 /* cw_synth.cpp -- synthetic pile generation on host and on device (see cw_synth.h). */
 #include "cw_synth.h"
 #include "cw_internal.h"
+#include "cw_private.h"
 
 static int check_spec(const cw_synth_spec* s) {
     if (!s || s->window_len < 16 || s->window_len > 1000) return CW_E_INVALID;

@@ -104,6 +104,11 @@ def load_library():
     lib.cw_destroy.restype = None
     lib.cw_run.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result)]
     lib.cw_run_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_void_p]
+    lib.cw_submit.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.POINTER(C.c_int)]
+    lib.cw_wait.argtypes = [C.c_void_p, C.c_int]
+    lib.cw_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.cw_host_free.argtypes = [C.c_void_p]
+    lib.cw_host_free.restype = None
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -375,6 +380,7 @@ class Engine:
     def __init__(self, params, device=0):
         self.lib = load_library()
         self.params = params
+        self.device = device
         self.handle = C.c_void_p()
         _check(self.lib, self.lib.cw_create(C.byref(params), device, C.byref(self.handle)), "cw_create")
 
@@ -397,6 +403,18 @@ class Engine:
         _check(self.lib, self.lib.cw_run(self.handle, C.byref(b), C.byref(r)), "cw_run", allow_capacity=True)
         return res
 
+    def submit(self, batch, res):
+        """cw_submit: enqueue a host batch (HostBatch + WindowResults from alloc_results); returns (ticket, keep-alive).  Up to two in flight."""
+        b = batch.c_struct()
+        r = _result_struct(res)
+        t = C.c_int(-1)
+        _check(self.lib, self.lib.cw_submit(self.handle, C.byref(b), C.byref(r), C.byref(t)), "cw_submit")
+        return t.value, (batch, res, b, r)
+
+    def wait(self, ticket):
+        """cw_wait: blocks until the batch of `ticket` is done and its WindowResults are filled."""
+        _check(self.lib, self.lib.cw_wait(self.handle, ticket), "cw_wait", allow_capacity=True)
+
     def run_device(self, batch_struct, result_struct, stream=None):
         _check(self.lib, self.lib.cw_run_device(self.handle, C.byref(batch_struct), C.byref(result_struct), stream), "cw_run_device")
 
@@ -406,7 +424,7 @@ class Engine:
         ends inclusive), `jobs` an (m,5) uint32 array (tpl_read, q_beg, q_end, ovl_first, ovl_count).  Returns a HostBatch."""
         import torch
 
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
 
         def up(a, dt):
             return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
@@ -425,10 +443,10 @@ class Engine:
         o_len = torch.zeros(max(ns.value, 1), dtype=torch.int32, device=dev)
         o_off = torch.zeros(max(ns.value, 1), dtype=torch.int64, device=dev)
         o_bases = torch.zeros(max(nw.value, 1) + 1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()  # the engine launches on its own stream: torch's fills above must have landed
+        torch.cuda.synchronize(dev)  # the engine launches on its own stream: torch's fills above must have landed
         _check(self.lib, self.lib.cw_extract_piles_device(self.handle, C.byref(rs), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), len(jb), k, o_wfs.data_ptr(), o_len.data_ptr(),
                                                           o_off.data_ptr(), o_bases.data_ptr(), ns.value, nw.value, C.byref(ns), C.byref(nw), None), "cw_extract_piles_device")
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         return HostBatch(o_wfs.cpu().numpy().view(np.uint32), o_len.cpu().numpy().view(np.uint32)[: ns.value], o_off.cpu().numpy().view(np.uint64)[: ns.value],
                          o_bases.cpu().numpy().view(np.uint32)[: max(nw.value, 1)])
 
@@ -438,7 +456,7 @@ class Engine:
         and what the engine returned for them.  Returns [(corrected_read, status)]."""
         import torch
 
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
 
         def up(a, dt):
             a = np.ascontiguousarray(a)
@@ -463,10 +481,10 @@ class Engine:
         t_out = torch.zeros(int(out_off[-1]) + 1, dtype=torch.uint8, device=dev)
         t_olen = torch.zeros(len(jb) + 1, dtype=torch.int32, device=dev)
         t_ost = torch.full((len(jb) + 1,), 255, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()  # the engine launches on its own stream: torch's fills above must have landed
+        torch.cuda.synchronize(dev)  # the engine launches on its own stream: torch's fills above must have landed
         _check(self.lib, self.lib.cw_stitch_device(self.handle, C.byref(rs), t_jb.data_ptr(), len(jb), t_pos.data_ptr(), C.byref(bs), C.byref(rstruct), window_size, window_overlap,
                                                    int(bool(do_trim)), t_out.data_ptr(), t_ooff.data_ptr(), t_olen.data_ptr(), t_ost.data_ptr(), None), "cw_stitch_device")
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         out, olen, ost = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy()
         return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode("latin-1"), int(ost[i])) for i in range(len(jb))]
 

@@ -96,12 +96,38 @@ typedef struct cw_engine cw_engine;
 const char* cw_version(void);
 const char* cw_strerror(int status);
 
-/* Engine bound to one HIP device (one process per GPU). */
+/* Engine bound to one HIP device.
+ *
+ * Threading.  The reference calls its operator from nbThreads pool threads at once (CONSENT-correction.cpp:77, one thread per read;
+ * CONSENT-polishing.cpp:37,49 one task per window), with no shared mutable state.  Here an engine owns one scratch arena and one set
+ * of streams, and every entry point that takes a cw_engine* locks the engine's mutex for the time it enqueues work: calls from
+ * several host threads on ONE engine are safe and are serialised; they do not run concurrently.  For concurrency use one engine per
+ * host thread or per device (any number of engines may share a GPU; results do not depend on how windows are spread over engines,
+ * batches or GPUs).  cw_run_device is asynchronous: the caller's device buffers must stay valid, and the engine's next call on
+ * another stream must be ordered by the caller, until that stream has been synchronised.  The host feeders (cw_index_reads,
+ * cw_paf_*) keep their state in their own handles: one thread per handle. */
 int cw_create(const cw_params* params, int device, cw_engine** out);
 void cw_destroy(cw_engine* e);
 
-/* Host buffers in, host buffers out (H2D, kernels, D2H, synchronous). */
+/* Largest batch one call accepts (per-window offsets into the engine's scratch are 32-bit); CW_E_INVALID beyond it.  Split larger
+ * inputs: results do not depend on the batch composition. */
+#define CW_MAX_BATCH_WINDOWS 131072u
+
+/* Host buffers in, host buffers out: H2D, kernels, D2H of the bytes the windows actually produced (not of the reserved
+ * capacities), synchronous.  Equivalent to cw_submit + cw_wait. */
 int cw_run(cw_engine* e, const cw_batch* batch, const cw_result* result);
+
+/* The same in two halves, so that a caller can keep the GPU busy: cw_submit enqueues the H2D copies and the kernels of a batch and
+ * returns a ticket; cw_wait blocks until that batch is done and fills `result`.  Up to two batches may be in flight per engine
+ * (submit n+1, then wait n: the copies of one overlap the kernels of the other); a third cw_submit returns CW_E_INVALID.  Every
+ * array named by `batch` and `result` must stay valid and untouched until cw_wait has returned.  Arrays from cw_host_alloc (pinned)
+ * are moved by real DMA that overlaps the kernels; plain pageable arrays work too, the runtime then stages them itself. */
+int cw_submit(cw_engine* e, const cw_batch* batch, const cw_result* result, int* ticket);
+int cw_wait(cw_engine* e, int ticket);
+
+/* Pinned host memory for batches / results (hipHostMalloc). */
+int cw_host_alloc(void** ptr, size_t bytes);
+void cw_host_free(void* ptr);
 
 /* Every pointer inside batch/result is a DEVICE pointer; asynchronous on `hip_stream` (a hipStream_t,
  * NULL = the engine's own stream); statuses are checked by the caller after synchronising.  */
@@ -110,16 +136,6 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* result, 
 /* Milliseconds spent in each device stage of the last cw_run / cw_run_device on this engine, measured
  * with HIP events on the launch stream.  n_stages entries are written (at most cap); names are static. */
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages);
-
-/* Inspection aid for tests: copies the engine's per-window bookkeeping of the last run to host, 16 uint32 per
- * window: status, n_seqs, tpl_len, n_kmers, solid_base, solid_cap, n_solid, seg_base, seg_cap, n_segs,
- * arena_base, arena_cap, arena_used, 3 reserved. */
-int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16);
-
-/* Inspection aid: 26 batch counters (uint32: tasks, members, next_task, next_window, next_finish, any_overflow,
- * n_tier[5], next_tier[5], n_over[5], next_over[5]) and 32 per-phase GPU cycle totals of the last run (index kernel 0-6; POA tier t at 8+5t..12+5t:
- * metadata, fill, traceback, merge, consensus). */
-int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* prof32);
 
 /* Pack one ASCII window pile (n strings, lens[i] bytes each, not NUL-terminated) at the tail of host
  * arrays laid out as cw_batch.  words_cap counts 32-bit words available at bases_out.  Returns the
@@ -222,31 +238,6 @@ typedef struct cw_stitch_read {
 int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_read* jobs, uint32_t n_reads, const uint32_t* win_pos,
                      const cw_batch* batch, const cw_result* res, uint32_t window_size, uint32_t window_overlap, int32_t do_trim,
                      char* out, const uint64_t* out_off, uint32_t* out_len, uint8_t* read_status, void* hip_stream);
-
-/* debug: with CW_STITCH_TRACE set in the environment the last cw_stitch_device call records, per window, 8 words
- * (al_pos, size_al, score, ref_begin, ref_end, query_begin, query_end, query_len); 0xFFFFFFFF = window not aligned. */
-int cw_debug_stitch_trace(cw_engine* e, uint32_t n_windows, uint32_t* out);
-
-/* ---- synthetic PacBio/ONT-profile piles (bench + tests; SURVEY 8d generator) --------------------- */
-typedef struct cw_synth_spec {
-    uint64_t seed;        /* window w draws from seed + first_window + w            */
-    uint64_t first_window;
-    uint32_t n_windows;
-    uint32_t depth;       /* support sequences per window (pile size = depth + 1)     */
-    uint32_t window_len;  /* template length, 500                                     */
-    uint32_t err_permille;/* total error rate, 120 = 12 %                             */
-    uint32_t sub_w, ins_w, del_w; /* error mix, PacBio 10:60:30, ONT 30:30:40          */
-    uint32_t seq_stride_words;    /* words reserved per sequence (>= (window_len+60)/16+1) */
-} cw_synth_spec;
-
-/* Sizes of the arrays a synthetic batch needs. */
-int cw_synth_sizes(const cw_synth_spec* spec, uint32_t* n_seqs, uint64_t* n_words);
-/* Fill host arrays (win_first_seq[n_windows+1], seq_len[n_seqs], seq_word_off[n_seqs], bases[n_words]). */
-int cw_synth_host(const cw_synth_spec* spec, uint32_t* win_first_seq, uint32_t* seq_len, uint64_t* seq_word_off,
-                  uint32_t* bases);
-/* Same arrays as DEVICE pointers, generated by a HIP kernel on `hip_stream`. */
-int cw_synth_device(cw_engine* e, const cw_synth_spec* spec, uint32_t* win_first_seq, uint32_t* seq_len,
-                    uint64_t* seq_word_off, uint32_t* bases, void* hip_stream);
 
 #ifdef __cplusplus
 }

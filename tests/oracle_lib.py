@@ -15,7 +15,7 @@ _R = None
 def oracle():
     global _O
     if _O is None:
-        _O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        _O = C.CDLL(os.environ.get("CW_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so"))
         _O.cwo_run.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.POINTER(Result), C.c_void_p, C.c_int]
     return _O
 

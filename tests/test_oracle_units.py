@@ -103,3 +103,21 @@ def test_window_consensus_template_fallback_and_single_sequence():
     assert res.status[0] == ca.WIN_TEMPLATE and res.consensus(0) == tpl  # correctionMSA.cpp:34-36
     res, _ = oracle_lib.oracle_run(prm, ca.pack_piles([[tpl]]))
     assert res.status[0] == ca.WIN_CONSENSUS and res.consensus(0) == tpl.lower()  # every k-mer count is 1 < solid
+
+
+def test_window_positions_refuses_the_parameters_the_reference_hangs_on():
+    """windowOverlap >= windowSize never advances (alignmentWindows.cpp:40-47) and a negative one indexes out of bounds: the library's
+    host function returns CW_E_INVALID instead."""
+    import ctypes as C
+
+    import numpy as np
+
+    import consent_amd as ca
+
+    lib = ca.load_library()
+    ov = np.array([[0, 999, 1, 0, 999, 0]], np.uint32)
+    out = np.zeros(64, np.uint32)
+    n = C.c_uint32()
+    for ws, wo in ((0, 0), (500, 500), (500, 600), (500, -1)):
+        assert lib.cw_window_positions(1000, ov.ctypes.data, 1, 1, ws, wo, out.ctypes.data, 32, C.byref(n)) == -1
+    assert lib.cw_window_positions(1000, ov.ctypes.data, 1, 1, 500, 50, out.ctypes.data, 32, C.byref(n)) == 0 and n.value == 3
