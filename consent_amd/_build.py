@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("cw_engine.cpp", "cw_synth.cpp", "cw_hostio.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("cw_engine.cpp", "cw_synth.cpp", "cw_hostio.cpp", "cw_driver.cpp")]
 HDR = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".h")]
 HDR += [os.path.join(HERE, "..", "include", f) for f in ("consent_amd.h", "cw_policy.h")]
 OUT = os.path.join(HERE, "libconsent_amd.so")
@@ -24,13 +24,48 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SRC + HDR)
 
 
+BIN = os.path.normpath(os.path.join(HERE, "..", "bin"))
+CLI = os.path.join(HERE, "cli")
+# (executable, source, extra flags): the wrappers' five programs (reference Makefile:5), plain g++ over the C ABI
+BINS = [
+    ("CONSENT-correction", "consent_main.cpp", ["-DCW_DRIVER_POLISHING=0"]),
+    ("CONSENT-polishing", "consent_main.cpp", ["-DCW_DRIVER_POLISHING=1"]),
+    ("explode", "paf_tools.cpp", ["-DCW_TOOL=1"]),
+    ("merge", "paf_tools.cpp", ["-DCW_TOOL=2"]),
+    ("reformatPAF", "paf_tools.cpp", ["-DCW_TOOL=3"]),
+]
+
+
+def bins_stale():
+    t_lib = os.path.getmtime(OUT) if os.path.exists(OUT) else 0
+    for exe, src, _ in BINS:
+        p = os.path.join(BIN, exe)
+        if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(os.path.join(CLI, src)), os.path.getmtime(HDR[-2])):
+            return True
+        if os.path.getmtime(p) < t_lib - 86400 * 365:
+            return True
+    return False
+
+
+def build_bins(verbose=True):
+    os.makedirs(BIN, exist_ok=True)
+    for exe, src, flags in BINS:
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", *flags, "-I", os.path.join(HERE, "..", "include"), os.path.join(CLI, src), "-L", HERE, "-lconsent_amd",
+               "-Wl,-rpath,$ORIGIN/../consent_amd", "-o", os.path.join(BIN, exe)]
+        if verbose:
+            print("[consent_amd] " + " ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+
 def build(force=False, verbose=True):
-    if not force and not stale():
-        return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *SRC, "-o", OUT]
-    if verbose:
-        print("[consent_amd] " + " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    if force or stale():
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *SRC, "-o", OUT]
+        if verbose:
+            print("[consent_amd] " + " ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        force = True
+    if force or bins_stale():
+        build_bins(verbose)
     return OUT
 
 

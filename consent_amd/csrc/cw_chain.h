@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
         /* one way through the body: every window ends at the status store + wave barrier at the bottom */
         const bool ready = ch_uni(wi->status) == CW_WIN_CONSENSUS; /* the index kernel got to the end of this window */
         uint32_t new_status = 0xFFFFFFFFu; /* unchanged */
+        uint32_t why = 0;
         uint32_t n_segs_out = 0, arena_used = 0;
         CW_PROF_T0();
         if (ready) {
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             if (m == 0 || m < prm.min_anchors) {
                 new_status = CW_WIN_TEMPLATE;
             } else if (m + 1 > seg_cap) {
-                new_status = CW_WIN_OVERFLOW;
+                new_status = CW_WIN_OVERFLOW; why = CW_WHY_SEGMENTS;
             } else {
                 /* ================= phase D: segments =================
                    Lanes = segments, 64 at a time.  Each lane walks the pile once (two matrix reads per sequence, no stores
@@ -445,14 +446,14 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     cw_wave_sync();
                 }
                 if (!over && q_cnt) flush();
-                if (over) new_status = CW_WIN_OVERFLOW;
+                if (over) { new_status = CW_WIN_OVERFLOW; why = CW_WHY_TASKS; }
                 else n_segs_out = m + 1;
             }
             CW_PROF(sc.ctr, 6, lane == 0);
         }
         new_status = ch_uni(new_status); n_segs_out = ch_uni(n_segs_out); arena_used = ch_uni(arena_used);
         if (lane == 0) {
-            if (new_status != 0xFFFFFFFFu) { wi->status = new_status; if (new_status == CW_WIN_OVERFLOW) sc.ctr->any_overflow = 1; }
+            if (new_status != 0xFFFFFFFFu) { wi->status = new_status; if (new_status == CW_WIN_OVERFLOW) { wi->pad_ = why; sc.ctr->any_overflow = 1; } }
             else if (ready) { wi->n_segs = n_segs_out; wi->arena_used = arena_used; }
         }
         cw_wave_sync();

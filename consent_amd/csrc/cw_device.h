@@ -38,8 +38,23 @@ struct WinInfo {
     uint32_t arena_used;
     uint32_t ab_base;    /* anchor block (index kernel -> chain kernel), in 16-byte units into DevScratch::ablock */
     uint32_t ab_cap;     /* 16-byte units */
-    uint32_t pad_;
+    uint32_t pad_;       /* why the window overflowed (CW_WHY_*), 0 otherwise: an inspection aid (cw_debug_win_info word 15) */
 };
+
+#define CW_WHY_SETUP 1      /* scratch slices of the batch exhausted (cw_setup_kernel)               */
+#define CW_WHY_COUNT 2      /* more saturated / distinct k-mers than the exact count tables hold     */
+#define CW_WHY_SOLIDCAP 3   /* solid set larger than the window's slice                              */
+#define CW_WHY_TEMPLATE 4   /* template longer than CW_TMAX k-mers                                   */
+#define CW_WHY_MATRIX 5     /* position matrix larger than the fallback slot / the anchor block      */
+#define CW_WHY_SEGMENTS 6   /* more chain segments than slots                                        */
+#define CW_WHY_TASKS 7      /* task / member / arena capacity of the batch                           */
+#define CW_WHY_POA 8        /* a POA task outgrew every tier, or its output slot                     */
+#define CW_WHY_FIN_LEN 9    /* consensus longer than the finish kernel's string buffers              */
+#define CW_WHY_FIN_SOLID 10 /* more solid k-mers than the visited bitmap covers                      */
+#define CW_WHY_FIN_POLISH 11/* the polish outgrew a buffer                                           */
+#define CW_WHY_OUT_CONS 12  /* the caller's consensus slot is too small                              */
+#define CW_WHY_OUT_SOLID 13 /* the caller's solid slot is too small                                  */
+
 
 struct PoaTask {
     uint32_t window;
@@ -107,6 +122,9 @@ struct DevScratch {
     uint64_t p_fallback_elems;     /* u16 elements per slot */
     uint8_t* ablock;               /* per-window anchor blocks: candidates, presence bitsets, position matrix */
     uint64_t ablock_units;         /* capacity in 16-byte units */
+    unsigned long long* ex_fallback; /* index kernel: per-work-group exact table of saturated keys for very deep piles (CW_EXG_SLOTS each) */
+    uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
+    uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */
 };

@@ -1,0 +1,482 @@
+/*
+ * cw_driver.cpp -- the loop of CONSENT's two drivers behind one C entry point, cw_run_correction:
+ *
+ *   runCorrection / processRead    (src/CONSENT-correction.cpp:62-135, :19-58)   polishing = 0
+ *   runCorrection / processContig  (src/CONSENT-polishing.cpp:107-135, :21-105)  polishing = 1 (never trims, :19)
+ *
+ * Same inputs (the flags of src/main.cpp:29-76), same output: FASTA records ">name\nsequence\n" in PAF order, nothing for a read
+ * without windows or dropped by the 10 % rule (CONSENT-correction.cpp:23-25, :52-56, :101-103).
+ *
+ * Shape: ONE host process; the calling thread reads the PAF pile by pile (cw_paf_next_pile), cuts the windows
+ * (cw_window_positions) and packs piles into jobs of ~32k windows; one worker thread per device owns an engine and a copy of the
+ * 2-bit read set and pulls jobs from a bounded queue (dynamic: a device that finishes early takes the next job); per job the piles
+ * never leave the device: cw_extract_piles_device -> cw_plan_results_device -> cw_run_device -> cw_stitch_device, and only the
+ * corrected reads come back.  An emitter thread writes finished jobs in submission order, so the output does not depend on the
+ * number of devices.  No collective: jobs are independent.
+ *
+ * Host code only (device memory through the HIP runtime API); everything that computes is behind the C ABI of consent_amd.h.
+ */
+#include "cw_internal.h"
+#include "cw_private.h"
+
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Job {
+    uint64_t seq = 0;
+    std::vector<cw_overlap> ovl;
+    std::vector<cw_window_job> wj;
+    std::vector<uint32_t> win_pos;   /* (beg, end) per window */
+    std::vector<cw_stitch_read> sr;  /* one per pile */
+    uint64_t cost = 0;               /* sum over windows of (overlaps + 1): what the shard balance goes by */
+    /* results */
+    std::vector<std::string> out;    /* per pile; "" = no record */
+    int rc = CW_OK;
+    std::string err;
+    int device = -1;
+    double ms_extract = 0, ms_consensus = 0, ms_stitch = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return CW_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return CW_E_NOMEM; }
+        cap = want;
+        return CW_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Shared {
+    const cw_driver_args* a = nullptr;
+    const cw_read_index* index = nullptr;
+    cw_read_set host_reads{};
+    uint64_t read_words = 0;
+    bool do_trim = true;
+    bool skip_on_capacity = false;
+    /* job queue (producer -> workers) */
+    std::mutex mu;
+    std::condition_variable cv_work, cv_room, cv_done;
+    std::deque<Job*> queue;
+    size_t queue_cap = 4;
+    bool closed = false;
+    /* finished jobs, keyed by sequence number (workers -> emitter) */
+    std::map<uint64_t, Job*> finished;
+    bool abort = false;
+    int first_error = CW_OK;
+    std::string first_error_msg;
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+#define DRV_HIP(expr, job, what)                                                        \
+    do {                                                                                \
+        if ((expr) != hipSuccess) { (job).rc = CW_E_NO_DEVICE; (job).err = what; return; } \
+    } while (0)
+#define DRV_RC(expr, job, what)                                                         \
+    do {                                                                                \
+        const int _rc = (expr);                                                         \
+        if (_rc != CW_OK) { (job).rc = _rc; (job).err = what; return; }                 \
+    } while (0)
+
+struct Worker {
+    int device = 0;
+    cw_engine* eng = nullptr;
+    hipStream_t st = nullptr;
+    cw_read_set dev_reads{};
+    DevBuf rd_len, rd_off, rd_bases;
+    void* pin = nullptr; /* pinned landing buffer for the corrected reads */
+    size_t pin_cap = 0;
+    DevBuf ovl, wj, pos, sr, b_wfs, b_len, b_off, b_bases, r_cons, r_coff, r_clen, r_stat, r_solid, r_soff, r_slen, o_buf, o_off, o_len, o_stat;
+    uint64_t windows = 0, reads = 0, jobs = 0;
+    double ms_extract = 0, ms_consensus = 0, ms_stitch = 0;
+
+    int init(const Shared& sh) {
+        if (hipSetDevice(device) != hipSuccess) return CW_E_NO_DEVICE;
+        const cw_driver_args& a = *sh.a;
+        cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
+        int rc = cw_create(&prm, device, &eng);
+        if (rc != CW_OK) return rc;
+        if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
+        const uint32_t n = sh.host_reads.n_reads;
+        if ((rc = rd_len.ensure((size_t)n * 4 + 4)) || (rc = rd_off.ensure((size_t)n * 8 + 8)) || (rc = rd_bases.ensure((size_t)sh.read_words * 4 + 8))) return rc;
+        if (hipMemcpy(rd_len.p, sh.host_reads.read_len, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(rd_off.p, sh.host_reads.read_word_off, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(rd_bases.p, sh.host_reads.bases, (size_t)sh.read_words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset((uint8_t*)rd_bases.p + (size_t)sh.read_words * 4, 0, 8) != hipSuccess)
+            return CW_E_NO_DEVICE;
+        dev_reads.n_reads = n;
+        dev_reads.read_len = rd_len.as<uint32_t>();
+        dev_reads.read_word_off = rd_off.as<uint64_t>();
+        dev_reads.bases = rd_bases.as<uint32_t>();
+        return CW_OK;
+    }
+
+    void close() {
+        (void)hipSetDevice(device);
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        if (eng) { cw_destroy(eng); eng = nullptr; }
+    }
+
+    /* one job, start to end, on this worker's device */
+    void process(const Shared& sh, Job& j) {
+        const cw_driver_args& a = *sh.a;
+        const uint32_t n_win = (uint32_t)j.wj.size(), n_piles = (uint32_t)j.sr.size();
+        j.out.assign(n_piles, std::string());
+        j.device = device;
+        if (n_win == 0 || n_piles == 0) return;
+        const double t0 = now_ms();
+        DRV_HIP(hipSetDevice(device), j, "hipSetDevice");
+        DRV_RC(ovl.ensure(j.ovl.size() * sizeof(cw_overlap) + 64), j, "device memory (overlaps)");
+        DRV_RC(wj.ensure((size_t)n_win * sizeof(cw_window_job)), j, "device memory (window jobs)");
+        DRV_RC(pos.ensure((size_t)n_win * 8), j, "device memory (window positions)");
+        DRV_RC(sr.ensure((size_t)n_piles * sizeof(cw_stitch_read)), j, "device memory (reads)");
+        if (!j.ovl.empty()) DRV_HIP(hipMemcpyAsync(ovl.p, j.ovl.data(), j.ovl.size() * sizeof(cw_overlap), hipMemcpyHostToDevice, st), j, "H2D overlaps");
+        DRV_HIP(hipMemcpyAsync(wj.p, j.wj.data(), (size_t)n_win * sizeof(cw_window_job), hipMemcpyHostToDevice, st), j, "H2D jobs");
+        DRV_HIP(hipMemcpyAsync(pos.p, j.win_pos.data(), (size_t)n_win * 8, hipMemcpyHostToDevice, st), j, "H2D positions");
+        DRV_HIP(hipMemcpyAsync(sr.p, j.sr.data(), (size_t)n_piles * sizeof(cw_stitch_read), hipMemcpyHostToDevice, st), j, "H2D reads");
+
+        /* ---- piles, cut on the device ---- */
+        uint32_t n_seqs = 0;
+        uint64_t n_words = 0;
+        int rc = cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>(), j.wj.data(), n_win, a.mer_size, nullptr, nullptr, nullptr,
+                                 nullptr, 0, 0, &n_seqs, &n_words, st);
+        if (rc != CW_OK && rc != CW_E_CAPACITY) { j.rc = rc; j.err = "cw_extract_piles_device (sizing)"; return; }
+        DRV_RC(b_wfs.ensure((size_t)(n_win + 1) * 4), j, "device memory (batch)");
+        DRV_RC(b_len.ensure((size_t)n_seqs * 4 + 4), j, "device memory (batch)");
+        DRV_RC(b_off.ensure((size_t)n_seqs * 8 + 8), j, "device memory (batch)");
+        DRV_RC(b_bases.ensure((size_t)n_words * 4 + 8), j, "device memory (batch)");
+        DRV_HIP(hipMemsetAsync((uint8_t*)b_bases.p + (size_t)n_words * 4, 0, 8, st), j, "memset");
+        DRV_RC(cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>(), j.wj.data(), n_win, a.mer_size, b_wfs.as<uint32_t>(),
+                               b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>(), n_seqs, n_words, &n_seqs, &n_words, st),
+               j, "cw_extract_piles_device");
+        cw_batch batch{n_win, n_seqs, n_words, b_wfs.as<uint32_t>(), b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>()};
+        const double t1 = now_ms();
+
+        /* ---- consensus per window ---- */
+        DRV_RC(r_coff.ensure((size_t)(n_win + 1) * 8), j, "device memory (results)");
+        DRV_RC(r_soff.ensure((size_t)(n_win + 1) * 8), j, "device memory (results)");
+        uint64_t cons_total = 0, solid_total = 0;
+        DRV_RC(cw_plan_results_device(eng, &batch, r_coff.as<uint64_t>(), r_soff.as<uint64_t>(), &cons_total, &solid_total, st), j, "cw_plan_results_device");
+        DRV_RC(r_cons.ensure(cons_total + 16), j, "device memory (results)");
+        DRV_RC(r_solid.ensure(solid_total * 4 + 16), j, "device memory (results)");
+        DRV_RC(r_clen.ensure((size_t)n_win * 4), j, "device memory (results)");
+        DRV_RC(r_slen.ensure((size_t)n_win * 4), j, "device memory (results)");
+        DRV_RC(r_stat.ensure(n_win), j, "device memory (results)");
+        DRV_HIP(hipMemsetAsync(r_stat.p, 0xFF, n_win, st), j, "memset");
+        cw_result res{r_cons.as<char>(), r_coff.as<uint64_t>(), r_clen.as<uint32_t>(), r_stat.as<uint8_t>(), r_solid.as<uint32_t>(), r_soff.as<uint64_t>(), r_slen.as<uint32_t>()};
+        DRV_RC(cw_run_device(eng, &batch, &res, st), j, "cw_run_device");
+
+        /* ---- re-assembly per read ---- */
+        std::vector<uint64_t> out_off((size_t)n_piles + 1, 0);
+        for (uint32_t i = 0; i < n_piles; ++i) out_off[i + 1] = out_off[i] + 2ull * sh.host_reads.read_len[j.sr[i].read] + 1024ull;
+        DRV_RC(o_off.ensure((size_t)(n_piles + 1) * 8), j, "device memory (output)");
+        DRV_RC(o_buf.ensure(out_off[n_piles] + 16), j, "device memory (output)");
+        DRV_RC(o_len.ensure((size_t)n_piles * 4), j, "device memory (output)");
+        DRV_RC(o_stat.ensure(n_piles), j, "device memory (output)");
+        DRV_HIP(hipMemcpyAsync(o_off.p, out_off.data(), (size_t)(n_piles + 1) * 8, hipMemcpyHostToDevice, st), j, "H2D offsets");
+        DRV_HIP(hipMemsetAsync(o_len.p, 0, (size_t)n_piles * 4, st), j, "memset");
+        DRV_HIP(hipMemsetAsync(o_stat.p, 0xFF, n_piles, st), j, "memset");
+        double t2 = 0;
+        if (getenv("CW_DRIVER_TIMING")) { DRV_HIP(hipStreamSynchronize(st), j, "sync"); t2 = now_ms(); }
+        DRV_RC(cw_stitch_device(eng, &dev_reads, sr.as<cw_stitch_read>(), n_piles, pos.as<uint32_t>(), &batch, &res, a.window_size, a.window_overlap, sh.do_trim ? 1 : 0,
+                                o_buf.as<char>(), o_off.as<uint64_t>(), o_len.as<uint32_t>(), o_stat.as<uint8_t>(), st),
+               j, "cw_stitch_device");
+        std::vector<uint32_t> h_len(n_piles);
+        std::vector<uint8_t> h_st(n_piles), h_wst(n_win);
+        DRV_HIP(hipMemcpyAsync(h_len.data(), o_len.p, (size_t)n_piles * 4, hipMemcpyDeviceToHost, st), j, "D2H lengths");
+        DRV_HIP(hipMemcpyAsync(h_st.data(), o_stat.p, n_piles, hipMemcpyDeviceToHost, st), j, "D2H read status");
+        DRV_HIP(hipMemcpyAsync(h_wst.data(), r_stat.p, n_win, hipMemcpyDeviceToHost, st), j, "D2H window status");
+        DRV_HIP(hipStreamSynchronize(st), j, "kernels");
+        const double t3 = now_ms();
+        if (t2 == 0) t2 = t3;
+        /* a read whose re-assembly, or one of whose windows, exceeded a documented capacity is never silently different from the reference */
+        std::vector<char> tainted(n_piles, 0);
+        std::string names;
+        uint32_t n_bad = 0;
+        for (uint32_t i = 0; i < n_piles; ++i) {
+            bool bad = h_st[i] == CW_READ_CAPACITY;
+            for (uint32_t w = j.sr[i].win_first; !bad && w < j.sr[i].win_first + j.sr[i].win_count; ++w) bad = h_wst[w] == CW_WIN_OVERFLOW;
+            if (bad) {
+                tainted[i] = 1;
+                if (n_bad++ < 64) { names += names.empty() ? "" : ", "; names += cw_read_index_name(sh.index, j.sr[i].read); }
+            }
+        }
+        if (n_bad) { /* say which capacity: the engine keeps a reason per window (CW_WHY_*, cw_device.h) */
+            std::vector<uint32_t> wi((size_t)n_win * 16);
+            uint32_t n_st = 0, hist[16] = {0};
+            for (uint32_t i = 0; i < n_piles; ++i) n_st += h_st[i] == CW_READ_CAPACITY;
+            if (cw_debug_win_info(eng, n_win, wi.data()) == CW_OK)
+                for (uint32_t w = 0; w < n_win; ++w) if (h_wst[w] == CW_WIN_OVERFLOW) hist[wi[(size_t)w * 16 + 15] & 15u]++;
+            names += " [";
+            for (int q = 0; q < 16; ++q) if (hist[q]) names += "window reason " + std::to_string(q) + " x" + std::to_string(hist[q]) + "; ";
+            names += std::to_string(n_st) + " read(s) beyond a re-assembly limit]";
+        }
+        if (n_bad && !sh.skip_on_capacity) {
+            j.rc = CW_E_CAPACITY;
+            j.err = "engine capacity exceeded for " + std::to_string(n_bad) + " read(s): " + names + (n_bad > 64 ? ", ..." : "") + " (CW_ON_CAPACITY=skip leaves them out)";
+            return;
+        }
+        if (n_bad) fprintf(stderr, "[consent_amd] left out (engine capacity): %s%s\n", names.c_str(), n_bad > 64 ? ", ..." : "");
+        /* only the corrected reads come back: one transfer of the output slots into pinned memory, then one string per read */
+        uint64_t used_end = 0;
+        for (uint32_t i = 0; i < n_piles; ++i)
+            if (!tainted[i] && h_st[i] == CW_READ_OK && h_len[i]) used_end = out_off[i] + h_len[i];
+        if (used_end) {
+            if (pin_cap < used_end) {
+                if (pin) (void)hipHostFree(pin);
+                pin = nullptr; pin_cap = 0;
+                if (hipHostMalloc(&pin, used_end + used_end / 4, hipHostMallocDefault) != hipSuccess) { pin = nullptr; j.rc = CW_E_NOMEM; j.err = "pinned host memory"; return; }
+                pin_cap = used_end + used_end / 4;
+            }
+            DRV_HIP(hipMemcpyAsync(pin, o_buf.p, used_end, hipMemcpyDeviceToHost, st), j, "D2H reads");
+            DRV_HIP(hipStreamSynchronize(st), j, "D2H reads");
+            for (uint32_t i = 0; i < n_piles; ++i)
+                if (!tainted[i] && h_st[i] == CW_READ_OK && h_len[i]) j.out[i].assign((const char*)pin + out_off[i], h_len[i]);
+        }
+        const double t4 = now_ms();
+        j.ms_extract = t1 - t0; j.ms_consensus = t2 - t1; j.ms_stitch = t4 - t2;
+        windows += n_win; reads += n_piles; jobs++;
+        ms_extract += j.ms_extract; ms_consensus += j.ms_consensus; ms_stitch += j.ms_stitch;
+    }
+};
+
+void worker_main(Shared* sh, Worker* w) {
+    for (;;) {
+        Job* j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(sh->mu);
+            sh->cv_work.wait(lk, [&] { return !sh->queue.empty() || sh->closed || sh->abort; });
+            if (sh->abort || (sh->queue.empty() && sh->closed)) return;
+            j = sh->queue.front();
+            sh->queue.pop_front();
+            sh->cv_room.notify_all();
+        }
+        w->process(*sh, *j);
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            if (j->rc != CW_OK && sh->first_error == CW_OK) { sh->first_error = j->rc; sh->first_error_msg = j->err; sh->abort = true; sh->cv_work.notify_all(); sh->cv_room.notify_all(); }
+            sh->finished[j->seq] = j;
+            sh->cv_done.notify_all();
+        }
+    }
+}
+
+bool write_all(int fd, const char* p, size_t n) {
+    while (n) {
+        const ssize_t k = write(fd, p, n);
+        if (k < 0) return false;
+        p += k; n -= (size_t)k;
+    }
+    return true;
+}
+
+/* writes finished jobs in submission order: the FASTA does not depend on which device took which job */
+void emitter_main(Shared* sh, int out_fd, const uint64_t* n_jobs_total, const bool* producer_done, uint64_t* records, uint64_t* bases) {
+    uint64_t next = 0;
+    std::string buf;
+    for (;;) {
+        Job* j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(sh->mu);
+            sh->cv_done.wait(lk, [&] { return sh->finished.count(next) || sh->abort || (*producer_done && next >= *n_jobs_total); });
+            if (sh->abort) return;
+            if (!sh->finished.count(next)) return; /* everything written */
+            j = sh->finished[next];
+            sh->finished.erase(next);
+        }
+        buf.clear();
+        for (size_t i = 0; i < j->out.size(); ++i) {
+            if (j->out[i].empty()) continue;
+            buf += '>'; buf += cw_read_index_name(sh->index, j->sr[i].read); buf += '\n';
+            buf += j->out[i]; buf += '\n';
+            ++*records; *bases += j->out[i].size();
+        }
+        const bool ok = buf.empty() || write_all(out_fd, buf.data(), buf.size());
+        delete j;
+        ++next;
+        if (!ok) {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            if (sh->first_error == CW_OK) { sh->first_error = CW_E_INTERNAL; sh->first_error_msg = "write to the output failed"; }
+            sh->abort = true; sh->cv_work.notify_all(); sh->cv_room.notify_all();
+            return;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!a || !a->alignment_file || !a->reads_file || out_fd < 0) return CW_E_INVALID;
+    if (a->window_size == 0 || a->window_overlap >= a->window_size || a->mer_size < 2 || a->mer_size > 16 || a->solid_thresh < 1 || a->max_msa < 1) return CW_E_INVALID;
+    const double t_begin = now_ms();
+    Shared sh;
+    sh.a = a;
+    const bool has_proof = a->proof_file && a->proof_file[0];
+    sh.do_trim = !a->polishing && !has_proof; /* CONSENT-correction.cpp:17,69-73; CONSENT-polishing.cpp:19 */
+    if (const char* oc = getenv("CW_ON_CAPACITY")) sh.skip_on_capacity = strcmp(oc, "skip") == 0;
+
+    /* ---- indexReads (+ the proof file into the same index) ---- */
+    cw_read_index* index = nullptr;
+    int rc = cw_index_reads(a->reads_file, &index);
+    if (rc != CW_OK) { fprintf(stderr, "[consent_amd] cannot index %s: %s\n", a->reads_file, cw_strerror(rc)); return rc; }
+    if (has_proof && (rc = cw_index_reads_append(index, a->proof_file)) != CW_OK) {
+        fprintf(stderr, "[consent_amd] cannot index %s: %s\n", a->proof_file, cw_strerror(rc));
+        cw_read_index_free(index);
+        return rc;
+    }
+    sh.index = index;
+    cw_read_index_view(index, &sh.host_reads, &sh.read_words);
+    const double t_indexed = now_ms();
+
+    /* ---- devices: explicit list, or CW_DEVICES="0,1,..." (an id may repeat: several engines on one GPU), or the first
+            min(nb_threads, device count) devices ---- */
+    std::vector<int> devs;
+    if (a->devices && a->n_devices > 0) devs.assign(a->devices, a->devices + a->n_devices);
+    else if (const char* env = getenv("CW_DEVICES")) {
+        for (const char* p = env; *p;) { char* e = nullptr; const long v = strtol(p, &e, 10); if (e == p) break; devs.push_back((int)v); p = *e == ',' ? e + 1 : e; }
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { cw_read_index_free(index); fprintf(stderr, "[consent_amd] no HIP device: the engine has no CPU path\n"); return CW_E_NO_DEVICE; }
+    if (devs.empty()) { const int want = a->nb_threads < 1 ? 1 : (int)a->nb_threads; for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d); }
+    for (int d : devs) if (d < 0 || d >= n_dev) { cw_read_index_free(index); return CW_E_INVALID; }
+
+    std::vector<Worker> workers(devs.size());
+    std::vector<int> init_rc(devs.size(), CW_OK);
+    {   /* engines and read-set uploads, all devices at once */
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < devs.size(); ++i) { workers[i].device = devs[i]; th.emplace_back([&, i] { init_rc[i] = workers[i].init(sh); }); }
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < devs.size(); ++i)
+        if (init_rc[i] != CW_OK) {
+            fprintf(stderr, "[consent_amd] device %d: %s\n", devs[i], cw_strerror(init_rc[i]));
+            for (auto& w : workers) w.close();
+            cw_read_index_free(index);
+            return init_rc[i];
+        }
+    sh.queue_cap = 2 * devs.size() + 1;
+
+    uint64_t n_jobs_total = 0, records = 0, bases_out = 0;
+    bool producer_done = false;
+    std::vector<std::thread> threads;
+    for (auto& w : workers) threads.emplace_back(worker_main, &sh, &w);
+    std::thread emitter(emitter_main, &sh, out_fd, &n_jobs_total, &producer_done, &records, &bases_out);
+
+    /* ---- producer: getNextReadPile -> getAlignmentWindowsPositions -> jobs ---- */
+    const uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
+    cw_paf_reader* paf = nullptr;
+    rc = cw_paf_open(a->alignment_file, index, a->max_support, &paf);
+    uint64_t n_piles = 0, n_windows = 0, n_overlaps = 0;
+    if (rc == CW_OK) {
+        std::vector<cw_overlap> ov(a->max_support ? a->max_support : 1);
+        std::vector<uint32_t> wp;
+        Job* cur = new Job();
+        auto push_job = [&]() {
+            if (cur->wj.empty()) return true;
+            cur->seq = n_jobs_total;
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv_room.wait(lk, [&] { return sh.queue.size() < sh.queue_cap || sh.abort; });
+            if (sh.abort) return false;
+            sh.queue.push_back(cur);
+            ++n_jobs_total;
+            sh.cv_work.notify_one();
+            cur = new Job();
+            return true;
+        };
+        for (;;) {
+            uint32_t tpl = 0, tpl_len = 0, n = 0;
+            rc = cw_paf_next_pile(paf, &tpl, &tpl_len, ov.data(), nullptr, (uint32_t)ov.size(), &n);
+            if (rc != CW_OK) { fprintf(stderr, "[consent_amd] %s: %s (malformed line, a name missing from the read file, or a length that disagrees with it)\n", a->alignment_file, cw_strerror(rc)); break; }
+            if (n == 0) break;
+            if (tpl_len != sh.host_reads.read_len[tpl]) {
+                fprintf(stderr, "[consent_amd] %s states length %u for %s, the read file has %u\n", a->alignment_file, tpl_len, cw_read_index_name(index, tpl), sh.host_reads.read_len[tpl]);
+                rc = CW_E_INVALID;
+                break;
+            }
+            uint32_t np = 0;
+            wp.resize(2 * ((size_t)tpl_len / (a->window_size - a->window_overlap) + 8));
+            rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), (uint32_t)(wp.size() / 2), &np);
+            if (rc == CW_E_CAPACITY) { wp.resize(2 * (size_t)np); rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), np, &np); }
+            if (rc != CW_OK) break;
+            ++n_piles;
+            if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
+            if (np > CW_MAX_BATCH_WINDOWS) { fprintf(stderr, "[consent_amd] %s has %u windows; one job holds at most %u\n", cw_read_index_name(index, tpl), np, CW_MAX_BATCH_WINDOWS); rc = CW_E_CAPACITY; break; }
+            if (!cur->wj.empty() && cur->wj.size() + np > CW_MAX_BATCH_WINDOWS && !push_job()) break;
+            cw_stitch_read s{tpl, (uint32_t)cur->wj.size(), np};
+            const uint32_t ovl_first = (uint32_t)cur->ovl.size();
+            cur->ovl.insert(cur->ovl.end(), ov.begin(), ov.begin() + n);
+            for (uint32_t i = 0; i < np; ++i) {
+                cur->wj.push_back(cw_window_job{tpl, wp[2 * i], wp[2 * i + 1], ovl_first, n});
+                cur->win_pos.push_back(wp[2 * i]); cur->win_pos.push_back(wp[2 * i + 1]);
+            }
+            cur->sr.push_back(s);
+            cur->cost += (uint64_t)np * (n + 1);
+            n_windows += np; n_overlaps += n;
+            if (cur->wj.size() >= per_job && !push_job()) break;
+        }
+        if (rc == CW_OK) push_job();
+        delete cur;
+        cw_paf_close(paf);
+    } else {
+        fprintf(stderr, "[consent_amd] cannot open %s\n", a->alignment_file);
+    }
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        producer_done = true;
+        sh.closed = true;
+        if (rc != CW_OK) { if (sh.first_error == CW_OK) { sh.first_error = rc; sh.first_error_msg = "reading the alignments"; } sh.abort = true; }
+        sh.cv_work.notify_all(); sh.cv_done.notify_all(); sh.cv_room.notify_all();
+    }
+    for (auto& t : threads) t.join();
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.cv_done.notify_all();
+    }
+    emitter.join();
+    for (auto& kv : sh.finished) delete kv.second;
+    for (Job* j : sh.queue) delete j;
+    const double t_end = now_ms();
+    if (stats) {
+        stats->n_devices = (uint32_t)devs.size();
+        stats->piles = n_piles; stats->windows = n_windows; stats->overlaps = n_overlaps; stats->jobs = n_jobs_total;
+        stats->records = records; stats->bases_out = bases_out;
+        stats->ms_index = t_indexed - t_begin; stats->ms_total = t_end - t_begin;
+        for (size_t i = 0; i < workers.size() && i < 16; ++i) {
+            stats->dev_windows[i] = workers[i].windows;
+            stats->dev_ms_extract[i] = workers[i].ms_extract; stats->dev_ms_consensus[i] = workers[i].ms_consensus; stats->dev_ms_stitch[i] = workers[i].ms_stitch;
+        }
+    }
+    if (getenv("CW_DRIVER_STATS")) { /* counters on stderr; stdout stays pure FASTA */
+        fprintf(stderr, "{\"devices\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
+                devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
+                t_indexed - t_begin, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
+        for (size_t i = 0; i < workers.size(); ++i)
+            fprintf(stderr, "%s{\"device\": %d, \"windows\": %llu, \"jobs\": %llu, \"ms_extract\": %.1f, \"ms_consensus\": %.1f, \"ms_stitch\": %.1f}", i ? ", " : "", workers[i].device,
+                    (unsigned long long)workers[i].windows, (unsigned long long)workers[i].jobs, workers[i].ms_extract, workers[i].ms_consensus, workers[i].ms_stitch);
+        fprintf(stderr, "]}\n");
+    }
+    for (auto& w : workers) w.close();
+    cw_read_index_free(index);
+    if (sh.first_error != CW_OK) fprintf(stderr, "[consent_amd] %s: %s\n", sh.first_error_msg.c_str(), cw_strerror(sh.first_error));
+    return sh.first_error;
+}

@@ -45,7 +45,7 @@ void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, finvis, exg, total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap;
@@ -83,6 +83,8 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);
+    put(p.exg, (size_t)cus * CW_EXG_SLOTS * 8);
+    put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
     p.total = o;
     return p;
 }
@@ -259,6 +261,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     }
     sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
     sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
+    sc.ex_fallback = (unsigned long long*)(base + p.exg);
+    sc.fin_vis = (uint32_t*)(base + p.finvis); sc.fin_vis_words = CW_FIN_VIS_GLB_WORDS;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     sc.producer_wgs = (uint32_t)cus * 3 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
@@ -455,6 +459,14 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
                             const cw_window_job* jobs, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len,
                             uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
                             uint64_t* n_words, void* hip_stream) {
+    return cw_extract_impl(e, reads, overlaps, n_overlaps, jobs, nullptr, n_jobs, k, win_first_seq, seq_len, seq_word_off, bases, seq_cap, word_cap, n_seqs,
+                           n_words, hip_stream);
+}
+
+/* jobs_host: the same jobs in host memory when the caller has them (the library's own driver does): saves the device-to-host copy */
+int cw_extract_impl(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps, const cw_window_job* jobs,
+                    const cw_window_job* jobs_host, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len, uint64_t* seq_word_off,
+                    uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs, uint64_t* n_words, void* hip_stream) {
     if (!e || !reads || !jobs || !n_seqs || !n_words || (n_overlaps && !overlaps) || k < 1) return CW_E_INVALID;
     *n_seqs = 0; *n_words = 0;
     if (n_jobs == 0) return CW_OK;
@@ -462,11 +474,14 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     /* per-window descriptor offsets need the jobs' overlap counts: take them from the device once */
-    std::vector<cw_window_job> hj;
+    std::vector<cw_window_job> hj_own;
     std::vector<uint64_t> doff;
-    try { hj.resize(n_jobs); doff.assign((size_t)n_jobs + 1, 0); } catch (...) { return CW_E_NOMEM; }
-    CW_HIP(hipMemcpyAsync(hj.data(), jobs, (size_t)n_jobs * sizeof(cw_window_job), hipMemcpyDeviceToHost, st));
-    CW_HIP(hipStreamSynchronize(st));
+    try { if (!jobs_host) hj_own.resize(n_jobs); doff.assign((size_t)n_jobs + 1, 0); } catch (...) { return CW_E_NOMEM; }
+    if (!jobs_host) {
+        CW_HIP(hipMemcpyAsync(hj_own.data(), jobs, (size_t)n_jobs * sizeof(cw_window_job), hipMemcpyDeviceToHost, st));
+        CW_HIP(hipStreamSynchronize(st));
+    }
+    const cw_window_job* hj = jobs_host ? jobs_host : hj_own.data();
     for (uint32_t w = 0; w < n_jobs; ++w) {
         if ((uint64_t)hj[w].ovl_first + hj[w].ovl_count > n_overlaps || hj[w].tpl_read >= reads->n_reads || hj[w].q_end < hj[w].q_beg) return CW_E_INVALID;
         doff[w + 1] = doff[w] + hj[w].ovl_count;
@@ -499,6 +514,30 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
     if (tot_s > seq_cap || tot_w > word_cap || !win_first_seq || !seq_len || !seq_word_off || !bases) return CW_E_CAPACITY;
     cw_extract_fill_kernel<<<(n_jobs + 1 + 3) / 4, 256, 0, st>>>(a);
     CW_HIP(hipGetLastError());
+    return CW_OK;
+}
+
+int cw_plan_results_device(cw_engine* e, const cw_batch* batch, uint64_t* cons_off, uint64_t* solid_off, uint64_t* cons_total, uint64_t* solid_total,
+                           void* hip_stream) {
+    if (!e || !batch || !cons_off || !solid_off || !cons_total || !solid_total) return CW_E_INVALID;
+    *cons_total = 0; *solid_total = 0;
+    if (batch->n_windows == 0) return CW_OK;
+    if (!batch->win_first_seq || !batch->seq_len) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CW_HIP(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    int rc = ensure(&e->xscratch, &e->xscratch_bytes, 256);
+    if (rc) return rc;
+    PlanArgs a;
+    a.n_windows = batch->n_windows; a.k = e->prm.k; a.solid = e->prm.solid;
+    a.win_first_seq = batch->win_first_seq; a.seq_len = batch->seq_len;
+    a.cons_off = cons_off; a.solid_off = solid_off; a.totals = (uint64_t*)e->xscratch;
+    cw_plan_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(a);
+    cw_plan_scan_kernel<<<1, 1024, 0, st>>>(a);
+    uint64_t tot[2] = {0, 0};
+    CW_HIP(hipMemcpyAsync(tot, a.totals, 16, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipStreamSynchronize(st));
+    *cons_total = tot[0]; *solid_total = tot[1];
     return CW_OK;
 }
 

@@ -17,7 +17,8 @@
 
 #define CW_FIN_WAVES 4
 #define CW_FIN_CB 3072        /* string capacity per buffer              */
-#define CW_FIN_VIS_WORDS 1024 /* visited bitmap: up to 32768 solid k-mers */
+#define CW_FIN_VIS_WORDS 1024 /* visited bitmap in LDS: up to 32768 solid k-mers */
+#define CW_FIN_VIS_GLB_WORDS 8192 /* per-wave bitmap in global memory beyond that: 4^9 keys, the most a direct count table can export */
 #define CW_FIN_FRAMES 56
 #define CW_FIN_SKEYS 1024     /* solid keys staged in LDS (every lookup of the polish is a binary search in them) */
 #define CW_FIN_SLAB (3 * CW_FIN_CB + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256 + 4 * CW_FIN_SKEYS + 16)
@@ -424,8 +425,9 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
     FinLds M;
     uint8_t* buf0 = slab; uint8_t* buf1 = slab + CW_FIN_CB;
     M.path = slab + 2 * CW_FIN_CB;
-    M.vis = (uint32_t*)(slab + 3 * CW_FIN_CB);
-    M.f_nbk = M.vis + CW_FIN_VIS_WORDS;
+    uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CW_FIN_CB);
+    M.vis = vis_lds;
+    M.f_nbk = vis_lds + CW_FIN_VIS_WORDS;
     M.f_nbi = M.f_nbk + CW_FIN_FRAMES * 4;
     M.f_meta = M.f_nbi + CW_FIN_FRAMES * 4;
     M.f_dist = M.f_meta + CW_FIN_FRAMES;
@@ -442,6 +444,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
         const uint32_t s0 = b.win_first_seq[w];
         const uint64_t o_beg = out.cons_off[w], o_cap = out.cons_off[w + 1] - o_beg;
         uint32_t status = wi.status;
+        uint32_t why = 0;
         int len = 0;
         M.s = buf0; M.alt = buf1;
 
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
             len = 0; /* a window beyond its template has an empty pile (alignmentWindows.cpp:95-97) */
         } else if (status == CW_WIN_TEMPLATE) { /* correctionMSA.cpp:34-36: the raw template */
             const uint32_t* words = b.bases + b.seq_word_off[s0];
-            if (wi.tpl_len > o_cap) status = CW_WIN_OVERFLOW;
+            if (wi.tpl_len > o_cap) { status = CW_WIN_OVERFLOW; why = CW_WHY_OUT_CONS; }
             else {
                 for (uint32_t q = lane; q < wi.tpl_len; q += 64) out.cons[o_beg + q] = "ACGT"[cw_base_at(words, q)];
                 len = (int)wi.tpl_len;
@@ -473,7 +476,11 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                 total = tot;
             }
             cw_wave_sync();
-            if (bad || wi.n_solid > 32u * CW_FIN_VIS_WORDS) status = CW_WIN_OVERFLOW;
+            /* the visited bitmap of link(): in LDS for up to 32768 solid k-mers (every correction pile); the piles of assembly polishing are
+               as deep as the coverage and can hold more: then this wave's slot in global memory */
+            const bool vis_glb = wi.n_solid > 32u * CW_FIN_VIS_WORDS;
+            M.vis = vis_glb ? sc.fin_vis + (size_t)(blockIdx.x * CW_FIN_WAVES + wave) * sc.fin_vis_words : vis_lds;
+            if (bad || wi.n_solid > 32u * sc.fin_vis_words) { status = CW_WIN_OVERFLOW; why = bad ? CW_WHY_FIN_LEN : CW_WHY_FIN_SOLID; }
             else {
                 len = (int)total;
                 if ((uint32_t)len >= prm.k) { /* correctionMSA.cpp:43-46 */
@@ -482,7 +489,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                     c.scnt16 = nullptr; c.staged = false;
                     if (wi.n_solid <= CW_FIN_SKEYS) { /* the usual case: searches run at LDS latency */
                         /* the visited bitmap needs 32 words for that many k-mers: the counts go behind it, as u16 when they all fit */
-                        uint16_t* cnt_lds = (uint16_t*)(M.vis + 64);
+                        uint16_t* cnt_lds = (uint16_t*)(vis_lds + 64);
                         bool big = false;
                         for (uint32_t q = lane; q < wi.n_solid; q += 64) {
                             skey_lds[q] = c.skey[q];
@@ -511,10 +518,10 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                     for (uint32_t q = lane; q < (wi.n_solid + 31) / 32; q += 64) M.vis[q] = 0;
                     cw_wave_sync();
                     len = fin_polish(c, M, (uint32_t)len, lane);
-                    if (len < 0) { status = CW_WIN_OVERFLOW; len = 0; }
+                    if (len < 0) { status = CW_WIN_OVERFLOW; why = CW_WHY_FIN_POLISH; len = 0; }
                 }
                 if (status == CW_WIN_CONSENSUS) {
-                    if ((uint64_t)len > o_cap) { status = CW_WIN_OVERFLOW; len = 0; }
+                    if ((uint64_t)len > o_cap) { status = CW_WIN_OVERFLOW; why = CW_WHY_OUT_CONS; len = 0; }
                     else for (uint32_t q = lane; q < (uint32_t)len; q += 64) out.cons[o_beg + q] = (char)M.s[q];
                 }
             }
@@ -523,14 +530,14 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
         uint32_t n_sol = 0;
         if (out.solid && status != CW_WIN_OVERFLOW) {
             const uint64_t so = out.solid_off[w], scap = out.solid_off[w + 1] - so;
-            if (wi.n_solid > scap) { status = CW_WIN_OVERFLOW; len = 0; }
+            if (wi.n_solid > scap) { status = CW_WIN_OVERFLOW; why = CW_WHY_OUT_SOLID; len = 0; }
             else {
                 for (uint32_t q = lane; q < wi.n_solid; q += 64) out.solid[so + q] = sc.solid_key[wi.solid_base + q];
                 n_sol = wi.n_solid;
             }
         }
         if (lane == 0) {
-            if (status == CW_WIN_OVERFLOW) { len = 0; sc.ctr->any_overflow = 1; }
+            if (status == CW_WIN_OVERFLOW) { len = 0; sc.ctr->any_overflow = 1; if (why) sc.win[w].pad_ = why; }
             out.cons_len[w] = (uint32_t)len;
             out.win_status[w] = (uint8_t)status;
             if (out.solid) out.solid_len[w] = (status == CW_WIN_OVERFLOW) ? 0u : n_sol;

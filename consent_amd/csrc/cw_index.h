@@ -25,6 +25,7 @@
 #define CW_IDX_LDS_BYTES 163840
 #define CW_TMAX 1024 /* template k-mer slots */
 #define CW_EX_SLOTS 2048
+#define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 /* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
    lengths, word offsets and the 2-bit words themselves, so that the four passes over the pile's k-mers read LDS instead of walking
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             wi.seg_base = (uint32_t)gb; wi.seg_cap = need_seg; wi.n_segs = 0;
             wi.arena_base = (uint32_t)ab; wi.arena_cap = need_arena; wi.arena_used = 0;
             wi.ab_base = (uint32_t)kb; wi.ab_cap = need_ab; wi.pad_ = 0;
-            if (over) { wi.status = CW_WIN_OVERFLOW; wi.solid_cap = wi.seg_cap = wi.arena_cap = wi.ab_cap = 0; wi.solid_base = wi.seg_base = wi.arena_base = wi.ab_base = 0; }
+            if (over) { wi.status = CW_WIN_OVERFLOW; wi.pad_ = CW_WHY_SETUP; wi.solid_cap = wi.seg_cap = wi.arena_cap = wi.ab_cap = 0; wi.solid_base = wi.seg_base = wi.arena_base = wi.ab_base = 0; }
             sc.win[w] = wi;
         }
         __syncthreads();
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (fits && np2 > HS) fits = false;
             if (tid == 0) {
                 wi->n_solid = fits ? written : 0;
-                if (!fits) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                if (!fits) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_COUNT; sc.ctr->any_overflow = 1; }
             }
             __threadfence_block();
             __syncthreads();
@@ -335,8 +336,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 __syncthreads();
             }
         } else {
+        /* keys that occur 16 times or more: at most n_kmers / 16 of them.  The LDS table holds every pile of read correction (<= 151
+           sequences); the piles of assembly polishing are as deep as the coverage (maxSupport = 20000, CONSENT-polish:43) and use this
+           work-group's table in global memory instead */
+        const bool big_ex = wi->n_kmers / 16u > CW_EX_SLOTS / 2u;
+        unsigned long long* const exg = sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS;
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
+        if (big_ex) for (uint32_t i = tid; i < CW_EXG_SLOTS; i += CW_IDX_THREADS) exg[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
         /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in the small hash table ex[] (key + 1 in the
@@ -352,8 +359,19 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 old = prev;
             }
             if (!sat) continue;
-            uint32_t slot = cw_hash32(key) >> (32 - 11);
             const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;
+            if (big_ex) {
+                uint32_t slot = cw_hash32(key) >> (32 - 18);
+                for (uint32_t probe = 0;; ++probe) {
+                    if (probe >= CW_EXG_SLOTS) { flags[0] = 1; break; }
+                    unsigned long long cur = atomicCAS(&exg[slot], 0ull, fresh);
+                    if (cur == 0ull) break;
+                    if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&exg[slot], 1ull); break; }
+                    slot = (slot + 1) & (CW_EXG_SLOTS - 1);
+                }
+                continue;
+            }
+            uint32_t slot = cw_hash32(key) >> (32 - 11);
             for (uint32_t probe = 0;; ++probe) {
                 if (probe >= CW_EX_SLOTS) { flags[0] = 1; break; }
                 unsigned long long cur = atomicCAS(&ex[slot], 0ull, fresh);
@@ -366,7 +384,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         CW_PROF(sc.ctr, 0, tid == 0);
         CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than the exact table holds */
-            if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_COUNT; sc.ctr->any_overflow = 1; }
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
@@ -379,6 +397,18 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             const uint32_t w_beg = min(nib_words, (uint32_t)tid * wpt), w_cnt = min(nib_words, w_beg + wpt) - w_beg;
             uint32_t lk[8], lc[8];
             uint32_t mine = 0;
+            auto ex_lookup = [&](const uint32_t key) -> uint32_t { /* occurrences beyond the 15th */
+                if (big_ex) {
+                    uint32_t slot = cw_hash32(key) >> (32 - 18);
+                    unsigned long long xe = exg[slot];
+                    while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EXG_SLOTS - 1); xe = exg[slot]; }
+                    return (uint32_t)xe;
+                }
+                uint32_t slot = cw_hash32(key) >> (32 - 11);
+                unsigned long long xe = ex[slot];
+                while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
+                return (uint32_t)xe;
+            };
             const uint32_t add = (16u - (prm.solid < 15u ? prm.solid : 15u)) * 0x01010101u;
             auto scan_word = [&](const uint32_t v, const uint32_t wd) {
                 if (v == 0) return;
@@ -393,12 +423,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     const uint32_t nib = (v >> (4 * q)) & 15u;
                     const uint32_t key = wd * 8 + q;
                     uint32_t c = nib;
-                    if (nib == 15u) {
-                        uint32_t slot = cw_hash32(key) >> (32 - 11);
-                        unsigned long long xe = ex[slot];
-                        while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
-                        c = 15u + (uint32_t)xe; /* exactly 15 occurrences leave no entry */
-                    }
+                    if (nib == 15u) c = 15u + ex_lookup(key); /* exactly 15 occurrences leave no entry */
                     if (c < prm.solid) continue;
 #pragma unroll
                     for (int z = 0; z < 8; ++z) if ((uint32_t)z == mine) { lk[z] = key; lc[z] = c; }
@@ -439,12 +464,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                         if (!nib) continue;
                         const uint32_t key = wd * 8 + q;
                         uint32_t c = nib;
-                        if (nib == 15u) {
-                            uint32_t slot = cw_hash32(key) >> (32 - 11);
-                            unsigned long long xe = ex[slot];
-                            while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
-                            c = 15u + (uint32_t)xe;
-                        }
+                        if (nib == 15u) c = 15u + ex_lookup(key);
                         if (c >= prm.solid) { sc.solid_key[o] = key; sc.solid_cnt[o] = c; o++; }
                     }
                 }
@@ -462,7 +482,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
             if (tid == 0) {
                 wi->n_solid = fits ? total : 0;
-                if (!fits) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                if (!fits) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_SOLIDCAP; sc.ctr->any_overflow = 1; }
             }
             __syncthreads();
             if (!fits) continue;
@@ -477,7 +497,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         if (nk0 == 0 || nk0 > CW_TMAX) {
             if (tid == 0) {
                 if (nk0 == 0) wi->status = CW_WIN_TEMPLATE;
-                else { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                else { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_TEMPLATE; sc.ctr->any_overflow = 1; }
             }
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
@@ -542,7 +562,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         /* LDS needs: the matrix (A*Np u16) + presence bitsets (A*Nw u64) + dirty list (N u16) */
         const bool pg = !tfit && (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
         if (pg && (uint64_t)A * Np > sc.p_fallback_elems) {
-            if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+            if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_MATRIX; sc.ctr->any_overflow = 1; }
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;
         }
@@ -621,7 +641,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         {
             uint8_t* blk = sc.ablock + ((size_t)wi->ab_base << 4);
             if (cw_ab_bytes(A, N, n_dirty) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
-                if (tid == 0) { wi->status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+                if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_MATRIX; sc.ctr->any_overflow = 1; }
                 __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
                 continue;
             }

@@ -61,6 +61,11 @@ struct cw_engine {
     size_t last_ctr_off = 0; /* where the last run's BatchCounters sit in scratch */
 };
 
+extern "C" int cw_extract_impl(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps, const cw_window_job* jobs,
+                               const cw_window_job* jobs_host, uint32_t n_jobs, uint32_t k, uint32_t* win_first_seq, uint32_t* seq_len,
+                               uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs, uint64_t* n_words,
+                               void* hip_stream);
+
 #define CW_HIP(expr)                                   \
     do {                                               \
         hipError_t _e = (expr);                        \

@@ -71,4 +71,56 @@ __global__ void __launch_bounds__(256) cw_pack_copy_kernel(PackArgs a) {
     }
 }
 
+/* ---- result-slot planning for device-resident batches (cw_plan_results_device) ----------------------------------------------
+ * cons slot = 3 x template + 256 bytes (the polish can lengthen a consensus; the engine reports an overflow beyond it);
+ * solid slot = (k-mers in the pile) / solidThresh + 16 entries (a k-mer needs solidThresh occurrences to be solid). */
+struct PlanArgs {
+    uint32_t n_windows, k, solid;
+    const uint32_t* win_first_seq;
+    const uint32_t* seq_len;
+    uint64_t* cons_off;  /* [n_windows + 1] */
+    uint64_t* solid_off; /* [n_windows + 1] */
+    uint64_t* totals;    /* [2] */
+};
+
+__global__ void __launch_bounds__(256) cw_plan_need_kernel(PlanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= a.n_windows) return;
+    const uint32_t s0 = a.win_first_seq[w], s1 = a.win_first_seq[w + 1];
+    unsigned long long nk = 0;
+    for (uint32_t s = s0 + lane; s < s1; s += 64) { const uint32_t l = a.seq_len[s]; nk += l >= a.k ? l - a.k + 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o);
+    if (lane == 0) {
+        a.cons_off[w] = s1 > s0 ? 3ull * a.seq_len[s0] + 256ull : 256ull;
+        a.solid_off[w] = nk / a.solid + 16ull;
+    }
+}
+
+__global__ void __launch_bounds__(1024) cw_plan_scan_kernel(PlanArgs a) {
+    __shared__ unsigned long long pa[1024], pb[1024];
+    __shared__ unsigned long long run[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) run[tid] = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < a.n_windows; w0 += 1024) {
+        const uint32_t w = w0 + tid;
+        const unsigned long long c = w < a.n_windows ? a.cons_off[w] : 0, s = w < a.n_windows ? a.solid_off[w] : 0;
+        pa[tid] = c; pb[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            unsigned long long va = 0, vb = 0;
+            if (tid >= o) { va = pa[tid - o]; vb = pb[tid - o]; }
+            __syncthreads();
+            pa[tid] += va; pb[tid] += vb;
+            __syncthreads();
+        }
+        if (w < a.n_windows) { a.cons_off[w] = run[0] + pa[tid] - c; a.solid_off[w] = run[1] + pb[tid] - s; }
+        __syncthreads();
+        if (tid == 0) { run[0] += pa[1023]; run[1] += pb[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { a.cons_off[a.n_windows] = run[0]; a.solid_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; }
+}
+
 #endif

@@ -874,9 +874,9 @@ __device__ __forceinline__ void poa_hand_over(const DevScratch& sc, const PoaTas
         const uint32_t bi = atomicAdd(&sc.ctr->n_over[next_tier], 1u);
         /* the entry itself is the flag (pre-set to 0xFFFFFFFF): tier L may be consuming this list while we produce */
         if (bi < sc.list_cap) __hip_atomic_store(&sc.over_list[next_tier][bi], ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1; }
+        else { sc.win[t.window].status = CW_WIN_OVERFLOW; sc.win[t.window].pad_ = CW_WHY_POA; sc.ctr->any_overflow = 1; }
     } else if (rc != 1) {
-        sc.win[t.window].status = CW_WIN_OVERFLOW; sc.ctr->any_overflow = 1;
+        sc.win[t.window].status = CW_WIN_OVERFLOW; sc.win[t.window].pad_ = CW_WHY_POA; sc.ctr->any_overflow = 1;
     }
     sc.tasks[ti].state = (uint32_t)rc;
 }

@@ -438,7 +438,7 @@ class Engine:
         ns, nw = C.c_uint32(), C.c_uint64()
         rc = self.lib.cw_extract_piles_device(self.handle, C.byref(rs), t_ov.data_ptr(), len(ov), t_jb.data_ptr(), len(jb), k, None, None, None, None, 0, 0, C.byref(ns), C.byref(nw), None)
         if rc not in (0, -4):
-            _check(self.lib, rc, "cw_extract_piles_device(size)")
+            _check(self.lib, rc, "cw_extract_piles_device(size)")  # -4 here only says "now you know the sizes"; a real capacity error repeats below
         o_wfs = torch.zeros(len(jb) + 1, dtype=torch.int32, device=dev)
         o_len = torch.zeros(max(ns.value, 1), dtype=torch.int32, device=dev)
         o_off = torch.zeros(max(ns.value, 1), dtype=torch.int64, device=dev)

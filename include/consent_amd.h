@@ -182,6 +182,12 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
                             uint64_t* seq_word_off, uint32_t* bases, uint32_t seq_cap, uint64_t word_cap, uint32_t* n_seqs,
                             uint64_t* n_words, void* hip_stream);
 
+/* Result slots for a device-resident batch (what a caller of cw_run_device has to size before the call): writes the exclusive offsets
+ * cons_off[n_windows+1] (3 x template length + 256 bytes per window: the polish may lengthen a consensus) and solid_off[n_windows+1]
+ * (k-mers in the window's pile / solidThresh + 16 entries), both DEVICE arrays, and returns their totals (one synchronisation). */
+int cw_plan_results_device(cw_engine* e, const cw_batch* batch, uint64_t* cons_off, uint64_t* solid_off, uint64_t* cons_total, uint64_t* solid_total,
+                           void* hip_stream);
+
 /* ---- host feeders: read indexer and PAF pile reader, plain host code ------------------------------------
  * cw_index_reads stands in for indexReads (src/utils.cpp:166-205): FASTA or FASTQ (multi-line allowed) -> 2-bit reads keyed by
  * name (header up to the first blank; a later record with the same name replaces the earlier one; bases upper-cased, anything
@@ -238,6 +244,38 @@ typedef struct cw_stitch_read {
 int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_read* jobs, uint32_t n_reads, const uint32_t* win_pos,
                      const cw_batch* batch, const cw_result* res, uint32_t window_size, uint32_t window_overlap, int32_t do_trim,
                      char* out, const uint64_t* out_off, uint32_t* out_len, uint8_t* read_status, void* hip_stream);
+
+/* ---- the drivers' loop (SURVEY 8b "who calls it", 8e, 8f-4) -----------------------------------------------------------------------
+ * cw_run_correction stands in for runCorrection of BOTH reference drivers -- src/CONSENT-correction.cpp:62-135 (with processRead :19-58)
+ * when polishing == 0, src/CONSENT-polishing.cpp:107-135 (with processContig :21-105) when polishing != 0 -- called by src/main.cpp:78
+ * with the values of its getopt loop (:29-76).  bin/CONSENT-correction and bin/CONSENT-polishing are that main() over this function.
+ * FASTA records (">name\nsequence\n") go to the file descriptor out_fd in PAF order; a read without windows, or dropped by the 10 % rule,
+ * produces none.  Trimming and dropping happen only for correction without a proof file (CONSENT-correction.cpp:17,69-73).
+ * nb_threads (-j) = how many GPUs to use: the first min(nb_threads, visible devices); `devices` / the environment variable CW_DEVICES
+ * ("0,1,..", an id may repeat) override that.  Piles are handed to the devices job by job from one queue, there is no collective, and
+ * the output does not depend on the number of devices.  paf_index (-i) and path (-p) are accepted and, as in the reference, never read. */
+typedef struct cw_driver_args {
+    const char* paf_index;      /* -i */
+    const char* alignment_file; /* -a */
+    const char* reads_file;     /* -r */
+    const char* proof_file;     /* -R, NULL or "" = none */
+    const char* path;           /* -p */
+    uint32_t min_support, max_support, window_size, mer_size, common_kmers, min_anchors, solid_thresh, window_overlap, nb_threads, max_msa;
+    int32_t polishing;
+    const int32_t* devices;     /* NULL = choose as described above */
+    int32_t n_devices;
+    uint32_t windows_per_batch; /* 0 = 32768: windows per job */
+} cw_driver_args;
+
+typedef struct cw_driver_stats {
+    uint32_t n_devices;
+    uint64_t piles, windows, overlaps, jobs, records, bases_out;
+    double ms_index, ms_total;
+    uint64_t dev_windows[16];
+    double dev_ms_extract[16], dev_ms_consensus[16], dev_ms_stitch[16];
+} cw_driver_stats;
+
+int cw_run_correction(const cw_driver_args* args, int out_fd, cw_driver_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -19,8 +19,8 @@ def _built():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     from consent_amd import _build
 
-    if _build.stale() and os.path.exists("/opt/rocm/bin/hipcc"):
-        _build.build(verbose=False)
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build(verbose=False)  # rebuilds the library and the bin/ executables only when stale
     yield
 
 

@@ -12,7 +12,7 @@ from test_oracle_ref import rand_overlaps, rand_seq
 pytestmark = pytest.mark.gpu
 
 
-def build_case(seed, n_templates=3):
+def build_case(seed, n_templates=3, n_ovl=(2, 40)):
     rng = random.Random(seed)
     reads, ovl_rows, jobs, expect_inputs = [], [], [], []
     for _ in range(n_templates):
@@ -20,7 +20,7 @@ def build_case(seed, n_templates=3):
         tpl = rand_seq(rng, tpl_len)
         tpl_id = len(reads)
         reads.append(tpl)
-        ovls, targets = rand_overlaps(rng, tpl_len, rng.randrange(2, 40))
+        ovls, targets = rand_overlaps(rng, tpl_len, rng.randrange(*n_ovl))
         first = len(ovl_rows)
         fixed = []
         for o, t in zip(ovls, targets):
@@ -70,4 +70,42 @@ def test_extracted_batch_feeds_the_engine():
     for w in range(hb.n_windows):
         if w not in keep:
             assert int(full.cons_len[w]) == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("seed,n_ovl", [(11, (65, 130)), (12, (150, 400)), (13, (2500, 3000))])
+def test_piles_of_many_overlaps(seed, n_ovl):
+    """more overlaps than lanes: the count kernel's 64-at-a-time loop, depth-150 piles, and polishing's "every overlap of the contig per
+    window" (CONSENT-polish:43 maxSupport=20000) -- against the reference's own alignmentWindows.cpp (oracle/_ref) when present"""
+    reads, ovl, jobs, exp_in = build_case(seed, n_templates=2, n_ovl=n_ovl)
+    eng = ca.Engine(ca.Params(9, 4, 8, 2, 20))
+    got = eng.extract_piles(ca.pack_piles([reads]), ovl, jobs, 9)
+    r = oracle_lib.ref()
+    deep = 0
+    for w, (fixed, tpl, targets, qb, qe) in enumerate(exp_in):
+        fn = r.ref_window_pile if r is not None else oracle_lib.oracle().cwo_window_pile
+        exp = oracle_lib.window_pile(fn, fixed, tpl, targets, qb, qe, 9)
+        assert got.pile(w) == exp, f"window {w} [{qb},{qe}]"
+        deep = max(deep, len(exp))
+    assert all(len(f) > 64 for f, *_ in exp_in)  # more overlaps than lanes in every job
+    assert deep > 64 or n_ovl[0] < 150   # and, from the second case on, piles deeper than one wave
+    eng.close()
+
+
+def test_a_piece_beyond_the_format_limit_is_an_error_not_a_shorter_pile():
+    """-l 70000: a window (and its overlap pieces) longer than the batch format's 65535 bases is CW_E_CAPACITY, never dropped silently"""
+    import ctypes as C
+
+    rng = random.Random(5)
+    tpl = rand_seq(rng, 70100)
+    tgt = rand_seq(rng, 70100)
+    reads = ca.pack_piles([[tpl, tgt]])
+    ovl = np.array([[0, 70099, 1, 0, 70099, 0]], np.uint32)
+    eng = ca.Engine(ca.Params(9, 4, 8, 2, 20))
+    with pytest.raises(ca.EngineError, match="capacity"):
+        eng.extract_piles(reads, ovl, np.array([[0, 0, 69999, 0, 1]], np.uint32), 9)
+    ok = eng.extract_piles(reads, ovl, np.array([[0, 100, 599, 0, 1]], np.uint32), 9)  # the same reads, an ordinary window
+    assert ok.pile(0) == [tpl[100:600], tgt[100:600]]
+    with pytest.raises(ca.EngineError, match="invalid"):  # an overlap naming a read outside the set
+        eng.extract_piles(reads, np.array([[0, 70099, 7, 0, 70099, 0]], np.uint32), np.array([[0, 100, 599, 0, 1]], np.uint32), 9)
     eng.close()

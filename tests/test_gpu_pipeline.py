@@ -18,29 +18,32 @@ pytestmark = pytest.mark.gpu
 COMP = str.maketrans("ACGT", "TGCA")
 
 
-def noisy_map(rng, s, rate):
-    """noisy copy of s and, for every position of s, the position of the copy it ends up at"""
+def noisy_map(rng, s, rate, mix=(0.3, 0.3)):
+    """noisy copy of s and, for every position of s, the position of the copy it ends up at; mix = (deletion, insertion) shares of the
+    errors, the rest are substitutions: (0.3, 0.3) is the tests' default, (0.4, 0.3) the ONT-like 30:30:40 sub:ins:del of SURVEY 8d,
+    (0.3, 0.6) the PacBio-like 10:60:30"""
     out, pos = [], []
+    d, i = mix
     for c in s:
         pos.append(len(out))
         x = rng.random()
-        if x < rate * 0.3:
+        if x < rate * d:
             continue  # deletion
-        if x < rate * 0.6:
+        if x < rate * (d + i):
             out.append(rng.choice("ACGT"))  # insertion before the base
         out.append(rng.choice("ACGT") if x < rate else c)
     pos.append(len(out))
     return "".join(out), pos
 
 
-def make_dataset(tmp_path, seed, n_reads=36, glen=7000, rate=0.1):
+def make_dataset(tmp_path, seed, n_reads=36, glen=7000, rate=0.1, mix=(0.3, 0.3), read_len=(1200, 3200)):
     rng = random.Random(seed)
     genome = rand_seq(rng, glen)
     reads = []
     for i in range(n_reads):
-        ln = rng.randrange(1200, 3200)
+        ln = rng.randrange(*read_len)
         g0 = rng.randrange(0, glen - ln)
-        fwd, pos = noisy_map(rng, genome[g0 : g0 + ln], rate)
+        fwd, pos = noisy_map(rng, genome[g0 : g0 + ln], rate, mix)
         rev = rng.random() < 0.4
         seq = fwd[::-1].translate(COMP) if rev else fwd
         reads.append(dict(name=f"r{i}", g0=g0, g1=g0 + ln, pos=pos, rev=rev, seq=seq))
@@ -129,7 +132,7 @@ def test_other_parameters_and_max_support_cut(tmp_path):
     assert got == want and len(got) > 5
 
 
-def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, monkeypatch, capsys):
+def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, monkeypatch, capfd):
     """With the banded-traceback scratch shrunk some reads cannot be re-assembled: the default raises, "skip" leaves exactly those
     out (named on stderr) and every other read is still identical."""
     fa, paf = make_dataset(tmp_path, 35, n_reads=24)
@@ -139,7 +142,7 @@ def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, monkeypatch, ca
     with pytest.raises(ca.EngineError, match="capacity"):
         correct_reads(fa, paf, None, **prm)
     part = correct_reads(fa, paf, None, on_capacity="skip", **prm)
-    err = capsys.readouterr().err
+    err = capfd.readouterr().err  # the native driver writes to the process's stderr
     assert 0 < len(part) < len(full)
     fd = dict(full)
     for n, s in part:
