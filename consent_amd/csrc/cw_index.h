@@ -337,10 +337,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         } else {
         /* keys that occur 16 times or more: at most n_kmers / 16 of them.  The LDS table holds every pile of read correction (<= 151
-           sequences); the piles of assembly polishing are as deep as the coverage (maxSupport = 20000, CONSENT-polish:43) and use this
-           work-group's table in global memory instead */
-        const bool big_ex = wi->n_kmers / 16u > CW_EX_SLOTS / 2u;
+           sequences) in practice; the piles of assembly polishing are as deep as the coverage (maxSupport = 20000, CONSENT-polish:43):
+           when the LDS table overflows the count pass is redone with this work-group's table in global memory */
+        bool big_ex = false; /* second attempt: the LDS table overflowed */
         unsigned long long* const exg = sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS;
+        for (;;) {
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (big_ex) for (uint32_t i = tid; i < CW_EXG_SLOTS; i += CW_IDX_THREADS) exg[i] = 0ull;
@@ -381,9 +382,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         })
         __syncthreads();
+        const bool ex_over = flags[0] != 0;
+        if (!ex_over || big_ex) break;
+        big_ex = true;
+        __syncthreads(); /* everybody has read the flag before it is cleared again */
+        }
         CW_PROF(sc.ctr, 0, tid == 0);
         CW_PROF(sc.ctr, 1, tid == 0);
-        if (flags[0]) { /* more saturated keys than the exact table holds */
+        if (flags[0]) { /* more saturated keys than even the global exact table holds */
             if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_COUNT; sc.ctr->any_overflow = 1; }
             __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
             continue;

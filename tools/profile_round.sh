@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-CMD="python bench.py --steps 5 --warmup 2 --cpu-sample 0 --workload $WL"
+CMD="python bench.py --steps 5 --warmup 2 --cpu-sample 0 --pcie-steps 0 --workload $WL"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/bench_trace.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/bench_fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/bench_write.log" 2>&1
