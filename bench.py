@@ -365,6 +365,8 @@ def main():
             names += [f"{tname}.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
         print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier", ctr[6:11].tolist(), "outgrew into tier", ctr[16:21].tolist(), file=sys.stderr)
         print("phase Mcycles", {n: round(float(v) / 1e6, 2) for n, v in zip(names, prof) if n != "-"}, file=sys.stderr)
+        print("chain kernel: windows", int(prof[44]), "mean anchors", float(prof[42]) / max(1, int(prof[44])), "mean dirty sequences", float(prof[43]) / max(1, int(prof[44])), file=sys.stderr)
+        print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             const uint16_t* gdirty = (const uint16_t*)((const uint8_t*)gpres + cw_ab_align((uint64_t)A * Nw * 8));
             const uint16_t* P = (const uint16_t*)((const uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
             const int sup_min = min((int)prm.common_kmers, (int)N / 2); /* correctionMSA.cpp:31 */
+            if (lane == 0) { atomicAdd(&sc.ctr->prof[42], (unsigned long long)A); atomicAdd(&sc.ctr->prof[43], (unsigned long long)n_dirty); atomicAdd(&sc.ctr->prof[44], 1ull); }
             const uint32_t seg_base = ch_uni(wi->seg_base), seg_cap = ch_uni(wi->seg_cap);
             const uint32_t arena_base = ch_uni(wi->arena_base), arena_cap = ch_uni(wi->arena_cap);
 

@@ -89,7 +89,7 @@ struct BatchCounters {
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
-    unsigned long long prof[32];  /* cycle totals per phase, see cw_debug_profile */
+    unsigned long long prof[48];  /* cycle totals per phase (0-32), longest single task per POA tier (36-40), see cw_debug_profile */
 };
 
 struct DevBatch {
@@ -117,12 +117,16 @@ struct DevScratch {
     uint32_t list_cap;
     uint8_t* slab[CW_TIERS];       /* per-wave slabs of tier t (DP matrix; for tier G also the graph) */
     uint64_t slab_bytes[CW_TIERS];
-    uint32_t slots[CW_TIERS];      /* resident waves of tier t */
+    uint32_t slots[CW_TIERS];      /* slabs of tier t: at least as many as waves of that tier the hardware can hold at once */
+    uint32_t* slot_busy[CW_TIERS]; /* one flag per slab: a wave claims a free one when it starts and gives it back when it ends */
+    uint32_t persist_wgs[CW_TIERS];/* the LAST so many work-groups of a tier's grid loop until its list is empty; the earlier ones take one
+                                      chunk of tasks and end, which returns their LDS to the dispatcher -- tier 0 = S */
     uint16_t* p_fallback;          /* index kernel: per-work-group slot for a position matrix that outgrows LDS */
     uint64_t p_fallback_elems;     /* u16 elements per slot */
     uint8_t* ablock;               /* per-window anchor blocks: candidates, presence bitsets, position matrix */
     uint64_t ablock_units;         /* capacity in 16-byte units */
     unsigned long long* ex_fallback; /* index kernel: per-work-group exact table of saturated keys for very deep piles (CW_EXG_SLOTS each) */
+    uint4* task_dbg;               /* NULL unless CW_TASK_TRACE is set: per task (start, duration) in 1024-cycle units, tier|rc|pass, wave */
     uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */

@@ -375,6 +375,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
             return init_rc[i];
         }
     sh.queue_cap = 2 * devs.size() + 1;
+    const double t_engines = now_ms();
+    double ms_parse = 0, ms_windows = 0;
 
     uint64_t n_jobs_total = 0, records = 0, bases_out = 0;
     bool producer_done = false;
@@ -405,7 +407,9 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         };
         for (;;) {
             uint32_t tpl = 0, tpl_len = 0, n = 0;
+            const double tp0 = now_ms();
             rc = cw_paf_next_pile(paf, &tpl, &tpl_len, ov.data(), nullptr, (uint32_t)ov.size(), &n);
+            ms_parse += now_ms() - tp0;
             if (rc != CW_OK) { fprintf(stderr, "[consent_amd] %s: %s (malformed line, a name missing from the read file, or a length that disagrees with it)\n", a->alignment_file, cw_strerror(rc)); break; }
             if (n == 0) break;
             if (tpl_len != sh.host_reads.read_len[tpl]) {
@@ -414,9 +418,11 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
                 break;
             }
             uint32_t np = 0;
+            const double tw0 = now_ms();
             wp.resize(2 * ((size_t)tpl_len / (a->window_size - a->window_overlap) + 8));
             rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), (uint32_t)(wp.size() / 2), &np);
             if (rc == CW_E_CAPACITY) { wp.resize(2 * (size_t)np); rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), np, &np); }
+            ms_windows += now_ms() - tw0;
             if (rc != CW_OK) break;
             ++n_piles;
             if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
@@ -467,9 +473,9 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         }
     }
     if (getenv("CW_DRIVER_STATS")) { /* counters on stderr; stdout stays pure FASTA */
-        fprintf(stderr, "{\"devices\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
+        fprintf(stderr, "{\"devices\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
                 devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
-                t_indexed - t_begin, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
+                t_indexed - t_begin, t_engines - t_indexed, ms_parse, ms_windows, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
         for (size_t i = 0; i < workers.size(); ++i)
             fprintf(stderr, "%s{\"device\": %d, \"windows\": %llu, \"jobs\": %llu, \"ms_extract\": %.1f, \"ms_consensus\": %.1f, \"ms_stitch\": %.1f}", i ? ", " : "", workers[i].device,
                     (unsigned long long)workers[i].windows, (unsigned long long)workers[i].jobs, workers[i].ms_extract, workers[i].ms_consensus, workers[i].ms_stitch);

@@ -36,16 +36,36 @@ size_t big_slab_bytes() {
     return align_up((size_t)CW_POAB_HC * 4 + CW_POA_GRAPH_BYTES(CW_POAB_NC, CW_POAB_EC, CW_POAB_LC), 256);
 }
 
+/* Work-groups per CU of the four concurrent POA tier kernels (S, M1, M2, L).  The tiers share each CU's 160 KiB of LDS, every kernel
+   is persistent, and which kernel's work-groups get onto a CU first is up to the hardware dispatcher: whatever is resident keeps its
+   LDS until its list is empty.  Measured with the task timeline (tools/task_trace.py): with the shallow mix on depth-150 piles tier S
+   (3 x 45 KB) held every CU for the first 27 ms and tier L, the long pole, started late (POA stage 79 ms); with fewer S and M2
+   work-groups and one more of tier L it takes 69 ms; the shallow piles of config 2 prefer the old mix (19.6 vs 21.5 ms).  The choice
+   goes by the mean pile depth of the batch.  Slabs are sized for the larger of the two, so the scratch layout does not depend on it.
+   CW_WGS_S / _M1 / _M2 / _L override (experiments). */
+struct TierMix { uint32_t s, m1, m2, l; };
+TierMix tier_mix(bool deep) {
+    TierMix m = deep ? TierMix{3, 5, 4, 2} : TierMix{3, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one */
+    auto knob = [](const char* name, uint32_t dflt) { const char* v = getenv(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
+    m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
+    if (m.s > 3) m.s = 3;
+    if (m.m1 > 5) m.m1 = 5;
+    if (m.m2 > 4) m.m2 = 4;
+    if (m.l > 4) m.l = 4;
+    return m;
+}
+
 void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
     t[0] = {0, 0};
-    t[1] = {(uint32_t)cus * 5 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
-    t[2] = {(uint32_t)cus * 4 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
-    t[3] = {(uint32_t)cus * 2 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
+    /* slabs: one per wave the hardware can hold at once (LDS-bound: 5, 4 and 4 work-groups per CU) plus a margin; waves claim them (slot_busy) */
+    t[1] = {(uint32_t)cus * 6 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
+    t[2] = {(uint32_t)cus * 5 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
+    t[3] = {(uint32_t)cus * 5 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
     t[4] = {big_slots, big_slab_bytes()};
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, finvis, exg, total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap;
@@ -83,7 +103,9 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);
+    for (int t = 1; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
     put(p.exg, (size_t)cus * CW_EXG_SLOTS * 8);
+    put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
     put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
     p.total = o;
     return p;
@@ -171,7 +193,6 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         return CW_E_NO_DEVICE;
     }
     bool ok = hipEventCreate(&e->ev_fork) == hipSuccess && hipEventCreate(&e->ev_begin) == hipSuccess && hipEventCreate(&e->ev_end) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->host_fb, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) memset(e->host_fb, 0, 64);
     for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
@@ -262,14 +283,32 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
     sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
     sc.ex_fallback = (unsigned long long*)(base + p.exg);
+    sc.task_dbg = getenv("CW_TASK_TRACE") ? (uint4*)(base + p.tdbg) : nullptr;
+    e->last_tasks_off = p.tasks; e->last_tdbg_off = p.tdbg; e->last_task_cap = p.task_cap;
+    if (sc.task_dbg) CW_HIP(hipMemsetAsync(sc.task_dbg, 0, (size_t)p.task_cap * 16, st));
     sc.fin_vis = (uint32_t*)(base + p.finvis); sc.fin_vis_words = CW_FIN_VIS_GLB_WORDS;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
-    sc.producer_wgs = (uint32_t)cus * 3 + p.tier[1].slots / CW_POAM1_WAVES + p.tier[2].slots / CW_POAM2_WAVES;
+    /* grids of the four concurrent tier kernels: `yield` work-groups that run one chunk of tasks and end, then `persist` ones that loop
+       until the list is empty (see cw_poa_slab_kernel).  The yielding part is sized for the lists of a full batch and shrinks with the
+       batch, so that a small batch does not pay for thousands of empty work-groups. */
+    const TierMix mix = tier_mix(batch->n_seqs / batch->n_windows > 64u);
+    const uint32_t W_ = batch->n_windows;
+    auto ymin = [](uint32_t a, uint32_t b_) { return a < b_ ? a : b_; };
+    uint32_t yield_wgs[4] = {ymin(8192u, W_ / 2u + 1u), ymin(16384u, W_), ymin(4096u, W_ / 4u + 1u), ymin(4096u, W_ / 4u + 1u)};
+    /* measured: with every tier on the machine all the time the stage is SLOWER (depth 150: 86-92 ms against 69-82; depth 30:
+       25.3 against 19.6) -- the CUs are short of issue slots, not of resident waves -- so yielding is off unless CW_YIELD is set */
+    if (!getenv("CW_YIELD")) yield_wgs[0] = yield_wgs[1] = yield_wgs[2] = yield_wgs[3] = 0;
+    sc.persist_wgs[0] = (uint32_t)cus * mix.s; sc.persist_wgs[1] = (uint32_t)cus * mix.m1; sc.persist_wgs[2] = (uint32_t)cus * mix.m2; sc.persist_wgs[3] = (uint32_t)cus * mix.l;
+    sc.persist_wgs[4] = 0;
+    const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
+                   wgs_l = yield_wgs[3] + sc.persist_wgs[3];
+    sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2;
     for (int t = 1; t < CW_TIERS; ++t) {
         sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
         sc.over_list[t] = (uint32_t*)(base + p.over[t]);
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
+        sc.slot_busy[t] = (uint32_t*)(base + p.sbusy[t]);
     }
     FinOut fo;
     fo.cons = res->cons; fo.cons_off = res->cons_off; fo.cons_len = res->cons_len; fo.win_status = res->win_status;
@@ -286,6 +325,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
+    CW_HIP(hipMemsetAsync(base + p.sbusy[1], 0, p.sbusy[4] + (size_t)p.tier[4].slots * 4 - p.sbusy[1], st)); /* every slab free */
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
@@ -310,23 +350,23 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     for (int i = 0; i < 3; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
     /* tier L also consumes the live overflow queue; only sc.linger_wgs of its work-groups stay for that (far fewer than
        CUs, so they can never keep the producers they wait for off the machine) */
-    const uint32_t grid_l = p.tier[3].slots / CW_POAL_WAVES;
+    const uint32_t grid_l = wgs_l;
     sid = stage_begin(e, e->side[2], "poa_large");
     cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
     stage_end(e, e->side[2], sid);
     sid = stage_begin(e, e->side[1], "poa_m2");
-    cw_poa_slab_kernel<M2_ARGS, 0><<<p.tier[2].slots / CW_POAM2_WAVES, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
+    cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
     stage_end(e, e->side[1], sid);
     sid = stage_begin(e, e->side[0], "poa_m1");
-    cw_poa_slab_kernel<M1_ARGS, 0><<<p.tier[1].slots / CW_POAM1_WAVES, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
+    cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
     sid = stage_begin(e, st, "poa");
-    cw_poa_kernel<<<cus * 3, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
+    cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, st, sid);
     for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
     sid = stage_begin(e, st, "poa_overflow");
-    cw_poa_slab_kernel<L_ARGS, 1><<<p.tier[3].slots / CW_POAL_WAVES, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
+    cw_poa_slab_kernel<L_ARGS, 1><<<(uint32_t)cus * 2, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
     cw_poa_big_kernel<<<p.tier[4].slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "finish");
@@ -403,7 +443,26 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
     memcpy(counters26, &c, 26 * 4);
-    memcpy(prof32, c.prof, sizeof(c.prof));
+    memcpy(prof32, c.prof, sizeof(c.prof)); /* 48 entries */
+    return CW_OK;
+}
+
+/* Debug/inspection (cw_private.h): with CW_TASK_TRACE set, 12 words per POA task of the last run: the PoaTask record (window, seg_slot,
+ * member_off, n_members, max_len, out_off, out_cap, state) + start and duration in 10 ns units, tier | rc << 8 | pass << 16, wave */
+int cw_debug_task_trace(cw_engine* e, uint32_t cap_tasks, uint32_t* out12, uint32_t* n_tasks) {
+    if (!e || !e->scratch || !out12 || !n_tasks || !getenv("CW_TASK_TRACE")) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CW_HIP(hipSetDevice(e->device));
+    CW_HIP(hipDeviceSynchronize());
+    BatchCounters c;
+    CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
+    uint32_t n = c.n_tasks < e->last_task_cap ? c.n_tasks : e->last_task_cap;
+    if (n > cap_tasks) n = cap_tasks;
+    std::vector<uint32_t> a((size_t)n * 8), d((size_t)n * 4);
+    CW_HIP(hipMemcpy(a.data(), (uint8_t*)e->scratch + e->last_tasks_off, (size_t)n * 32, hipMemcpyDeviceToHost));
+    CW_HIP(hipMemcpy(d.data(), (uint8_t*)e->scratch + e->last_tdbg_off, (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) { memcpy(out12 + (size_t)i * 12, &a[(size_t)i * 8], 32); memcpy(out12 + (size_t)i * 12 + 8, &d[(size_t)i * 4], 16); }
+    *n_tasks = n;
     return CW_OK;
 }
 
@@ -610,6 +669,14 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     const bool want_solid = r->solid != nullptr;
     if (want_solid && (!r->solid_off || !r->solid_len)) return CW_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
+    /* the copy streams exist only for callers of the host-batch path, and are created after the four kernel streams: the runtime
+       multiplexes streams onto a handful of hardware queues in creation order, and two POA tiers that land on one queue run one after
+       the other instead of side by side (measured: tier M1 started only when tier M2 had ended) */
+    if (!e->copy_in) {
+        CW_HIP(hipSetDevice(e->device));
+        if (hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) != hipSuccess) { e->copy_in = nullptr; return CW_E_NO_DEVICE; }
+        if (hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking) != hipSuccess) { e->copy_out = nullptr; return CW_E_NO_DEVICE; }
+    }
     int si = -1;
     for (int i = 0; i < CW_SLOTS; ++i) if (!e->slot[i].busy) { si = i; break; }
     if (si < 0) return CW_E_INVALID; /* CW_SLOTS batches are in flight already: cw_wait one of them first */

@@ -24,15 +24,16 @@
 #define CW_IDX_WAVES 16
 #define CW_IDX_LDS_BYTES 163840
 #define CW_TMAX 1024 /* template k-mer slots */
-#define CW_EX_SLOTS 2048
+#define CW_EX_SLOTS 1024 /* in LDS; a pile that saturates more keys than this is counted again with the table in global memory */
+#define CW_EX_BITS 10
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 /* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
    lengths, word offsets and the 2-bit words themselves, so that the four passes over the pile's k-mers read LDS instead of walking
    seq_len -> seq_word_off -> bases in global memory (three dependent round trips per sequence and pass, with all 16 waves waiting
    at the same time) */
-#define CW_IDX_STAGE_OFF 147968
-#define CW_IDX_STAGE_N 256
+#define CW_IDX_STAGE_OFF 139776 /* behind the count table (128 KiB), the exact table (8 KiB) and 512 B of flags and scan scratch */
+#define CW_IDX_STAGE_N 192
 #define CW_IDX_STAGE_WORDS ((CW_IDX_LDS_BYTES - CW_IDX_STAGE_OFF - 16 - CW_IDX_STAGE_N * 8) / 4)
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -339,54 +340,49 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         /* keys that occur 16 times or more: at most n_kmers / 16 of them.  The LDS table holds every pile of read correction (<= 151
            sequences) in practice; the piles of assembly polishing are as deep as the coverage (maxSupport = 20000, CONSENT-polish:43):
            when the LDS table overflows the count pass is redone with this work-group's table in global memory */
-        bool big_ex = false; /* second attempt: the LDS table overflowed */
+        bool big_ex = false; /* the LDS table overflowed and the pass was redone with the table in global memory */
         unsigned long long* const exg = sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS;
-        for (;;) {
+        /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in a small hash table (key + 1 in the
+           high half, the overflow count in the low half), so that a key's exact count is its nibble, plus its overflow when the nibble is 15 */
+#define CW_IDX_COUNT_PASS(EXTAB, EXSLOTS, EXBITS)                                                                       \
+        CW_IDX_PASS_BLOCK({                                                                                             \
+            const uint32_t wd = key >> 3, sh = (key & 7) * 4;                                                           \
+            uint32_t old = tab[wd];                                                                                     \
+            bool sat = false;                                                                                           \
+            for (;;) {                                                                                                  \
+                if (((old >> sh) & 15u) == 15u) { sat = true; break; }                                                  \
+                uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));                                             \
+                if (prev == old) break;                                                                                 \
+                old = prev;                                                                                             \
+            }                                                                                                           \
+            if (!sat) continue;                                                                                         \
+            uint32_t slot = cw_hash32(key) >> (32 - (EXBITS));                                                          \
+            const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;                              \
+            for (uint32_t probe = 0;; ++probe) {                                                                        \
+                if (probe >= (EXSLOTS)) { flags[0] = 1; break; }                                                        \
+                unsigned long long cur = atomicCAS(&(EXTAB)[slot], 0ull, fresh);                                        \
+                if (cur == 0ull) break;                                                                                 \
+                if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&(EXTAB)[slot], 1ull); break; }                       \
+                slot = (slot + 1) & ((EXSLOTS) - 1);                                                                    \
+            }                                                                                                           \
+        })
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
-        if (big_ex) for (uint32_t i = tid; i < CW_EXG_SLOTS; i += CW_IDX_THREADS) exg[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
-        /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in the small hash table ex[] (key + 1 in the
-           high half, the overflow count in the low half), so that a key's exact count is its nibble, plus its overflow when the nibble is 15 */
-        CW_IDX_PASS_BLOCK({
-            const uint32_t wd = key >> 3, sh = (key & 7) * 4;
-            uint32_t old = tab[wd];
-            bool sat = false;
-            for (;;) {
-                if (((old >> sh) & 15u) == 15u) { sat = true; break; }
-                uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));
-                if (prev == old) break;
-                old = prev;
-            }
-            if (!sat) continue;
-            const unsigned long long fresh = ((unsigned long long)(key + 1) << 32) | 1ull;
-            if (big_ex) {
-                uint32_t slot = cw_hash32(key) >> (32 - 18);
-                for (uint32_t probe = 0;; ++probe) {
-                    if (probe >= CW_EXG_SLOTS) { flags[0] = 1; break; }
-                    unsigned long long cur = atomicCAS(&exg[slot], 0ull, fresh);
-                    if (cur == 0ull) break;
-                    if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&exg[slot], 1ull); break; }
-                    slot = (slot + 1) & (CW_EXG_SLOTS - 1);
-                }
-                continue;
-            }
-            uint32_t slot = cw_hash32(key) >> (32 - 11);
-            for (uint32_t probe = 0;; ++probe) {
-                if (probe >= CW_EX_SLOTS) { flags[0] = 1; break; }
-                unsigned long long cur = atomicCAS(&ex[slot], 0ull, fresh);
-                if (cur == 0ull) break;
-                if ((uint32_t)(cur >> 32) == key + 1) { atomicAdd(&ex[slot], 1ull); break; }
-                slot = (slot + 1) & (CW_EX_SLOTS - 1);
-            }
-        })
+        CW_IDX_COUNT_PASS(ex, CW_EX_SLOTS, CW_EX_BITS)
         __syncthreads();
-        const bool ex_over = flags[0] != 0;
-        if (!ex_over || big_ex) break;
-        big_ex = true;
-        __syncthreads(); /* everybody has read the flag before it is cleared again */
+        if (flags[0]) { /* rare (deep polishing piles): everything again, saturated keys into this work-group's global table */
+            __syncthreads(); /* everybody has read the flag before it is cleared */
+            for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
+            for (uint32_t i = tid; i < CW_EXG_SLOTS; i += CW_IDX_THREADS) exg[i] = 0ull;
+            if (tid < 8) flags[tid] = 0;
+            __syncthreads();
+            CW_IDX_COUNT_PASS(exg, CW_EXG_SLOTS, 18)
+            __syncthreads();
+            big_ex = true;
         }
+#undef CW_IDX_COUNT_PASS
         CW_PROF(sc.ctr, 0, tid == 0);
         CW_PROF(sc.ctr, 1, tid == 0);
         if (flags[0]) { /* more saturated keys than even the global exact table holds */
@@ -410,7 +406,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EXG_SLOTS - 1); xe = exg[slot]; }
                     return (uint32_t)xe;
                 }
-                uint32_t slot = cw_hash32(key) >> (32 - 11);
+                uint32_t slot = cw_hash32(key) >> (32 - CW_EX_BITS);
                 unsigned long long xe = ex[slot];
                 while (xe != 0ull && (uint32_t)(xe >> 32) != key + 1) { slot = (slot + 1) & (CW_EX_SLOTS - 1); xe = ex[slot]; }
                 return (uint32_t)xe;

@@ -59,6 +59,8 @@ struct cw_engine {
     uint32_t linger_wgs = 0; /* tier-L work-groups kept on the live overflow queue (adapted from the previous batch) */
     uint64_t last_words = 0;
     size_t last_ctr_off = 0; /* where the last run's BatchCounters sit in scratch */
+    size_t last_tasks_off = 0, last_tdbg_off = 0;
+    uint32_t last_task_cap = 0;
 };
 
 extern "C" int cw_extract_impl(cw_engine* e, const cw_read_set* reads, const cw_overlap* overlaps, uint64_t n_overlaps, const cw_window_job* jobs,

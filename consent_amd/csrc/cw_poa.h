@@ -34,6 +34,8 @@
 #define CW_POA_HC 2048  /* DP cells (int16) */
 #define CW_POA_DC 0     /* traceback direction words: (rows x 64-column chunks) pairs of u64 */
 #define CW_POA_WAVES 4
+#define CW_POA_CHUNK_S 8   /* tasks a yielding wave of tier S runs before it ends (~0.3 ms each) */
+#define CW_POA_CHUNK_M1 2  /* ... of tier M1 (~1 ms each); tiers M2 and L: one */
 /* tiers M1 / M2 / L: graph in LDS, DP matrix (int16) in a per-wave global slab that stays L2 / Infinity-Cache
    resident.  Direction words are off there: they cost more occupancy than they save (measured). */
 #define CW_POAM1_NC 256
@@ -865,7 +867,10 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
 }
 
 __device__ __forceinline__ void poa_flush_prof(const DevScratch& sc, int base, const unsigned long long (&acc)[6], int lane) {
-    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[base + q], acc[q]);
+    if (lane == 0) {
+        for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[base + q], acc[q]);
+        atomicMax(&sc.ctr->prof[36 + (base - 8) / 5], acc[5]); /* the longest single task of this tier */
+    }
 }
 
 __device__ __forceinline__ void poa_hand_over(const DevScratch& sc, const PoaTask& t, uint32_t ti, int rc, int next_tier) {
@@ -899,6 +904,9 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
                                                  false, true);
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    /* see cw_poa_slab_kernel: all but the last persist_wgs work-groups take a chunk of tasks and end */
+    const bool yields = blockIdx.x + sc.persist_wgs[0] < gridDim.x;
+    uint32_t ran = 0;
     for (;;) {
         uint32_t ti = 0;
         if (lane == 0) ti = atomicAdd(&sc.ctr->next_task, 1u);
@@ -906,9 +914,12 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         if (ti >= n_tasks) break;
         const PoaTask t = sc.tasks[ti];
         if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
+        const unsigned long long _t0 = __builtin_readcyclecounter();
         const int rc = poa_run<int16_t, true>(M, t, b, sc, lane, acc);
+        { const unsigned long long d = __builtin_readcyclecounter() - _t0; acc[5] = d > acc[5] ? d : acc[5]; }
         if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
         cw_wave_sync();
+        if (yields && ++ran >= CW_POA_CHUNK_S) break;
     }
     poa_flush_prof(sc, 8, acc, lane);
     poa_producer_done(sc);
@@ -922,7 +933,25 @@ __global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 5 : 1) /* M1: five wav
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t gw = blockIdx.x * WAVES + wave; /* the grid never exceeds the slots */
+    /* Yielding persistence.  The four tier kernels run side by side and share each CU's LDS; a work-group that loops until its tier's
+       list is empty keeps its LDS for the whole stage, so whichever kernel reaches a CU first owns it (measured: tier S held every CU
+       for 27 ms of a depth-150 batch while the long tasks of tier L had not started).  Here only the LAST persist_wgs work-groups of
+       a grid are persistent; every earlier one takes a chunk of tasks and ends, and the dispatcher hands its LDS to the next pending
+       work-group of ANY tier: the mix on a CU follows the remaining work instead of the launch order.  A wave's slab is therefore
+       not tied to its block index: it claims a free one (there are more slabs than waves the hardware can hold at once). */
+    uint32_t gw = 0;
+    if (lane == 0) {
+        const uint32_t n_slots = sc.slots[TIER];
+        uint32_t s = (uint32_t)(((unsigned long long)(blockIdx.x * WAVES + wave) * 2654435761ull) % n_slots);
+        for (;;) {
+            if (__hip_atomic_load(&sc.slot_busy[TIER][s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
+                atomicCAS(&sc.slot_busy[TIER][s], 0u, 1u) == 0u) break;
+            s = s + 1u == n_slots ? 0u : s + 1u;
+        }
+        gw = s;
+    }
+    gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gw);
+    const bool yields = PASS == 0 && blockIdx.x + sc.persist_wgs[TIER] < gridDim.x;
     /* the slab is global memory: say so, or every access to the DP matrix is a flat_* instruction (both wait counters, aperture check) */
     typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
     uint8_t* my_slab = (uint8_t*)(cw_gptr)(sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER]);
@@ -941,23 +970,33 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
+        const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
         const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2)>(M, t, b, sc, lane, acc);
+        const unsigned long long _t1 = __builtin_readcyclecounter();
+        acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];
+        if (lane == 0 && sc.task_dbg) { /* inspection aid (CW_TASK_TRACE): when each task of the slab tiers ran (10 ns units since the tier sort), where, and how it ended */
+            uint4 d;
+            d.x = (uint32_t)(_w0 - sc.ctr->prof[41]); d.y = (uint32_t)(wall_clock64() - _w0); d.z = (uint32_t)TIER | ((uint32_t)rc << 8) | ((uint32_t)PASS << 16); d.w = gw;
+            sc.task_dbg[ti] = d;
+        }
         if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
     };
     if (PASS == 0) {
         const uint32_t* list = sc.tier_list[TIER];
         const uint32_t n_work = min(sc.ctr->n_tier[TIER], sc.list_cap);
+        uint32_t ran = 0;
         for (;;) {
             uint32_t mi = 0;
             if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER], 1u);
             mi = (uint32_t)__shfl((int)mi, 0);
             if (mi >= n_work) break;
             run_task(list[mi]);
+            if (yields && ++ran >= (TIER == 1 ? CW_POA_CHUNK_M1 : 1u)) break;
         }
     }
-    if (TIER == 3 && (PASS == 1 || blockIdx.x < sc.linger_wgs)) {
-        /* Live queue (only the first few work-groups stay for it: a lingering tier-L work-group holds 37 KB of LDS that
+    if (TIER == 3 && !yields && (PASS == 1 || gridDim.x - 1u - blockIdx.x < sc.linger_wgs)) {
+        /* Live queue (only the last few work-groups of the grid stay for it: a lingering tier-L work-group holds 37 KB of LDS that
            the other tiers could use): tasks that outgrow tiers S/M1/M2 while those kernels are still running on their own streams are
            picked up here at once instead of waiting for a later pass.  An entry is its own flag (0xFFFFFFFF = not yet
            written); we stop when every producing work-group has signed off and the queue is drained.  Every wait is
@@ -998,6 +1037,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         /* not used for tiers below L */
     }
     poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
+    if (lane == 0) __hip_atomic_store(&sc.slot_busy[TIER][gw], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); /* the slab goes back */
     if (PASS == 0 && TIER < 3) poa_producer_done(sc);
 }
 
@@ -1029,6 +1069,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
     __shared__ uint32_t tot_c[CW_SORT_CLASSES];
     extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* CW_SORT_LDS_CLS bytes */
     const int tier = 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
     uint32_t* list = sc.tier_list[tier];
     uint32_t* tmp = sc.over_list[tier];

@@ -86,37 +86,24 @@ def main():
                 n_lines += 1
     print(f"data set: genome {glen}, {n_reads} reads, {n_lines} overlaps", flush=True)
 
-    import torch
+    # the native driver (cw_run_correction) with its own per-stage clocks
+    import json
+    import subprocess
 
-    # time the device stages by wrapping the three entry points
-    lib = ca.load_library()
-    acc = {"extract": 0.0, "consensus": 0.0, "stitch": 0.0}
-    orig = {k: getattr(lib, k) for k in ("cw_extract_piles_device", "cw_run_device", "cw_stitch_device")}
-
-    class Timed:
-        def __init__(self, fn, key):
-            self.fn, self.key = fn, key
-
-        def __call__(self, *a):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rc = self.fn(*a)
-            torch.cuda.synchronize()
-            acc[self.key] += time.perf_counter() - t0
-            return rc
-
-    for name, key in (("cw_extract_piles_device", "extract"), ("cw_run_device", "consensus"), ("cw_stitch_device", "stitch")):
-        setattr(lib, name, Timed(orig[name], key))
+    exe = os.path.join(ROOT, "bin", "CONSENT-correction")
+    argv = [exe, "-a", paf, "-s", "3", "-S", "150", "-l", "500", "-k", "9", "-c", "8", "-A", "2", "-f", "4", "-m", "50", "-j", os.environ.get("CW_BENCH_GPUS", "1"), "-r", fa, "-M", "150", "-p", "x"]
     for rep in range(2):
-        for k in acc:
-            acc[k] = 0.0
         t0 = time.perf_counter()
-        res = pipeline.correct_reads(fa, paf, io.StringIO(), windows_per_batch=16384)
+        out = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, CW_DRIVER_STATS="1", CW_DRIVER_TIMING="1"))
         wall = time.perf_counter() - t0
-    bases = sum(len(s) for _, s in res)
-    up = sum(sum(c.isupper() for c in s) for _, s in res)
-    print(f"corrected {len(res)} reads, {bases} bases ({up / max(bases, 1):.3f} upper case) in {wall:.2f} s wall; device stages (s): "
-          + ", ".join(f"{k} {v:.3f}" for k, v in acc.items()), flush=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+    st = json.loads([l for l in out.stderr.splitlines() if l.startswith("{")][-1])
+    lines = out.stdout.split("\n")
+    seqs = lines[1::2]
+    bases = sum(len(x) for x in seqs)
+    up = sum(sum(c.isupper() for c in x) for x in seqs)
+    print(f"corrected {len(seqs)} reads, {bases} bases ({up / max(bases, 1):.3f} upper case) in {wall:.2f} s wall (process start to exit)")
+    print(json.dumps(st))
 
 
 if __name__ == "__main__":
