@@ -19,6 +19,7 @@
 #include "cw_device.h"
 #include "cw_index.h"
 #include "cw_poa.h" /* tier capacities for the routing rule */
+#include "cw_poa_q.h"
 
 #define CW_CH_WAVES 4
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
@@ -304,29 +305,33 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     /* deep piles grow wider graphs: the smallest tier is only worth trying when the graph will very likely stay in it
                        (a task that outgrows tier S is redone in tier L, the scarcest one) */
                     const uint32_t est_s = (e_mx * (15u + e_n / 5u) + 9u) / 10u;
+                    /* tier Q (four tasks per wave, cw_poa_q.h): members of at most 31 bases and a graph that should stay small */
                     const uint32_t tier = !poa ? 0xFFu
+                                          : (sc.use_q && e_mx <= (uint32_t)CW_POAQ_LC && est_s <= (uint32_t)CW_POAQ_ROUTE_NODES) ? 4u
                                           : ((est_s + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est_s <= (uint32_t)CW_POA_NC) ? 0u
                                           : (est <= (uint32_t)CW_POAM1_ROUTE && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
                                           : (est <= (uint32_t)CW_POAM2_ROUTE && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long pm = __ballot(poa);
-                    const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u);
+                    const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u), tmq = __ballot(tier == 4u);
                     const int minc = cw_wave_scan_add(poa ? (int)e_n : 0);
                     const uint32_t m_total = (uint32_t)cw_lane_value(minc, 63);
-                    uint32_t tb = 0, mb = 0, b1 = 0, b2 = 0, b3 = 0;
+                    uint32_t tb = 0, mb = 0, b1 = 0, b2 = 0, b3 = 0, bq = 0;
                     if (lane == 0 && pm) {
                         tb = atomicAdd(&sc.ctr->n_tasks, (uint32_t)__popcll(pm));
                         mb = atomicAdd(&sc.ctr->n_members, m_total);
                         if (tm1) b1 = atomicAdd(&sc.ctr->n_tier[1], (uint32_t)__popcll(tm1));
                         if (tm2) b2 = atomicAdd(&sc.ctr->n_tier[2], (uint32_t)__popcll(tm2));
                         if (tm3) b3 = atomicAdd(&sc.ctr->n_tier[3], (uint32_t)__popcll(tm3));
+                        if (tmq) bq = atomicAdd(&sc.ctr->n_tier[0], (uint32_t)__popcll(tmq));
                     }
                     tb = (uint32_t)cw_lane_value((int)tb, 0); mb = (uint32_t)cw_lane_value((int)mb, 0);
                     b1 = (uint32_t)cw_lane_value((int)b1, 0); b2 = (uint32_t)cw_lane_value((int)b2, 0); b3 = (uint32_t)cw_lane_value((int)b3, 0);
+                    bq = (uint32_t)cw_lane_value((int)bq, 0);
                     const bool cap_ok = (uint64_t)tb + (uint32_t)__popcll(pm) <= sc.task_cap && (uint64_t)mb + m_total <= sc.member_cap &&
                                         b1 + (uint32_t)__popcll(tm1) <= sc.list_cap && b2 + (uint32_t)__popcll(tm2) <= sc.list_cap &&
-                                        b3 + (uint32_t)__popcll(tm3) <= sc.list_cap;
+                                        b3 + (uint32_t)__popcll(tm3) <= sc.list_cap && bq + (uint32_t)__popcll(tmq) <= sc.list_cap;
                     if (!cap_ok) { over = true; }
                     else {
                         const uint32_t t_idx = tb + (uint32_t)__popcll(pm & below);
@@ -335,11 +340,12 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             PoaTask t;
                             t.window = w; t.seg_slot = seg_base + q_seg[lane]; t.member_off = m_off; t.n_members = e_n; t.max_len = e_mx;
                             t.out_off = q_off[lane]; t.out_cap = q_need[lane];
-                            t.state = tier ? 2u : 0u;
+                            t.state = tier ? 2u : 0u; /* 0 = tier S takes it from the task array; anything else is on a list */
                             sc.tasks[t_idx] = t;
                             if (tier == 1u) sc.tier_list[1][b1 + (uint32_t)__popcll(tm1 & below)] = t_idx;
                             else if (tier == 2u) sc.tier_list[2][b2 + (uint32_t)__popcll(tm2 & below)] = t_idx;
                             else if (tier == 3u) sc.tier_list[3][b3 + (uint32_t)__popcll(tm3 & below)] = t_idx;
+                            else if (tier == 4u) sc.tier_list[0][bq + (uint32_t)__popcll(tmq & below)] = t_idx;
                             sc.seg_off[t.seg_slot] = t.out_off; sc.seg_len[t.seg_slot] = 0;
                         }
                         /* the wave-wide part, entry by entry: member lists (coalesced matrix rows) and long single pieces */

@@ -8,6 +8,7 @@
 #include "cw_index.h"
 #include "cw_chain.h"
 #include "cw_poa.h"
+#include "cw_poa_q.h"
 #include "cw_finish.h"
 #include "cw_extract.h"
 #include "cw_stitch.h"
@@ -93,8 +94,8 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.tasks, (size_t)p.task_cap * sizeof(PoaTask));
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
     put(p.ctr, sizeof(BatchCounters));
-    for (int t = 1; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4);
-    for (int t = 1; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
+    for (int t = 0; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4); /* list 0 = tier Q */
+    for (int t = 0; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
@@ -132,6 +133,7 @@ int set_kernel_attributes() {
         hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -304,6 +306,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
                    wgs_l = yield_wgs[3] + sc.persist_wgs[3];
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2;
+    sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
+    sc.use_q = getenv("CW_NO_TIER_Q") ? 0u : 1u;
     for (int t = 1; t < CW_TIERS; ++t) {
         sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
         sc.over_list[t] = (uint32_t*)(base + p.over[t]);
@@ -343,7 +347,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
-    cw_sort_tier_kernel<<<3, 1024, CW_SORT_LDS_CLS, st>>>(sc); /* tiers M2, L and M1: largest tasks first */
+    cw_sort_tier_kernel<<<4, 1024, CW_SORT_LDS_CLS, st>>>(sc); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     CW_HIP(hipEventRecord(e->ev_fork, st));
@@ -360,6 +364,9 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, e->side[0], "poa_m1");
     cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
+    sid = stage_begin(e, st, "poa_q");
+    cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, st>>>(db, sc); /* four tasks per wave, one work-group per CU */
+    stage_end(e, st, sid);
     sid = stage_begin(e, st, "poa");
     cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, st, sid);
@@ -478,12 +485,16 @@ int cw_window_positions(uint32_t tpl_len, const cw_overlap* overlaps, uint32_t n
        negative one: an error here */
     if (window_size == 0 || window_overlap < 0 || (uint32_t)window_overlap >= window_size) return CW_E_INVALID;
     if (tpl_len == 0) return CW_OK;
+    /* getCoverages (:5-25) adds one to every base of every overlap; the same depths from a difference array and one prefix sum:
+       O(overlaps + length) instead of O(sum of the overlap lengths), which was most of the host time per pile */
     std::vector<uint32_t> cov;
-    try { cov.assign(tpl_len, 0); } catch (...) { return CW_E_NOMEM; }
+    try { cov.assign((size_t)tpl_len + 1, 0); } catch (...) { return CW_E_NOMEM; }
     for (uint32_t o = 0; o < n_overlaps; ++o) {
         if (overlaps[o].q_end < overlaps[o].q_start || overlaps[o].q_end >= tpl_len) return CW_E_INVALID; /* the reference would write out of bounds */
-        for (uint32_t i = overlaps[o].q_start; i <= overlaps[o].q_end; ++i) cov[i]++;
+        cov[overlaps[o].q_start]++;
+        cov[(size_t)overlaps[o].q_end + 1]--; /* wraps; the prefix sum below brings it back */
     }
+    for (uint32_t i = 1; i < tpl_len; ++i) cov[i] += cov[i - 1];
     uint32_t count = 0;
     bool over = false;
     auto push = [&](uint32_t b, uint32_t e2) {

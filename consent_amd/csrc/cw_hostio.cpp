@@ -21,7 +21,14 @@
  */
 #include "../../include/consent_amd.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -102,54 +109,113 @@ struct cw_paf_reader {
 
 extern "C" {
 
+/* indexReads (src/utils.cpp:166-205), fast: the file is mapped; one sequential pass finds the records with the reference's own line
+ * rules (below), then the bases are packed by all cores, each record into the words its place in the file gives it.
+ *   - a record = a header line (first character dropped, cut at the first blank), one sequence line, and every following line that is
+ *     not empty and does not start with '>' or '+'; a '+' line is followed by as many quality lines as there were sequence lines, then
+ *     the next header; the loop ends at the first empty header line (or the end of the file)
+ *   - a later record with the same name replaces the earlier one (its words stay where they were written, unreferenced)
+ * Only '\n' ends a line: a '\r' is a base like any other non-ACG byte (T), as with std::getline. */
+struct RecSpan { size_t seq_beg, seq_end; uint32_t len, id; uint64_t word_off; };
+
+static void pack_span(const char* p, size_t beg, size_t end, uint32_t* words) {
+    static const uint8_t* lut = [] {
+        static uint8_t t[256];
+        for (int c = 0; c < 256; ++c) { const int u = toupper(c); t[c] = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : 3; }
+        return (const uint8_t*)t;
+    }();
+    uint32_t acc = 0, nb = 0;
+    size_t w = 0;
+    for (size_t i = beg; i < end; ++i) {
+        const unsigned char c = (unsigned char)p[i];
+        if (c == '\n') continue;
+        acc |= (uint32_t)lut[c] << (30 - 2 * nb);
+        if (++nb == 16) { words[w++] = acc; acc = 0; nb = 0; }
+    }
+    if (nb) words[w] = acc;
+}
+
 static int index_file(cw_read_index* ix, const char* path) {
-    std::ifstream f(path);
-    if (!f) return CW_E_INVALID;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return CW_E_INVALID;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return CW_E_INVALID; }
+    const size_t n = (size_t)sb.st_size;
+    const char* p = n ? (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    close(fd);
+    if (n && p == (const char*)MAP_FAILED) return CW_E_INVALID;
+    int rc = CW_OK;
     try {
         if (!ix->words.empty()) ix->words.pop_back(); /* the guard word of an earlier file */
-        std::string header, seq, sequence;
-        std::getline(f, header);
-        while (header.length() > 0) {
-            header.erase(0, 1);
-            const size_t sp = header.find(' ');
-            if (sp != std::string::npos) header.erase(sp);
-            std::getline(f, seq);
-            sequence = seq;
+        std::vector<RecSpan> recs;
+        /* a "line" = [pos, eol); getline semantics: the last line may lack its newline; past the end every line is empty */
+        auto eol_of = [&](size_t pos) { if (pos >= n) return n; const void* q = memchr(p + pos, '\n', n - pos); return q ? (size_t)((const char*)q - p) : n; };
+        auto next_of = [&](size_t eol) { return eol < n ? eol + 1 : n; };
+        size_t pos = 0, eol = eol_of(0);
+        uint64_t woff = ix->words.size();
+        while (eol > pos) { /* header.length() > 0 */
+            size_t hb = pos + 1, he = eol;
+            const void* sp = hb < he ? memchr(p + hb, ' ', he - hb) : nullptr;
+            if (sp) he = (size_t)((const char*)sp - p);
+            std::string header(p + hb, he > hb ? he - hb : 0);
+            pos = next_of(eol); eol = eol_of(pos);
+            RecSpan r;
+            r.seq_beg = pos;
+            size_t len = eol - pos;
             int nb_lines = 1;
-            seq.clear();
-            std::getline(f, seq);
-            while (seq.length() > 0 && seq[0] != '>' && seq[0] != '+') {
-                sequence += seq;
-                nb_lines++;
-                seq.clear();
-                std::getline(f, seq);
+            r.seq_end = eol;
+            pos = next_of(eol); eol = eol_of(pos);
+            while (eol > pos && p[pos] != '>' && p[pos] != '+') {
+                len += eol - pos; nb_lines++;
+                r.seq_end = eol;
+                pos = next_of(eol); eol = eol_of(pos);
             }
-            uint32_t id;
+            if (len > 0xFFFFFFFFull) { rc = CW_E_INVALID; break; }
+            r.len = (uint32_t)len;
             auto it = ix->by_name.find(header);
             if (it == ix->by_name.end()) {
-                id = (uint32_t)ix->names.size();
-                ix->by_name.emplace(header, id);
+                r.id = (uint32_t)ix->names.size();
+                ix->by_name.emplace(header, r.id);
                 ix->names.push_back(header);
                 ix->len.push_back(0);
                 ix->word_off.push_back(0);
-            } else id = it->second;                              /* index[header] = ... replaces */
-            ix->len[id] = (uint32_t)sequence.size();
-            ix->word_off[id] = ix->words.size();
-            pack_into(sequence, ix->words);
-            if (!seq.empty() && seq[0] == '+') {                  /* FASTQ: skip the quality block by line count */
-                seq.clear();
-                std::getline(f, seq);
-                for (int i = 1; i < nb_lines; ++i) { seq.clear(); std::getline(f, seq); }
-                seq.clear();
-                std::getline(f, seq);
+            } else r.id = it->second;                            /* index[header] = ... replaces */
+            r.word_off = woff;
+            woff += (len + 15) / 16;
+            ix->len[r.id] = r.len;
+            ix->word_off[r.id] = r.word_off;
+            recs.push_back(r);
+            if (eol > pos && p[pos] == '+') {                    /* FASTQ: skip the quality block by line count */
+                pos = next_of(eol); eol = eol_of(pos);
+                for (int i = 1; i < nb_lines; ++i) { pos = next_of(eol); eol = eol_of(pos); }
+                pos = next_of(eol); eol = eol_of(pos);
             }
-            header = seq;
         }
-        ix->words.push_back(0u); /* readers may look one word past a sequence's last word */
+        if (rc == CW_OK) {
+            ix->words.resize((size_t)woff + 1, 0u);              /* + the guard word: readers may look one word past a sequence's last word */
+            uint32_t* words = ix->words.data();
+            unsigned nt = std::thread::hardware_concurrency();
+            nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
+            if (recs.size() < 64 || n < (1u << 20)) nt = 1;
+            std::vector<std::thread> th;
+            std::atomic<size_t> cursor{0};
+            auto work = [&]() {
+                for (;;) {
+                    const size_t i0 = cursor.fetch_add(64);
+                    if (i0 >= recs.size()) break;
+                    const size_t i1 = i0 + 64 < recs.size() ? i0 + 64 : recs.size();
+                    for (size_t i = i0; i < i1; ++i) pack_span(p, recs[i].seq_beg, recs[i].seq_end, words + recs[i].word_off);
+                }
+            };
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto& t : th) t.join();
+        }
     } catch (...) {
-        return CW_E_NOMEM;
+        rc = CW_E_NOMEM;
     }
-    return CW_OK;
+    if (n) munmap((void*)p, n);
+    return rc;
 }
 
 int cw_index_reads(const char* path, cw_read_index** out) {

@@ -907,6 +907,20 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
     /* see cw_poa_slab_kernel: all but the last persist_wgs work-groups take a chunk of tasks and end */
     const bool yields = blockIdx.x + sc.persist_wgs[0] < gridDim.x;
     uint32_t ran = 0;
+    {   /* what outgrew tier Q (its kernel ran before this one on the same stream: the list is complete) */
+        const uint32_t n_q = min(sc.ctr->n_over[0], sc.list_cap);
+        for (;;) {
+            uint32_t qi = 0;
+            if (lane == 0) qi = atomicAdd(&sc.ctr->next_over[0], 1u);
+            qi = (uint32_t)__shfl((int)qi, 0);
+            if (qi >= n_q) break;
+            const uint32_t ti = sc.over_list[0][qi];
+            const PoaTask t = sc.tasks[ti];
+            const int rc = poa_run<int16_t, true>(M, t, b, sc, lane, acc);
+            if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
+            cw_wave_sync();
+        }
+    }
     for (;;) {
         uint32_t ti = 0;
         if (lane == 0) ti = atomicAdd(&sc.ctr->next_task, 1u);
@@ -1053,6 +1067,11 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
 #define CW_SORT_LDS_CLS 131072 /* classes of the first so many list entries are kept in LDS between the two passes */
 __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t max_len, int tier) {
     uint32_t c;
+    if (tier == 0) { /* tier Q: the four tasks of a wave advance in lock step, so neighbours in the list should be alike: longest members first,
+                        then by how many there are */
+        const uint32_t nm = n_members >> 3;
+        return (CW_SORT_CLASSES - 1) - ((max_len < 32u ? max_len : 31u) * 4u + (nm < 3u ? nm : 3u));
+    }
     if (tier == 1) {
         c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;
     } else {
@@ -1068,7 +1087,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
     __shared__ uint32_t cnt[16][CW_SORT_CLASSES];
     __shared__ uint32_t tot_c[CW_SORT_CLASSES];
     extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* CW_SORT_LDS_CLS bytes */
-    const int tier = 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tier = blockIdx.x == 3 ? 0 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list */
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
     uint32_t* list = sc.tier_list[tier];

@@ -127,3 +127,48 @@ def test_paf_errors_are_loud(tmp_path):
         list(ca.PafReader(short, ix))
     with pytest.raises(ca.EngineError):
         ca.ReadIndex(str(tmp_path / "missing.fa"))
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_index_reads_parallel_path_on_a_larger_file(tmp_path, fastq):
+    """more than 64 records and more than 1 MB: the records are packed by several threads; every read still equals the reference's,
+    including lower case, non-ACGT letters, duplicate names and a '\\r' kept as a base"""
+    r = need_ref()
+    rng = random.Random(77 + fastq)
+    path = str(tmp_path / ("big.fq" if fastq else "big.fa"))
+    names, seqs = [], []
+    with open(path, "w") as f:
+        for i in range(700):
+            name = f"r{i % 690}"  # ten names come back: the later record wins
+            s = "".join(rng.choice("ACGTacgtNn") for _ in range(rng.randrange(800, 3200)))
+            if i == 5:
+                s = s[:100] + "\r" + s[100:]
+            names.append(name)
+            seqs.append(s)
+            lines = [s[x : x + 70] for x in range(0, len(s), 70)] if i % 2 else [s]
+            f.write(("@" if fastq else ">") + name + (" desc" if i % 5 == 0 else "") + "\n" + "\n".join(lines))
+            if fastq:
+                f.write("\n+\n" + "\n".join("#" * len(x) for x in lines))
+            f.write("\n")  # (the reference itself never returns from a file whose last line lacks its newline)
+    assert os.path.getsize(path) > (1 << 20)
+    ix = ca.ReadIndex(path)
+    assert len(ix.names) == 690
+    buf = np.zeros(8192, np.uint8)
+    ln = C.c_uint32()
+    for name in sorted(set(names), key=lambda x: int(x[1:]))[::7] + ["r5", "r0", "r9", "r689"]:
+        n_ref = r.ref_index_reads_lookup(path.encode(), name.encode(), C.c_void_p(buf.ctypes.data), len(buf), C.byref(ln))
+        assert n_ref == 690
+        i = ix.find(name)
+        assert i >= 0 and ix.seq_len[i] == ln.value, name
+        assert ix.sequence(i) == buf[: ln.value].tobytes().decode(), name
+
+
+def test_index_reads_without_a_final_newline_simply_ends(tmp_path):
+    """(no reference comparison: the reference spins on such a file) the last record is complete, FASTA and FASTQ"""
+    pa, pq = str(tmp_path / "a.fa"), str(tmp_path / "a.fq")
+    open(pa, "w").write(">x\nACGT\nGG\n>y z\nTTTA")
+    open(pq, "w").write("@x\nACGT\n+\nIIII\n@y\nTTTA\n+\nIIII")
+    for p in (pa, pq):
+        ix = ca.ReadIndex(p)
+        assert ix.names == ["x", "y"] and ix.sequence(1) == "TTTA"
+    assert ca.ReadIndex(pa).sequence(0) == "ACGTGG"
