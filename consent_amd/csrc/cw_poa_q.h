@@ -6,7 +6,7 @@
  * three quarters of the lanes of every DP row idle and spends the same instructions on a 14-column row as on a 128-column one.
  * Here a task owns a 16-lane DPP row: two DP columns per lane in packed int16 (members up to 31 bases), a four-step row_shr
  * prefix max (the row_bcast steps of the 64-lane ladder fall away), the same graph arrays as tier S in a quarter-size slab
- * (64 nodes / 192 edges, 7.3 KB per task).  The four tasks of a wave run the same instruction stream under their own
+ * (40 nodes / 120 edges, 4.7 KB per task).  The four tasks of a wave run the same instruction stream under their own
  * predicates -- every "wave-uniform" quantity of cw_poa.h (graph size, row, path position) is a per-lane value that is equal
  * inside a row -- so one instruction advances four alignments.
  *
@@ -18,14 +18,14 @@
 
 #include "cw_poa.h"
 
-#define CW_POAQ_NC 64
-#define CW_POAQ_EC 192
+#define CW_POAQ_NC 40
+#define CW_POAQ_EC 120
 #define CW_POAQ_LC 31
 #define CW_POAQ_HS 32 /* row stride of the DP matrix: columns 0..31 */
 #define CW_POAQ_HC ((CW_POAQ_NC + 1) * CW_POAQ_HS)
 #define CW_POAQ_TASK_BYTES ((CW_POAQ_HC * 2 + CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC) + 15) / 16 * 16)
-#define CW_POAQ_WAVES 5 /* 20 tasks per work-group: 146 KB of LDS, one work-group per CU */
-#define CW_POAQ_ROUTE_NODES 56 /* tasks expected to stay below this many nodes come here */
+#define CW_POAQ_WAVES 8 /* 32 tasks per work-group: 150 KB of LDS, one work-group per CU (measured: 5 waves of 64-node slabs 26 ms, 7 x 48 13 ms, 8 x 40 8.7 ms, 10 x 32 5.2 ms for the tasks they take; the step is best here) */
+#define CW_POAQ_ROUTE_NODES 35 /* tasks expected to stay below this many nodes come here */
 
 /* ---- 16-lane row primitives ------------------------------------------------------------------------------------------------ */
 __device__ __forceinline__ unsigned q_ballot(bool p) { return (unsigned)(__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFu; }
