@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "1")), help="engines per GPU taking the steps in turn (each has its own scratch and streams)")
     ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
 
@@ -119,7 +120,8 @@ def main():
     if args.windows > 0:
         n_win = args.windows
     prm = ca.Params(9, 4, 8, 2, max_msa)
-    eng = ca.Engine(prm, device=local_rank)
+    engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, args.engines))]
+    eng = engines[0]
     lib = eng.lib
     dev = torch.device("cuda", local_rank)
 
@@ -152,10 +154,16 @@ def main():
     t_soff = (torch.arange(n_win + 1, dtype=torch.int64, device=dev) * solid_cap)
     t_slen = torch.zeros(n_win, dtype=torch.int32, device=dev)
     r = Result(t_cons.data_ptr(), t_coff.data_ptr(), t_clen.data_ptr(), t_stat.data_ptr(), t_solid.data_ptr(), t_soff.data_ptr(), t_slen.data_ptr())
+    rs, keep_r = [r], []
+    for _ in range(1, len(engines)):  # batches in flight at the same time need their own result arrays
+        tt_ = (torch.zeros_like(t_cons), torch.zeros_like(t_clen), torch.zeros_like(t_stat), torch.zeros_like(t_solid), torch.zeros_like(t_slen))
+        keep_r.append(tt_)
+        rs.append(Result(tt_[0].data_ptr(), t_coff.data_ptr(), tt_[1].data_ptr(), tt_[2].data_ptr(), tt_[3].data_ptr(), t_soff.data_ptr(), tt_[4].data_ptr()))
     torch.cuda.synchronize(dev)
 
+    ne = len(engines)
     for i in range(args.warmup):
-        eng.run_device(batches[i % n_batches], r)
+        engines[i % ne].run_device(batches[i % n_batches], rs[i % ne])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -164,14 +172,18 @@ def main():
     n_over = n_tpl = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.run_device(batches[(args.warmup + i) % n_batches], r)
-        for k, v in eng.timings().items():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
-            stage_ms.setdefault(k, []).append(v)
+        engines[i % ne].run_device(batches[(args.warmup + i) % n_batches], rs[i % ne])
+        if ne == 1 or i >= args.steps - ne:  # with several engines only their last steps are read (reading waits for the step)
+            for k, v in engines[i % ne].timings().items() if ne == 1 else ():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
+                stage_ms.setdefault(k, []).append(v)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if ne > 1:
+        for k, v in engines[(args.steps - 1) % ne].timings().items():
+            stage_ms.setdefault(k, []).append(v)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -366,6 +378,7 @@ def main():
         print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier", ctr[6:11].tolist(), "outgrew into tier", ctr[16:21].tolist(), file=sys.stderr)
         print("phase Mcycles", {n: round(float(v) / 1e6, 2) for n, v in zip(names, prof) if n != "-"}, file=sys.stderr)
         print("chain kernel: windows", int(prof[44]), "mean anchors", float(prof[42]) / max(1, int(prof[44])), "mean dirty sequences", float(prof[43]) / max(1, int(prof[44])), file=sys.stderr)
+        print("tier L: chunk-rows", int(prof[46]), "rows", int(prof[47]), "fill cycles per chunk-row", float(prof[8 + 5 * 3 + 1]) / max(1, int(prof[46])), file=sys.stderr)
         print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))

@@ -23,7 +23,7 @@
 
 #define CW_CH_WAVES 4
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
-#define CW_CH_LIST_BYTES 1536
+#define CW_CH_LIST_BYTES 1792
 
 __device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t ch_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             uint16_t* q_mx = q_n + 64;
             uint16_t* q_fs = q_mx + 64;
             uint16_t* q_fst = q_fs + 64;
+            uint32_t* q_sl = (uint32_t*)(q_fst + 64);                               /* sum of the members' lengths */
             const size_t var_room = (size_t)((uint8_t*)q_off - var);
             const size_t pres_bytes = use_bits ? (size_t)A * Nw * 8 : 0;
             const size_t pd_bytes = use_bits ? (size_t)A * n_dirty * 2 : 0;
@@ -338,7 +339,8 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         const uint32_t m_off = mb + (uint32_t)minc - (poa ? e_n : 0u);
                         if (poa) { /* task records: one lane each */
                             PoaTask t;
-                            t.window = w; t.seg_slot = seg_base + q_seg[lane]; t.member_off = m_off; t.n_members = e_n; t.max_len = e_mx;
+                            t.window = w; t.seg_slot = seg_base + q_seg[lane]; t.member_off = m_off; t.n_members = e_n;
+                            t.max_len = e_mx | ((e_n ? q_sl[lane] / e_n : 0u) << 16); /* longest member | mean member length: what the tier sort goes by */
                             t.out_off = q_off[lane]; t.out_cap = q_need[lane];
                             t.state = tier ? 2u : 0u; /* 0 = tier S takes it from the task array; anything else is on a list */
                             sc.tasks[t_idx] = t;
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     const bool valid = seg <= m;
                     const int ca = (valid && seg > 0) ? (int)chain[seg - 1] : -1;
                     const int cb = (valid && seg < m) ? (int)chain[seg] : -1;
-                    uint32_t n_mem = 0, mn = 0xFFFFFFFFu, mx = 0, first_seq = 0, first_start = 0;
+                    uint32_t n_mem = 0, mn = 0xFFFFFFFFu, mx = 0, first_seq = 0, first_start = 0, sl = 0;
                     const uint32_t ra = (uint32_t)(ca >= 0 ? ca : 0) * Np, rb = (uint32_t)(cb >= 0 ? cb : 0) * Np;
 #pragma unroll 8
                     for (uint32_t s = 0; s < N; ++s) {
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             if (is) {
                                 if (n_mem == 0) { first_seq = s; first_start = st; }
                                 n_mem++;
-                                mn = min(mn, ln); mx = max(mx, ln);
+                                mn = min(mn, ln); mx = max(mx, ln); sl += ln;
                             }
                         }
                     }
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         if (serial) {
                             const uint32_t qi = q_cnt + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
                             q_off[qi] = abs_off; q_need[qi] = need; q_seg[qi] = (uint16_t)seg; q_ca[qi] = (int16_t)ca; q_cb[qi] = (int16_t)cb;
-                            q_n[qi] = (uint16_t)n_mem; q_mx[qi] = (uint16_t)mx; q_fs[qi] = (uint16_t)first_seq; q_fst[qi] = (uint16_t)first_start;
+                            q_n[qi] = (uint16_t)n_mem; q_mx[qi] = (uint16_t)mx; q_fs[qi] = (uint16_t)first_seq; q_fst[qi] = (uint16_t)first_start; q_sl[qi] = sl;
                         }
                         q_cnt += n_new;
                         cw_wave_sync();

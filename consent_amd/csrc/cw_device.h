@@ -89,7 +89,7 @@ struct BatchCounters {
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
-    unsigned long long prof[48];  /* cycle totals per phase (0-32), longest single task per POA tier (36-40), see cw_debug_profile */
+    unsigned long long prof[64];  /* cycle totals per phase (0-32), longest single task per POA tier (36-40), see cw_debug_profile */
 };
 
 struct DevBatch {

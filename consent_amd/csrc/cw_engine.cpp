@@ -350,11 +350,34 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     cw_sort_tier_kernel<<<4, 1024, CW_SORT_LDS_CLS, st>>>(sc); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
+    const char* ph_env = getenv("CW_PHASES");
+    const int phases = ph_env ? atoi(ph_env) : 0;
+    const uint32_t grid_l = wgs_l;
+    if (phases == 2) {
+        /* experiment: tier Q, then S + M1 + M2 side by side, then tier L alone with every hand-over already on its list */
+        sid = stage_begin(e, st, "poa_q");
+        cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, st>>>(db, sc);
+        stage_end(e, st, sid);
+        CW_HIP(hipEventRecord(e->ev_fork, st));
+        for (int i = 0; i < 2; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
+        sid = stage_begin(e, e->side[1], "poa_m2");
+        cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
+        stage_end(e, e->side[1], sid);
+        sid = stage_begin(e, e->side[0], "poa_m1");
+        cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
+        stage_end(e, e->side[0], sid);
+        sid = stage_begin(e, st, "poa");
+        cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc);
+        stage_end(e, st, sid);
+        for (int i = 0; i < 2; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
+        sid = stage_begin(e, st, "poa_large");
+        cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
+        stage_end(e, st, sid);
+    } else {
     CW_HIP(hipEventRecord(e->ev_fork, st));
     for (int i = 0; i < 3; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
     /* tier L also consumes the live overflow queue; only sc.linger_wgs of its work-groups stay for that (far fewer than
        CUs, so they can never keep the producers they wait for off the machine) */
-    const uint32_t grid_l = wgs_l;
     sid = stage_begin(e, e->side[2], "poa_large");
     cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
     stage_end(e, e->side[2], sid);
@@ -371,6 +394,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, st, sid);
     for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
+    }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
     sid = stage_begin(e, st, "poa_overflow");
     cw_poa_slab_kernel<L_ARGS, 1><<<(uint32_t)cus * 2, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
@@ -450,7 +474,7 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
     memcpy(counters26, &c, 26 * 4);
-    memcpy(prof32, c.prof, sizeof(c.prof)); /* 48 entries */
+    memcpy(prof32, c.prof, sizeof(c.prof)); /* 64 entries */
     return CW_OK;
 }
 

@@ -176,6 +176,19 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         int v[NCH], dgv[NCH], upv[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
+        const bool linear_row = np == 1 && pr0 == r; /* see poa_fill_pk */
+        if (linear_row) {
+            int carry_in = CW_NEG;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int upc = rc_[0][c];
+                const int dg = cw_wave_shr1(upc, carry_in);
+                if (c + 1 < NCH) carry_in = cw_lane_value(upc, 63);
+                const int s_ = (sq_[c] == base) ? MS : XS;
+                dgv[c] = dg + s_; upv[c] = upc + G;
+                v[c] = max(dgv[c], upv[c]);
+            }
+        } else
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
             const int dist = i - prow;
@@ -196,6 +209,8 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
                     const int j = c * 64 + lane;
                     up[c] = act[c] ? (int)M.H[pr + j] : CW_NEG;
                 }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(up[c])); /* see poa_fill_pk: keeps the wait for this load out of the common path */
             }
             int carry_in = CW_NEG;
 #pragma unroll
@@ -222,9 +237,13 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             if (act[c]) M.H[i * cols + j] = (HT)nv;
             if (use_dirs && c < nch) {
                 /* single-predecessor row: the code the traceback would derive (diagonal, then vertical, then horizontal) */
-                int code = 3;
-                if (np == 1) code = (j > 0 && nv == dgv[c]) ? 0 : (nv == upv[c]) ? 1 : 2;
-                const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code >> 1);
+                unsigned long long b0, b1;
+                if (np == 1) {
+                    const unsigned long long bd = __ballot(j > 0 && nv == dgv[c]), bu = __ballot(nv == upv[c]);
+                    b0 = ~bd & bu; b1 = ~bd & ~bu;
+                } else {
+                    b0 = b1 = ~0ull;
+                }
                 if (lane == 0) { M.dirs[(r * nch + c) * 2] = b0; M.dirs[(r * nch + c) * 2 + 1] = b1; }
             }
         }
@@ -299,6 +318,22 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
             v[c] = CW_NEGPK; dgv[c] = CW_NEGPK; upv[c] = CW_NEGPK;
             srow[c] = pk_score(qpk[c], base); /* the row's substitution scores, branch-free */
         }
+        /* the usual row -- one predecessor, the row just computed (a linear stretch of the graph): straight-line code, no predecessor
+           loop, no choice of the source row.  Read in the ISA: the general loop below costs ~12 taken branches and ~130 instructions per
+           row (814 cycles per row measured in tier L); this path is the ~45 vector instructions the recurrence needs */
+        const bool linear_row = np == 1 && pr0 == r;
+        if (linear_row) {
+            int carry_in = CW_NEGPK;
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) {
+                const int upc = rc_[0][c];
+                const int sh = CW_DPP(carry_in, upc, 0x138, 0xF);
+                if (c + 1 < NCH2) carry_in = cw_lane_value(upc, 63);
+                const int dg = __builtin_amdgcn_alignbit(upc, sh, 16);
+                dgv[c] = pk_add(dg, srow[c]); upv[c] = pk_add(upc, GPK);
+                v[c] = pk_max(dgv[c], upv[c]);
+            }
+        } else
         for (int q = 0; q < np; ++q) {
             const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
             int up[NCH2];
@@ -318,6 +353,11 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
                     const int j0 = c * 128 + 2 * lane;
                     up[c] = (j0 < cols) ? Hw[(prow * hs + j0) >> 1] : CW_NEGPK;
                 }
+                /* the loaded row is "used" here, inside the branch: otherwise the compiler waits for it (s_waitcnt vmcnt(0)) where the two
+                   branches meet, i.e. in EVERY row -- and vmcnt also counts the stores of the row before, so every row waited for the
+                   previous row to reach the L2 (read in the ISA: 834 cycles per row in tier L where the arithmetic needs ~200) */
+#pragma unroll
+                for (int c = 0; c < NCH2; ++c) asm volatile("" : "+v"(up[c]));
             }
             int carry_in = CW_NEGPK;
 #pragma unroll
@@ -349,13 +389,17 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
             const int j0 = c * 128 + 2 * lane;
             if (j0 < cols) Hw[(i * hs + j0) >> 1] = nv;
             if (use_dirs && c < nch) {
-                int ce = 3, co = 3;
+                /* code 0 diagonal, 1 vertical, 2 horizontal (single predecessor), 3 = compare cell values: straight from four
+                   half-word compares to the four ballots (bit 0 = vertical, bit 1 = horizontal; both = 3) */
+                unsigned long long e0, e1, o0, o1;
                 if (np == 1) {
-                    const int xd = nv ^ dgv[c], xu = nv ^ upv[c];
-                    ce = (j0 > 0 && (xd & 0xFFFF) == 0) ? 0 : ((xu & 0xFFFF) == 0) ? 1 : 2;
-                    co = (((unsigned)xd >> 16) == 0u) ? 0 : (((unsigned)xu >> 16) == 0u) ? 1 : 2;
+                    const bool de = j0 > 0 && (short)nv == (short)dgv[c], ue = (short)nv == (short)upv[c];
+                    const bool dd = (short)((unsigned)nv >> 16) == (short)((unsigned)dgv[c] >> 16), uo = (short)((unsigned)nv >> 16) == (short)((unsigned)upv[c] >> 16);
+                    const unsigned long long bde = __ballot(de), bue = __ballot(ue), bdo = __ballot(dd), buo = __ballot(uo);
+                    e0 = ~bde & bue; e1 = ~bde & ~bue; o0 = ~bdo & buo; o1 = ~bdo & ~buo;
+                } else {
+                    e0 = e1 = o0 = o1 = ~0ull;
                 }
-                const unsigned long long e0 = __ballot(ce & 1), e1 = __ballot(ce >> 1), o0 = __ballot(co & 1), o1 = __ballot(co >> 1);
                 if (lane == 0) {
                     unsigned long long* d = M.dirs + (size_t)(r * nch + c) * 4;
                     d[0] = e0; d[1] = e1; d[2] = o0; d[3] = o1;
@@ -520,6 +564,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
             else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
         }
         POA_PROF(1);
+        if (PK == 2 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
         int bi;
@@ -1065,7 +1110,12 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
  * re-initialised afterwards by the kernel itself). */
 #define CW_SORT_CLASSES 128
 #define CW_SORT_LDS_CLS 131072 /* classes of the first so many list entries are kept in LDS between the two passes */
-__device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t max_len, int tier) {
+__device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t len_pair, int tier) {
+    /* PoaTask::max_len = longest member | mean member length << 16.  A task's time is its members' fills: rows (the graph: about the
+       longest member, growing with every member) x columns (that member's length), so members x mean length x longest member; the
+       piles of the first and last segment of a window are ragged (one long member among short ones), which the longest member alone
+       overstates by far (measured: ordering by members x longest^2 left 27-ms tasks of tier L to start after 40 ms) */
+    const uint32_t max_len = len_pair & 0xFFFFu, mean_len = len_pair >> 16;
     uint32_t c;
     if (tier == 0) { /* tier Q: the four tasks of a wave advance in lock step, so neighbours in the list should be alike: longest members first,
                         then by how many there are */
@@ -1075,7 +1125,9 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t m
     if (tier == 1) {
         c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;
     } else {
-        const unsigned long long cost = (unsigned long long)n_members * max_len * max_len + 1ull;
+        /* fitted on the task timeline of a depth-150 batch (tools/task_trace.py, CW_FIT): tier L time ~ members^1.76 x mean length^0.84 x
+           longest^0.21, tier M2 members^1.54 x mean^0.49 x longest^0.48 -- the graph grows with every member, so members count twice */
+        const unsigned long long cost = (unsigned long long)n_members * n_members * (mean_len ? mean_len : max_len) + 1ull;
         const int lg = 63 - __clzll((long long)cost);                                   /* floor(log2) */
         const uint32_t frac = lg >= 3 ? (uint32_t)((cost >> (lg - 3)) & 7ull) : 0u;     /* next three bits: eighths of an octave */
         const int q = lg * 8 + (int)frac - 8 * 13;                                      /* costs below 2^13 share the last class */

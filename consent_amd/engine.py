@@ -497,7 +497,7 @@ class Engine:
 
     def profile(self):
         c = np.zeros(26, np.uint32)
-        p = np.zeros(48, np.uint64)
+        p = np.zeros(64, np.uint64)
         _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
         return c, p
 

@@ -1,7 +1,15 @@
-"""Time the end-to-end correction loop (consent_amd.pipeline) on a synthetic long-read data set: 30x coverage of a random genome,
-12 % errors (PacBio-like mix), overlaps by construction.  Prints per-stage device time.  GPU box only."""
-import io
+"""Synthetic end-to-end workloads for the wrapper-level configurations of BASELINE.json (reads.fasta, the genome and minimap2
+are absent, so reads AND overlaps are synthesised; the PAF is written from ground-truth coordinates with the 12 columns Overlap.h
+reads) and a timed run of the native driver through bin/CONSENT-correction / bin/CONSENT-polishing with the wrappers' own flags.
+
+  config 1  --genome 460000  --cov 10 --profile pacbio                 (example/reads.fasta scale: 10x sim PacBio)
+  config 4  --genome 4600000 --cov 30 --profile ont                    (E. coli 30x, CONSENT-correct --type ONT)
+  config 5  --genome 3350000 --cov 30 --profile pacbio --polish 86     (CONSENT-polish: 86 contigs of 3.35 Mbp + 30x reads)
+GPU box only.  CW_BENCH_GPUS = number of GPUs handed to -j."""
+import argparse
+import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -9,21 +17,19 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import consent_amd as ca  # noqa: E402
-from consent_amd import pipeline  # noqa: E402
-
 COMP = np.zeros(256, np.uint8)
-for a, b in zip(b"ACGT", b"TGCA"):
-    COMP[a] = b
+for a_, b_ in zip(b"ACGT", b"TGCA"):
+    COMP[a_] = b_
+MIX = {"pacbio": (0.3, 0.6), "ont": (0.4, 0.3)}  # (deletion, insertion) shares of the errors; the rest are substitutions: 10:60:30 and 30:30:40 sub:ins:del
 
 
-def noisy(rng, seg, rate):
+def noisy(rng, seg, rate, mix=(0.3, 0.3)):
     """numpy version of the test generator: returns the noisy copy and the position map (len(seg)+1 entries)"""
     n = len(seg)
     x = rng.random(n)
-    dele = x < rate * 0.3
-    ins = (x >= rate * 0.3) & (x < rate * 0.6)
+    d_, i_ = mix
+    dele = x < rate * d_
+    ins = (x >= rate * d_) & (x < rate * (d_ + i_))
     sub = x < rate
     base = np.where(sub, rng.integers(0, 4, n), seg)
     emit = (~dele).astype(np.int64) + ins.astype(np.int64)
@@ -35,22 +41,36 @@ def noisy(rng, seg, rate):
     return out, pos
 
 
+def span(r, a, b):
+    """coordinates of genome [a, b) on sequence r's own forward strand"""
+    s, e = int(r[2][a - r[0]]), int(r[2][b - r[0]])
+    if r[3]:
+        n = len(r[4])
+        s, e = n - e, n - s
+    return s, max(e, s + 1)
+
+
 def main():
-    glen = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-    cov = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    rlen = 8000
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=400000)
+    ap.add_argument("--cov", type=int, default=30)
+    ap.add_argument("--profile", choices=sorted(MIX), default="pacbio")
+    ap.add_argument("--polish", type=int, default=0, help="number of contigs: polish them with the reads instead of correcting the reads")
+    ap.add_argument("--read-len", type=int, default=8000)
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    glen, rlen, mix = args.genome, args.read_len, MIX[args.profile]
     rng = np.random.default_rng(7)
     genome = rng.integers(0, 4, glen)
-    n_reads = glen * cov // rlen
+    n_reads = glen * args.cov // rlen
     reads = []
     for i in range(n_reads):
-        ln = int(rng.integers(rlen // 2, rlen * 3 // 2))
+        ln = int(min(glen - 1, max(1000, rng.lognormal(np.log(rlen), 0.35))))
         g0 = int(rng.integers(0, glen - ln))
-        s, pos = noisy(rng, genome[g0 : g0 + ln], 0.12)
-        rev = bool(rng.random() < 0.5)
-        reads.append((g0, g0 + ln, pos, rev, s))
+        s, pos = noisy(rng, genome[g0 : g0 + ln], 0.12, mix)
+        reads.append((g0, g0 + ln, pos, bool(rng.random() < 0.5), s))
     d = tempfile.mkdtemp()
-    fa, paf = os.path.join(d, "reads.fa"), os.path.join(d, "ovl.paf")
+    fa, paf, ctg_fa = os.path.join(d, "reads.fa"), os.path.join(d, "ovl.paf"), os.path.join(d, "contigs.fa")
     lut = np.frombuffer(b"ACGT", np.uint8)
     with open(fa, "w") as f:
         for i, (g0, g1, pos, rev, s) in enumerate(reads):
@@ -59,50 +79,71 @@ def main():
                 a = COMP[a[::-1]]
             f.write(f">r{i}\n{a.tobytes().decode()}\n")
     order = np.argsort([r[0] for r in reads])
+    starts = np.array([reads[i][0] for i in order])
     n_lines = 0
-    with open(paf, "w") as f:
-        for qi in range(n_reads):
-            q = reads[qi]
-            for ti in order:
-                t = reads[ti]
-                if ti == qi or t[1] <= q[0] + 500:
-                    continue
-                if t[0] >= q[1] - 500:
-                    break
-                a, b = max(q[0], t[0]), min(q[1], t[1])
-                if b - a < 500:
-                    continue
+    if args.polish:
+        cuts = np.linspace(0, glen, args.polish + 1).astype(int)
+        contigs = []
+        for c in range(args.polish):
+            s, pos = noisy(rng, genome[cuts[c] : cuts[c + 1]], 0.03, (0.3, 0.3))
+            contigs.append((int(cuts[c]), int(cuts[c + 1]), pos, False, s))
+        with open(ctg_fa, "w") as f:
+            for c, q in enumerate(contigs):
+                f.write(f">ctg{c}\n{lut[q[4]].tobytes().decode()}\n")
+        with open(paf, "w") as f:  # what `sort -k6,6 | reformatPAF` leaves: the contig is the query, one run of lines per contig
+            for c, q in enumerate(contigs):
+                for ti in order[np.searchsorted(starts, q[0] - 4 * rlen) :]:
+                    t = reads[ti]
+                    if t[0] >= q[1] - 300:
+                        break
+                    a, b = max(q[0], t[0]), min(q[1], t[1])
+                    if b - a < 300:
+                        continue
+                    qs, qe = span(q, a, b)
+                    ts, te = span(t, a, b)
+                    f.write(f"ctg{c}\t{len(q[4])}\t{qs}\t{qe}\t{'-' if t[3] else '+'}\tr{ti}\t{len(t[4])}\t{ts}\t{te}\t{int((b - a) * 0.8)}\t{b - a}\t60\n")
+                    n_lines += 1
+    else:
+        with open(paf, "w") as f:
+            for qi in range(n_reads):
+                q = reads[qi]
+                for ti in order[np.searchsorted(starts, q[0] - 4 * rlen) :]:
+                    t = reads[ti]
+                    if ti == qi or t[1] <= q[0] + 500:
+                        continue
+                    if t[0] >= q[1] - 500:
+                        break
+                    a, b = max(q[0], t[0]), min(q[1], t[1])
+                    if b - a < 500:
+                        continue
+                    qs, qe = span(q, a, b)
+                    ts, te = span(t, a, b)
+                    f.write(f"r{qi}\t{len(q[4])}\t{qs}\t{qe}\t{'+' if q[3] == t[3] else '-'}\tr{ti}\t{len(t[4])}\t{ts}\t{te}\t{int((b - a) * 0.76)}\t{b - a}\t60\n")
+                    n_lines += 1
+    print(f"data set: genome {glen}, {n_reads} {args.profile} reads ({os.path.getsize(fa) / 1e6:.0f} MB), {n_lines} overlaps ({os.path.getsize(paf) / 1e6:.0f} MB)"
+          + (f", {args.polish} contigs" if args.polish else ""), flush=True)
 
-                def span(r, a, b):
-                    s, e = int(r[2][a - r[0]]), int(r[2][b - r[0]])
-                    if r[3]:
-                        n = len(r[4])
-                        s, e = n - e, n - s
-                    return s, max(e, s + 1)
-
-                qs, qe = span(q, a, b)
-                ts, te = span(t, a, b)
-                f.write(f"r{qi}\t{len(q[4])}\t{qs}\t{qe}\t{'+' if q[3] == t[3] else '-'}\tr{ti}\t{len(t[4])}\t{ts}\t{te}\t{int((b - a) * 0.76)}\t{b - a}\t60\n")
-                n_lines += 1
-    print(f"data set: genome {glen}, {n_reads} reads, {n_lines} overlaps", flush=True)
-
-    # the native driver (cw_run_correction) with its own per-stage clocks
-    import json
-    import subprocess
-
-    exe = os.path.join(ROOT, "bin", "CONSENT-correction")
-    argv = [exe, "-a", paf, "-s", "3", "-S", "150", "-l", "500", "-k", "9", "-c", "8", "-A", "2", "-f", "4", "-m", "50", "-j", os.environ.get("CW_BENCH_GPUS", "1"), "-r", fa, "-M", "150", "-p", "x"]
-    for rep in range(2):
+    gpus = os.environ.get("CW_BENCH_GPUS", "1")
+    if args.polish:  # CONSENT-polish:197
+        argv = [os.path.join(ROOT, "bin", "CONSENT-polishing"), "-a", paf, "-s", "1", "-S", "20000", "-l", "500", "-k", "9", "-c", "8", "-A", "2", "-f", "4", "-m", "50", "-j", gpus,
+                "-r", ctg_fa, "-R", fa, "-M", "150", "-p", "x"]
+    else:  # CONSENT-correct:202
+        argv = [os.path.join(ROOT, "bin", "CONSENT-correction"), "-a", paf, "-s", "3", "-S", "150", "-l", "500", "-k", "9", "-c", "8", "-A", "2", "-f", "4", "-m", "50", "-j", gpus,
+                "-r", fa, "-M", "150", "-p", "x"]
+    for rep in range(args.reps):
         t0 = time.perf_counter()
-        out = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, CW_DRIVER_STATS="1", CW_DRIVER_TIMING="1"))
+        out = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, CW_DRIVER_STATS="1", CW_DRIVER_TIMING="1", CW_ON_CAPACITY="skip"))
         wall = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-2000:]
     st = json.loads([l for l in out.stderr.splitlines() if l.startswith("{")][-1])
     lines = out.stdout.split("\n")
     seqs = lines[1::2]
     bases = sum(len(x) for x in seqs)
-    up = sum(sum(c.isupper() for c in x) for x in seqs)
-    print(f"corrected {len(seqs)} reads, {bases} bases ({up / max(bases, 1):.3f} upper case) in {wall:.2f} s wall (process start to exit)")
+    up = sum(sum(c.isupper() for c in x) for x in seqs[:2000])
+    print(f"{'polished' if args.polish else 'corrected'} {len(seqs)} sequences, {bases} bases ({up / max(sum(len(x) for x in seqs[:2000]), 1):.3f} upper case in the first 2000) in {wall:.2f} s wall (process start to exit)")
+    skipped = [l for l in out.stderr.splitlines() if "left out" in l]
+    if skipped:
+        print(f"{len(skipped)} job(s) left sequences out for an engine capacity: {skipped[0][:300]}")
     print(json.dumps(st))
 
 

@@ -44,6 +44,9 @@ n = C.c_uint32()
 lib.cw_debug_task_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
 assert lib.cw_debug_task_trace(eng.handle, cap, out.ctypes.data, C.byref(n)) == 0
 a = out[: n.value]
+a = a.copy()
+mean_len = a[:, 4] >> 16
+a[:, 4] &= 0xFFFF
 tier = a[:, 10] & 0xFF
 rc = (a[:, 10] >> 8) & 0xFF
 start, dur = a[:, 8] * 1e-5, a[:, 9] * 1e-5  # ms
@@ -74,3 +77,11 @@ for tr, name in ((1, "M1"), (2, "M2"), (3, "L")):
     for lo, hi in ((0, 32), (32, 64), (64, 128), (128, 256), (256, 1024)):
         q = (ml >= lo) & (ml < hi)
         print(f"    max_len [{lo},{hi}): {int(q.sum()):7d} tasks, busy {dur[m][q].sum():9.0f} wave-ms")
+if os.environ.get("CW_FIT"):
+    for tr, name in ((1, "M1"), (2, "M2"), (3, "L")):
+        m = (tier == tr) & (dur > 0.05) & (rc == 1)
+        x1, x2, x3, y = np.log(a[m, 3].astype(float)), np.log(a[m, 4].astype(float)), np.log(np.maximum(mean_len[m], 1).astype(float)), np.log(dur[m])
+        A = np.stack([x1, x2, x3, np.ones_like(x1)], 1)
+        coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+        pred = A @ coef
+        print(f"fit {name}: dur ~ members^{coef[0]:.2f} * maxlen^{coef[1]:.2f} * meanlen^{coef[2]:.2f} * {np.exp(coef[3]):.3g} ms; residual sd of log {np.std(y - pred):.2f}; n={int(m.sum())}")
