@@ -208,6 +208,53 @@ struct Worker {
         DRV_HIP(hipStreamSynchronize(st), j, "kernels");
         const double t3 = now_ms();
         if (t2 == 0) t2 = t3;
+        if (getenv("CW_DRIVER_PROFILE")) { /* inspection: how the job's POA tasks spread over the tiers, and where tier L's time went */
+            uint32_t c[26]; unsigned long long pr[64];
+            if (cw_debug_profile(eng, c, pr) == CW_OK)
+                fprintf(stderr, "[job %llu] windows %u tasks %u members %u | routed Q %u M1 %u M2 %u L %u, outgrew into S %u L %u G %u | L Mcycles meta %.0f fill %.0f trace %.0f merge %.0f, rows %llu chunk-rows %llu, longest task M1 %.1f M2 %.1f L %.1f Mcycles\n",
+                        (unsigned long long)j.seq, n_win, c[0], c[1], c[6], c[7], c[8], c[9], c[16], c[19], c[20], pr[23] / 1e6, pr[24] / 1e6, pr[25] / 1e6, pr[26] / 1e6,
+                        pr[47], pr[46], pr[37] / 1e6, pr[38] / 1e6, pr[39] / 1e6);
+            if (getenv("CW_TASK_TRACE")) { /* timeline of the slab tiers: when their tasks ran (10 ns units since the tier sort) */
+                std::vector<uint32_t> tr((size_t)c[0] * 12 + 12);
+                uint32_t nt = 0;
+                if (cw_debug_task_trace(eng, c[0], tr.data(), &nt) == CW_OK) {
+                    for (uint32_t tier = 1; tier <= 3; ++tier) {
+                        double busy = 0, first = 1e30, last = 0, longest = 0; uint32_t cnt = 0;
+                        for (uint32_t i = 0; i < nt; ++i) {
+                            const uint32_t* q = &tr[(size_t)i * 12];
+                            if ((q[10] & 0xFF) != tier || q[9] == 0) continue;
+                            const double st_ = q[8] * 1e-5, du = q[9] * 1e-5;
+                            busy += du; first = st_ < first ? st_ : first; last = st_ + du > last ? st_ + du : last; longest = du > longest ? du : longest; ++cnt;
+                        }
+                        if (!cnt) continue;
+                        int occ[9] = {0};
+                        for (uint32_t i = 0; i < nt; ++i) {
+                            const uint32_t* q = &tr[(size_t)i * 12];
+                            if ((q[10] & 0xFF) != tier || q[9] == 0) continue;
+                            const double st_ = q[8] * 1e-5, en = st_ + q[9] * 1e-5;
+                            for (int k = 1; k <= 9; ++k) { const double at = last * k / 10.0; if (st_ < at && en > at) occ[k - 1]++; }
+                        }
+                        if (tier == 3) { /* the three runs that ended last */
+                            for (int rep = 0; rep < 3; ++rep) {
+                                double best = -1; uint32_t bi = 0;
+                                for (uint32_t i = 0; i < nt; ++i) {
+                                    const uint32_t* q = &tr[(size_t)i * 12];
+                                    if ((q[10] & 0xFF) != tier || q[9] == 0) continue;
+                                    const double en = (q[8] + (double)q[9]) * 1e-5;
+                                    if (en > best && en < last + 1 - rep * 1e-9 && (rep == 0 || en < last)) { best = en; bi = i; }
+                                }
+                                const uint32_t* q = &tr[(size_t)bi * 12];
+                                fprintf(stderr, "[job %llu]    ends %.2f start %.2f dur %.2f ms members %u max_len %u mean_len %u rc %u pass %u wave %u\n", (unsigned long long)j.seq, best,
+                                        q[8] * 1e-5, q[9] * 1e-5, q[3], q[4] & 0xFFFF, q[4] >> 16, (q[10] >> 8) & 0xFF, q[10] >> 16, q[11]);
+                                last = best;
+                            }
+                        }
+                        fprintf(stderr, "[job %llu] tier %u: %u runs, busy %.0f wave-ms, first start %.2f, last end %.2f ms, longest %.2f ms; running at 10..90 %% of its span: %d %d %d %d %d %d %d %d %d\n",
+                                (unsigned long long)j.seq, tier, cnt, busy, first, last, longest, occ[0], occ[1], occ[2], occ[3], occ[4], occ[5], occ[6], occ[7], occ[8]);
+                    }
+                }
+            }
+        }
         /* a read whose re-assembly, or one of whose windows, exceeded a documented capacity is never silently different from the reference */
         std::vector<char> tainted(n_piles, 0);
         std::string names;
@@ -357,7 +404,14 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { cw_read_index_free(index); fprintf(stderr, "[consent_amd] no HIP device: the engine has no CPU path\n"); return CW_E_NO_DEVICE; }
-    if (devs.empty()) { const int want = a->nb_threads < 1 ? 1 : (int)a->nb_threads; for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d); }
+    if (devs.empty()) {
+        /* two workers (engine + buffers each) per device: while one job is in its re-assembly -- one wave per read, the longest read sets
+           the time, most of the GPU idle -- the other worker's consensus kernels run (measured on one GPU: 717 -> 550 ms for 112 k windows) */
+        int per_dev = 2;
+        if (const char* env = getenv("CW_WORKERS_PER_DEVICE")) { const int v = atoi(env); if (v >= 1 && v <= 8) per_dev = v; }
+        const int want = a->nb_threads < 1 ? 1 : (int)a->nb_threads;
+        for (int k = 0; k < per_dev; ++k) for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d);
+    }
     for (int d : devs) if (d < 0 || d >= n_dev) { cw_read_index_free(index); return CW_E_INVALID; }
 
     std::vector<Worker> workers(devs.size());
@@ -473,7 +527,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         }
     }
     if (getenv("CW_DRIVER_STATS")) { /* counters on stderr; stdout stays pure FASTA */
-        fprintf(stderr, "{\"devices\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
+        fprintf(stderr, "{\"workers\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
                 devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
                 t_indexed - t_begin, t_engines - t_indexed, ms_parse, ms_windows, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
         for (size_t i = 0; i < workers.size(); ++i)

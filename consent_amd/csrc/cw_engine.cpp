@@ -194,7 +194,8 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         delete e;
         return CW_E_NO_DEVICE;
     }
-    bool ok = hipEventCreate(&e->ev_fork) == hipSuccess && hipEventCreate(&e->ev_begin) == hipSuccess && hipEventCreate(&e->ev_end) == hipSuccess;
+    bool ok = hipEventCreate(&e->ev_fork) == hipSuccess && hipEventCreate(&e->ev_begin) == hipSuccess && hipEventCreate(&e->ev_end) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_join_s, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->host_fb, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) memset(e->host_fb, 0, 64);
     for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
@@ -227,6 +228,7 @@ void cw_destroy(cw_engine* e) {
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
     for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join_s) (void)hipEventDestroy(e->ev_join_s);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
@@ -306,6 +308,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
                    wgs_l = yield_wgs[3] + sc.persist_wgs[3];
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2;
+    if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
     sc.use_q = getenv("CW_NO_TIER_Q") ? 0u : 1u;
     for (int t = 1; t < CW_TIERS; ++t) {
@@ -387,12 +390,19 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, e->side[0], "poa_m1");
     cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
-    sid = stage_begin(e, st, "poa_q");
-    cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, st>>>(db, sc); /* four tasks per wave, one work-group per CU */
-    stage_end(e, st, sid);
-    sid = stage_begin(e, st, "poa");
-    cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, st>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
-    stage_end(e, st, sid);
+    /* Tiers Q and S go on the ENGINE's stream, also when the caller brought its own: the runtime multiplexes streams onto a few hardware
+       queues, and a caller's stream that shares a queue with tier L's stream would make tier S wait for tier L's kernel to end --
+       whose last work-groups wait for tier S to sign off (measured in the native driver: 131 ms per job until the bounded wait ran out).
+       The engine's four streams were created together and first. */
+    hipStream_t ms = e->stream;
+    if (ms != st) CW_HIP(hipStreamWaitEvent(ms, e->ev_fork, 0));
+    sid = stage_begin(e, ms, "poa_q");
+    cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, ms>>>(db, sc); /* four tasks per wave, one work-group per CU */
+    stage_end(e, ms, sid);
+    sid = stage_begin(e, ms, "poa");
+    cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, ms>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
+    stage_end(e, ms, sid);
+    if (ms != st) { CW_HIP(hipEventRecord(e->ev_join_s, ms)); CW_HIP(hipStreamWaitEvent(st, e->ev_join_s, 0)); }
     for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
     }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
@@ -474,6 +484,7 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
     memcpy(counters26, &c, 26 * 4);
+    if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] done_wgs %u any_overflow %u n_over[0] %u next_over[0] %u n_over[3] %u next_over[3] %u\n", c.done_wgs, c.any_overflow, c.n_over[0], c.next_over[0], c.n_over[3], c.next_over[3]);
     memcpy(prof32, c.prof, sizeof(c.prof)); /* 64 entries */
     return CW_OK;
 }

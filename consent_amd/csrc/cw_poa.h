@@ -1077,7 +1077,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
             stop = (uint32_t)__shfl((int)stop, 0);
             if (stop) break;
             if (claimed == 0xFFFFFFFFu) {
-                if (++idle > (1u << 16)) break; /* ~tens of ms of polling: give up, PASS 1 takes the rest */
+                if (++idle > (1u << 13)) break; /* ~15 ms of polling: give up, PASS 1 takes the rest */
                 __builtin_amdgcn_s_sleep(64);
                 continue;
             }

@@ -252,7 +252,8 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
  * FASTA records (">name\nsequence\n") go to the file descriptor out_fd in PAF order; a read without windows, or dropped by the 10 % rule,
  * produces none.  Trimming and dropping happen only for correction without a proof file (CONSENT-correction.cpp:17,69-73).
  * nb_threads (-j) = how many GPUs to use: the first min(nb_threads, visible devices); `devices` / the environment variable CW_DEVICES
- * ("0,1,..", an id may repeat) override that.  Piles are handed to the devices job by job from one queue, there is no collective, and
+ * ("0,1,..", an id may repeat: one worker = one engine per entry) override that; by default every device gets two workers, so that
+ * one job's re-assembly overlaps the other's consensus kernels (CW_WORKERS_PER_DEVICE changes the two).  Piles are handed to the devices job by job from one queue, there is no collective, and
  * the output does not depend on the number of devices.  paf_index (-i) and path (-p) are accepted and, as in the reference, never read. */
 typedef struct cw_driver_args {
     const char* paf_index;      /* -i */

@@ -133,7 +133,7 @@ def test_two_and_three_engines_write_the_same_fasta_as_one(tmp_path):
     argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", fa, "-M", 150, "-p", "x"]
     got, err = run_bin("CONSENT-correction", argv, env={"CW_DEVICES": "0,0", "CW_DRIVER_STATS": "1"})
     assert got == fasta(one)
-    assert '"devices": 2' in err  # counters on stderr, stdout stays pure FASTA
+    assert '"workers": 2' in err  # counters on stderr, stdout stays pure FASTA
 
 
 def test_polishing_a_contig_sharded_over_engines(tmp_path):

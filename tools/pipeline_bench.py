@@ -69,7 +69,8 @@ def main():
         g0 = int(rng.integers(0, glen - ln))
         s, pos = noisy(rng, genome[g0 : g0 + ln], 0.12, mix)
         reads.append((g0, g0 + ln, pos, bool(rng.random() < 0.5), s))
-    d = tempfile.mkdtemp()
+    d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
+    os.makedirs(d, exist_ok=True)
     fa, paf, ctg_fa = os.path.join(d, "reads.fa"), os.path.join(d, "ovl.paf"), os.path.join(d, "contigs.fa")
     lut = np.frombuffer(b"ACGT", np.uint8)
     with open(fa, "w") as f:
@@ -141,6 +142,9 @@ def main():
     bases = sum(len(x) for x in seqs)
     up = sum(sum(c.isupper() for c in x) for x in seqs[:2000])
     print(f"{'polished' if args.polish else 'corrected'} {len(seqs)} sequences, {bases} bases ({up / max(sum(len(x) for x in seqs[:2000]), 1):.3f} upper case in the first 2000) in {wall:.2f} s wall (process start to exit)")
+    for l in out.stderr.splitlines():
+        if l.startswith("[job") or l.startswith("[debug"):
+            print(l)
     skipped = [l for l in out.stderr.splitlines() if "left out" in l]
     if skipped:
         print(f"{len(skipped)} job(s) left sequences out for an engine capacity: {skipped[0][:300]}")

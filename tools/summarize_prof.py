@@ -13,7 +13,8 @@ def main():
     out_json = os.path.join("profiles", f"{tag}.json")
     lines, summary = [], {"kernels": {}, "source": src, "windows_per_step": windows}
     db = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --cpu-sample 0 ...   [{tag}]")
+    cmd = os.environ.get("CW_PROF_CMD", "python bench.py --steps 5 --warmup 2 --cpu-sample 0 --pcie-steps 0 --workload ...")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- {cmd}   [{tag}]")
     lines.append(f"{'kernel':90s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}")
     for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         if not name.startswith(("cw_", "void cw_", "synth_kernel")):
