@@ -377,8 +377,11 @@ def main():
             names += [f"{tname}.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
         print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier", ctr[6:11].tolist(), "outgrew into tier", ctr[16:21].tolist(), file=sys.stderr)
         print("phase Mcycles", {n: round(float(v) / 1e6, 2) for n, v in zip(names, prof) if n != "-"}, file=sys.stderr)
-        print("chain kernel: windows", int(prof[44]), "mean anchors", float(prof[42]) / max(1, int(prof[44])), "mean dirty sequences", float(prof[43]) / max(1, int(prof[44])), file=sys.stderr)
+        print("chain kernel: windows", int(prof[44]), "mean anchors", float(prof[42]) / max(1, int(prof[44])), "mean dirty sequences", float(prof[43]) / max(1, int(prof[44])),
+              "Mcycles: stage-in", round(float(prof[48]) / 1e6, 1), "(part of idx.chain) segment flush", round(float(prof[49]) / 1e6, 1), "(part of idx.segments)", file=sys.stderr)
         print("tier L: chunk-rows", int(prof[46]), "rows", int(prof[47]), "fill cycles per chunk-row", float(prof[8 + 5 * 3 + 1]) / max(1, int(prof[46])), file=sys.stderr)
+        print("chain kernel: windows with bad masks", int(prof[52]), "with correction rows", int(prof[50]), "rows", int(prof[51]), "windows on the slow path", int(prof[53]), "Mcycles there", round(float(prof[54]) / 1e6, 1), file=sys.stderr)
+        print("stage ms", {k: round(v, 2) for k, v in eng.timings().items()}, file=sys.stderr)
         print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))

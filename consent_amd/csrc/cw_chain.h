@@ -16,6 +16,7 @@
 #ifndef CW_CHAIN_H
 #define CW_CHAIN_H
 
+#include <type_traits>
 #include "cw_device.h"
 #include "cw_index.h"
 #include "cw_poa.h" /* tier capacities for the routing rule */
@@ -24,6 +25,7 @@
 #define CW_CH_WAVES 4
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
 #define CW_CH_LIST_BYTES 1792
+#define CW_CH_TILE_STRIDE 66u /* u16 per row of phase D's tile: 64 sequences + 2 (33 words: a column read by 64 lanes hits every bank twice) */
 
 __device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t ch_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -51,13 +53,21 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             const uint8_t* blk = sc.ablock + ((size_t)ch_uni(wi->ab_base) << 4);
             const uint32_t* hdr = (const uint32_t*)blk;
             const uint32_t A = ch_uni(hdr[0]), N = ch_uni(hdr[1]), n_dirty = ch_uni(hdr[2]);
-            const bool use_bits = ch_uni(hdr[3]) != 0u;
+            const uint32_t ab_flags = ch_uni(hdr[3]);
+            const bool use_bits = (ab_flags & 1u) != 0u;
+            const bool has_bm = (ab_flags & 2u) != 0u; /* bad-anchor masks: the dirty sequences are in the presence bits except at their out-of-order anchors */
+            const uint32_t n_rows = (ab_flags & 4u) ? ch_uni(hdr[4]) : 0u; /* correction rows: what those anchors add to a pair's score, ready-made */
+            const uint32_t Ap = cw_ab_ap(A);
             const uint32_t Np = cw_ab_np(N), Nw = (N + 63u) >> 6;
             const uint32_t* ckey = (const uint32_t*)(blk + CW_AB_HDR);
             const unsigned long long* gpres = (const unsigned long long*)((const uint8_t*)ckey + cw_ab_align((uint64_t)A * 4));
             const uint16_t* gdirty = (const uint16_t*)((const uint8_t*)gpres + cw_ab_align((uint64_t)A * Nw * 8));
-            const uint16_t* P = (const uint16_t*)((const uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
+            const unsigned long long* gbadm = (const unsigned long long*)((const uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
+            const uint8_t* growid = (const uint8_t*)gbadm + cw_ab_align((uint64_t)A * 8);
+            const uint8_t* gdelta = growid + cw_ab_align((uint64_t)A);
+            const uint16_t* P = (const uint16_t*)(n_rows ? gdelta + (size_t)n_rows * Ap : growid);
             const int sup_min = min((int)prm.common_kmers, (int)N / 2); /* correctionMSA.cpp:31 */
+            if (lane == 0) { atomicAdd(&sc.ctr->prof[50], (ab_flags & 4u) ? 1ull : 0ull); atomicAdd(&sc.ctr->prof[51], (unsigned long long)n_rows); atomicAdd(&sc.ctr->prof[52], has_bm ? 1ull : 0ull); }
             if (lane == 0) { atomicAdd(&sc.ctr->prof[42], (unsigned long long)A); atomicAdd(&sc.ctr->prof[43], (unsigned long long)n_dirty); atomicAdd(&sc.ctr->prof[44], 1ull); }
             const uint32_t seg_base = ch_uni(wi->seg_base), seg_cap = ch_uni(wi->seg_cap);
             const uint32_t arena_base = ch_uni(wi->arena_base), arena_cap = ch_uni(wi->arena_cap);
@@ -67,8 +77,10 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             int16_t* cnxt = clen + A;                          /* A     */
             int16_t* smax = cnxt + A;                          /* A + 1 */
             uint16_t* chain = (uint16_t*)(smax + A + 1);       /* A     */
-            int32_t* csc = (int32_t*)(((uintptr_t)(chain + A) + 3) & ~(uintptr_t)3); /* A */
-            uint8_t* var = (uint8_t*)(((uintptr_t)(csc + A) + 7) & ~(uintptr_t)7);
+            /* offsets, not pointer arithmetic through integers: the compiler must keep seeing LDS pointers (ds_ instead of flat_ instructions) */
+            const uint32_t off_csc = (8u * A + 2u + 3u) & ~3u, off_var = (off_csc + 4u * A + 7u) & ~7u;
+            int32_t* csc = (int32_t*)(slab + off_csc);         /* A     */
+            uint8_t* var = slab + off_var;
             /* the last CW_CH_LIST_BYTES of the slab: segments waiting for the whole wave (phase D), 64 entries */
             uint32_t* q_off = (uint32_t*)(slab + CW_CH_SLAB - CW_CH_LIST_BYTES);   /* arena offset            */
             uint32_t* q_need = q_off + 64;                                           /* arena bytes reserved    */
@@ -80,27 +92,32 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             uint16_t* q_fs = q_mx + 64;
             uint16_t* q_fst = q_fs + 64;
             uint32_t* q_sl = (uint32_t*)(q_fst + 64);                               /* sum of the members' lengths */
-            const size_t var_room = (size_t)((uint8_t*)q_off - var);
-            const size_t pres_bytes = use_bits ? (size_t)A * Nw * 8 : 0;
-            const size_t pd_bytes = use_bits ? (size_t)A * n_dirty * 2 : 0;
-            const bool pres_lds = use_bits && pres_bytes <= var_room;
-            const bool pd_lds = pres_lds && n_dirty > 0 && pres_bytes + pd_bytes <= var_room;
+            const size_t var_room = (size_t)(CW_CH_SLAB - CW_CH_LIST_BYTES) - off_var;
+            /* behind the presence bitsets: the correction rows (row ids + rows) when the block has them and they fit */
+            const size_t pres_only = use_bits ? (size_t)A * Nw * 8 : 0;
+            const size_t delta_bytes = (size_t)Ap + (size_t)n_rows * Ap;
+            const bool pres_lds = use_bits && pres_only <= var_room;
+            const bool use_delta = pres_lds && n_rows > 0u && pres_only + delta_bytes <= var_room;
+            const bool far_delta = pres_lds && n_rows > 0u && !use_delta && pres_only + Ap <= var_room; /* row ids in LDS, the rows stay in the block */
             unsigned long long* lpres = (unsigned long long*)var;
-            uint16_t* lpd = (uint16_t*)(var + pres_bytes);     /* Pd[a * n_dirty + d] */
+            const uint8_t* lrowid = (const uint8_t*)(lpres + (size_t)A * Nw); /* anchor -> correction row or 0xFF */
+            const uint8_t* ldelta = lrowid + Ap;                              /* row r: ldelta[r * Ap + other anchor] */
             if (pres_lds) for (uint32_t i = lane; i < A * Nw; i += 64) lpres[i] = gpres[i];
-            if (pd_lds)
-                for (uint32_t i = lane; i < A * n_dirty; i += 64) {
-                    const uint32_t a = i / n_dirty, d = i - a * n_dirty;
-                    lpd[i] = P[a * Np + gdirty[d]];
-                }
+            if (use_delta || far_delta) {
+                unsigned long long* dst = lpres + (size_t)A * Nw;
+                const unsigned long long* src = (const unsigned long long*)growid; /* row ids and rows are contiguous, 16-byte granules */
+                for (uint32_t i = lane; i < (use_delta ? delta_bytes : (size_t)Ap) / 8; i += 64) dst[i] = src[i];
+            }
             if (lane == 0) smax[A] = -1;
             cw_wave_sync();
+            CW_PROF(sc.ctr, 48, lane == 0);
 
             /* ================= phase C: chain ================= */
             /* The recurrence is serial over the anchors, so its cost is the latency of one step.  In the usual case (presence bitsets in
-               LDS, at most 256 sequences) the 64 nearest successors of the current anchor -- all that is looked at unless the early stop
-               fails -- are a register window: lane l holds length, score and presence of anchor a+1+l, shifted by one lane per step
-               (DPP), so that a step neither waits for lane 0's LDS writes of the step before nor re-reads what it already had. */
+               LDS, at most 256 sequences, no dirty sequence or correction rows for them) the 64 nearest successors of the current anchor
+               -- all that is looked at unless the early stop fails -- are a register window: lane l holds length, score, presence and
+               correction row of anchor a+1+l, shifted by one lane per step (DPP), so that a step neither waits for lane 0's LDS writes of
+               the step before nor re-reads what it already had; what a step needs from LDS besides is requested one step ahead. */
             const bool narrow = (uint64_t)A * N < (1ull << 21) && A < 2047u; /* (length + 1, score) fit 11 + 21 bits: a chain's score is at most its length x N */
             auto wave_best = [&](unsigned long long key, uint32_t b0) -> unsigned long long {
                 if (!narrow) return cw_wave_max_u64(key);
@@ -111,13 +128,40 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                 const uint32_t fb = b0 + (uint32_t)(__ffsll((long long)who) - 1);
                 return ((unsigned long long)(mx >> 21) << 48) | ((unsigned long long)(mx & 0x1FFFFFu) << 16) | (unsigned long long)(0xFFFFu - fb);
             };
-            if (use_bits && pres_lds && Nw <= 4u) {
+            /* the window path, compiled once per (words of presence, correction rows or not): everything it tests is then a constant */
+            auto chain_window = [&](auto nw_tag, auto delta_tag) {
+                constexpr uint32_t NW = decltype(nw_tag)::value;
+                constexpr uint32_t DELTA = decltype(delta_tag)::value; /* 0 no dirty sequence, 1 correction rows in LDS, 2 in the block (too many for LDS) */
+                auto row_at = [&](const uint32_t row, const uint32_t col) -> uint32_t {
+                    if constexpr (DELTA == 2u) return (uint32_t)gdelta[(size_t)row * Ap + col];
+                    else return (uint32_t)ldelta[row * Ap + col];
+                };
                 int r_len = 0, r_sc = 0, sm_run = -1;
-                unsigned long long r_p[4] = {0ull, 0ull, 0ull, 0ull};
-                for (int a = (int)A - 1; a >= 0; --a) {
-                    unsigned long long pa[4];
+                unsigned long long r_p[NW];
+                unsigned long long pa_n[NW];
 #pragma unroll
-                    for (uint32_t x = 0; x < 4; ++x) pa[x] = x < Nw ? lpres[(size_t)a * Nw + x] : 0ull;
+                for (uint32_t x = 0; x < NW; ++x) { r_p[x] = 0ull; pa_n[x] = A > 0 ? lpres[(size_t)(A - 1u) * NW + x] : 0ull; }
+                int r_row = 0xFF;        /* correction row of anchor a + 1 + lane */
+                uint32_t d_b = 0;        /* row(bb)[a] of this step, requested during the step before */
+                uint32_t row_n = DELTA && A > 0 ? (uint32_t)lrowid[A - 1u] : 0xFFu;
+                int sm_n = 0;
+                for (int a = (int)A - 1; a >= 0; --a) {
+                    unsigned long long pa[NW];
+#pragma unroll
+                    for (uint32_t x = 0; x < NW; ++x) pa[x] = pa_n[x];
+                    const uint32_t row_a = row_n;
+                    const uint32_t d_b_cur = d_b;
+                    const int sm_far = sm_n; /* smax[a + 65] when that anchor exists */
+                    const int r_row_next = DELTA ? cw_wave_shr1(r_row, (int)row_a) : 0xFF; /* the window as the next step sees it */
+                    if (a > 0) {
+#pragma unroll
+                        for (uint32_t x = 0; x < NW; ++x) pa_n[x] = lpres[(size_t)(a - 1) * NW + x];
+                        if (DELTA) {
+                            row_n = (uint32_t)lrowid[a - 1];
+                            d_b = r_row_next != 0xFF ? row_at((uint32_t)r_row_next, (uint32_t)(a - 1)) : 0u;
+                        }
+                        sm_n = (uint32_t)a + 64u < A ? (int)smax[a + 64] : 0;
+                    }
                     unsigned long long best = 0ull;
                     bool stop = false;
                     {   /* successors a+1 .. a+64: from the window */
@@ -126,25 +170,14 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         if (bb < A) {
                             uint32_t cnt = 0;
 #pragma unroll
-                            for (uint32_t x = 0; x < 4; ++x) cnt += (uint32_t)__popcll(pa[x] & r_p[x]);
-                            if (pd_lds) {
-                                for (uint32_t d = 0; d < n_dirty; ++d) {
-                                    const uint32_t pa_ = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
-                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
-                                }
-                            } else {
-                                for (uint32_t d = 0; d < n_dirty; ++d) {
-                                    const uint32_t sd = gdirty[d];
-                                    const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
-                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
-                                }
-                            }
+                            for (uint32_t x = 0; x < NW; ++x) cnt += (uint32_t)__popcll(pa[x] & r_p[x]);
+                            if (DELTA) { cnt += d_b_cur; if (row_a != 0xFFu) cnt += row_at(row_a, bb); }
                             if ((int)cnt >= sup_min)
                                 key = ((unsigned long long)((uint32_t)r_len + 1u) << 48) | ((unsigned long long)((uint32_t)r_sc + cnt) << 16) |
                                       (unsigned long long)(0xFFFFu - bb);
                         }
                         best = wave_best(key, b0);
-                        if (best != 0ull && b0 + 64 < A) stop = (int)smax[b0 + 64] < (int)(best >> 48) - 1;
+                        if (best != 0ull && b0 + 64 < A) stop = sm_far < (int)(best >> 48) - 1;
                         stop = ch_uni(stop ? 1 : 0) != 0u;
                     }
                     if (!stop) {
@@ -153,18 +186,12 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             unsigned long long key = 0ull;
                             if (bb < A) {
                                 uint32_t cnt = 0;
-                                for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(pa[x < 4 ? x : 0] & lpres[(size_t)bb * Nw + x]);
-                                if (pd_lds) {
-                                    for (uint32_t d = 0; d < n_dirty; ++d) {
-                                        const uint32_t pa_ = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
-                                        cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
-                                    }
-                                } else {
-                                    for (uint32_t d = 0; d < n_dirty; ++d) {
-                                        const uint32_t sd = gdirty[d];
-                                        const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
-                                        cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
-                                    }
+#pragma unroll
+                                for (uint32_t x = 0; x < NW; ++x) cnt += (uint32_t)__popcll(pa[x] & lpres[(size_t)bb * NW + x]);
+                                if (DELTA) {
+                                    const uint32_t row_b = lrowid[bb];
+                                    if (row_a != 0xFFu) cnt += row_at(row_a, bb);
+                                    if (row_b != 0xFFu) cnt += row_at(row_b, (uint32_t)a);
                                 }
                                 if ((int)cnt >= sup_min)
                                     key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
@@ -189,14 +216,27 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     r_len = cw_wave_shr1(r_len, la);
                     r_sc = cw_wave_shr1(r_sc, sca);
 #pragma unroll
-                    for (uint32_t x = 0; x < 4; ++x) {
+                    for (uint32_t x = 0; x < NW; ++x) {
                         const int lo_ = cw_wave_shr1((int)(uint32_t)r_p[x], (int)(uint32_t)pa[x]);
                         const int hi_ = cw_wave_shr1((int)(uint32_t)(r_p[x] >> 32), (int)(uint32_t)(pa[x] >> 32));
                         r_p[x] = ((unsigned long long)(uint32_t)hi_ << 32) | (uint32_t)lo_;
                     }
+                    r_row = r_row_next;
                 }
                 cw_wave_sync();
+            };
+            const bool fast_path = pres_lds && Nw <= 4u && (n_dirty == 0u || use_delta || far_delta);
+            const unsigned long long _c0 = __builtin_readcyclecounter();
+            if (fast_path) {
+                const uint32_t dm = use_delta ? 1u : far_delta ? 2u : 0u;
+#define CW_CH_CASE(NWV)                                                                                                 \
+                    if (dm == 0u) chain_window(std::integral_constant<uint32_t, NWV>{}, std::integral_constant<uint32_t, 0>{});        \
+                    else if (dm == 1u) chain_window(std::integral_constant<uint32_t, NWV>{}, std::integral_constant<uint32_t, 1>{});   \
+                    else chain_window(std::integral_constant<uint32_t, NWV>{}, std::integral_constant<uint32_t, 2>{});
+                if (Nw == 1u) { CW_CH_CASE(1) } else if (Nw == 2u) { CW_CH_CASE(2) } else if (Nw == 3u) { CW_CH_CASE(3) } else { CW_CH_CASE(4) }
+#undef CW_CH_CASE
             } else
+            /* everything else (deep polishing piles, more dirty sequences than a mask holds, rows that do not fit): from the block in place */
             for (int a = (int)A - 1; a >= 0; --a) {
                 unsigned long long best = 0ull;
                 const uint32_t* pa_row = (const uint32_t*)(P + (uint32_t)a * Np);
@@ -209,16 +249,24 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         if (use_bits) {
                             if (pres_lds) { for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(lpres[(size_t)a * Nw + x] & lpres[(size_t)bb * Nw + x]); }
                             else { for (uint32_t x = 0; x < Nw; ++x) cnt += (uint32_t)__popcll(gpres[(size_t)a * Nw + x] & gpres[(size_t)bb * Nw + x]); }
-                            if (pd_lds) {
-                                for (uint32_t d = 0; d < n_dirty; ++d) {
-                                    const uint32_t pa = lpd[(uint32_t)a * n_dirty + d], pb = lpd[bb * n_dirty + d];
-                                    cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                            if (n_rows) { /* correction rows, in the block */
+                                const uint32_t row_a = growid[a], row_b = growid[bb];
+                                if (row_a != 0xFFu) cnt += gdelta[(size_t)row_a * Ap + bb];
+                                if (row_b != 0xFFu) cnt += gdelta[(size_t)row_b * Ap + (uint32_t)a];
+                            } else if (has_bm) { /* bad masks: the dirty sequences that are out of order at a or at bb */
+                                unsigned long long mm = gbadm[a] | gbadm[bb];
+                                while (mm) {
+                                    const uint32_t d = (uint32_t)__ffsll((long long)mm) - 1u;
+                                    mm &= mm - 1ull;
+                                    const uint32_t sd = gdirty[d];
+                                    const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
                                 }
-                            } else {
+                            } else { /* every dirty sequence */
                                 for (uint32_t d = 0; d < n_dirty; ++d) {
                                     const uint32_t sd = gdirty[d];
-                                    const uint32_t pa = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
-                                    cnt += (pa < pb && pb != CW_NONE16) ? 1u : 0u;
+                                    const uint32_t pa_ = P[(uint32_t)a * Np + sd], pb = P[bb * Np + sd];
+                                    cnt += (pa_ < pb && pb != CW_NONE16) ? 1u : 0u;
                                 }
                             }
                         } else {
@@ -258,6 +306,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                 }
                 cw_wave_sync();
             }
+            if (!fast_path && lane == 0) { atomicAdd(&sc.ctr->prof[53], 1ull); atomicAdd(&sc.ctr->prof[54], __builtin_readcyclecounter() - _c0); }
             /* chain start: longest, then best score, then largest index; a chain needs at least one edge */
             uint32_t m = 0;
             {
@@ -296,7 +345,11 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                    the whole wave -- POA tasks and long single pieces -- follow one by one. */
                 bool over = false;
                 uint32_t q_cnt = 0;
+                unsigned long long t_flush = 0;
+                uint16_t* d_tile = (uint16_t*)(slab + off_csc);                         /* 65 rows x 66 u16 */
+                uint32_t* d_len = (uint32_t*)(slab + off_csc + 65u * CW_CH_TILE_STRIDE * 2u + 4u); /* 64 sequence lengths */
                 auto flush = [&]() {
+                    const unsigned long long _f0 = __builtin_readcyclecounter();
                     const bool e = (uint32_t)lane < q_cnt;
                     const uint32_t e_n = e ? q_n[lane] : 0u, e_mx = e ? q_mx[lane] : 0u;
                     const bool poa = e && e_n > 1u;
@@ -388,6 +441,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     }
                     q_cnt = 0;
                     cw_wave_sync();
+                    t_flush += __builtin_readcyclecounter() - _f0;
                 };
                 for (uint32_t seg0 = 0; seg0 <= m && !over; seg0 += 64) {
                     const uint32_t seg = seg0 + (uint32_t)lane;
@@ -395,24 +449,55 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     const int ca = (valid && seg > 0) ? (int)chain[seg - 1] : -1;
                     const int cb = (valid && seg < m) ? (int)chain[seg] : -1;
                     uint32_t n_mem = 0, mn = 0xFFFFFFFFu, mx = 0, first_seq = 0, first_start = 0, sl = 0;
-                    const uint32_t ra = (uint32_t)(ca >= 0 ? ca : 0) * Np, rb = (uint32_t)(cb >= 0 ? cb : 0) * Np;
-#pragma unroll 8
-                    for (uint32_t s = 0; s < N; ++s) {
-                        /* the loads do not depend on what was counted so far, so they issue ahead of the bookkeeping */
-                        const uint32_t va = P[ra + s], vb = P[rb + s];
-                        if (valid && n_mem < prm.max_msa) {
-                            const uint32_t pa = ca >= 0 ? va : 0u;
-                            const uint32_t pb = cb >= 0 ? vb : 0u;
-                            bool is; uint32_t st, ln;
-                            if (seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
-                            else if (seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
-                            else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
-                            if (is) {
-                                if (n_mem == 0) { first_seq = s; first_start = st; }
-                                n_mem++;
-                                mn = min(mn, ln); mx = max(mx, ln); sl += ln;
+                    /* A lane needs the rows of its two chain anchors, all N sequences of them: read per lane that is two scattered 2-byte loads per
+                       sequence (64 cache lines per instruction).  Instead the 65 rows of this round's chain anchors go through an LDS tile 64
+                       sequences at a time -- a row is one coalesced 128-byte load, lanes = sequences -- and the lanes read their two rows back
+                       column-wise (row stride 33 words: conflict-free).  The tile lies over the chain DP arrays, which are dead by now. */
+                    const int cb63 = cw_lane_value(cb, 63);
+                    for (uint32_t sb = 0; sb < N; sb += 64) {
+                        const uint32_t ns = min(64u, N - sb);
+                        const bool s_in = (uint32_t)lane < ns;
+#pragma unroll 1
+                        for (uint32_t r0 = 0; r0 < 66u; r0 += 33u) { /* 33 loads in flight: the wave has the registers (two waves per SIMD) */
+                            uint32_t v[33];
+#pragma unroll
+                            for (uint32_t q = 0; q < 33u; ++q) {
+                                const uint32_t r = r0 + q;
+                                const int an = r < 64u ? __builtin_amdgcn_readlane(ca, (int)r) : r == 64u ? cb63 : -1; /* row r = left anchor of lane r's segment */
+                                v[q] = (an >= 0 && s_in) ? (uint32_t)P[(uint32_t)an * Np + sb + (uint32_t)lane] : (uint32_t)CW_NONE16;
+                            }
+#pragma unroll
+                            for (uint32_t q = 0; q < 33u; ++q) if (r0 + q < 65u) d_tile[(r0 + q) * CW_CH_TILE_STRIDE + (uint32_t)lane] = (uint16_t)v[q];
+                        }
+                        d_len[lane] = s_in ? b.seq_len[s0 + sb + (uint32_t)lane] : 0u;
+                        cw_wave_sync();
+                        const uint16_t* row_a = d_tile + (uint32_t)lane * CW_CH_TILE_STRIDE;
+                        const uint16_t* row_b = row_a + CW_CH_TILE_STRIDE;
+                        /* One rule for the three kinds of segment, without branches (a branch per kind made every LDS read of the loop wait on its
+                           own): the piece of sequence s runs from pa (0 in front of the first anchor) to pb (the sequence's end behind the last
+                           one; a k-mer starts before the end, so pa < pb there whenever pa is a hit) and exists iff both are hits and pa < pb. */
+                        const bool seg_first = seg == 0u, seg_last = seg == m;
+                        for (uint32_t j0 = 0; j0 < ns; j0 += 8u) {
+                            uint32_t va[8], vb[8], sln[8];
+#pragma unroll
+                            for (uint32_t q = 0; q < 8u; ++q) { va[q] = row_a[j0 + q]; vb[q] = row_b[j0 + q]; sln[q] = d_len[(j0 + q) & 63u]; } /* rows are padded: reading past ns is harmless */
+#pragma unroll
+                            for (uint32_t q = 0; q < 8u; ++q) {
+                                const uint32_t pa = seg_first ? 0u : va[q];
+                                const uint32_t pb = seg_last ? sln[q] : vb[q];
+                                const bool hit_b = seg_last || vb[q] != CW_NONE16;
+                                const bool take = valid && j0 + q < ns && n_mem < prm.max_msa && pa != CW_NONE16 && hit_b && pa < pb;
+                                const uint32_t ln = pb - pa;
+                                const bool fst = take && n_mem == 0u;
+                                first_seq = fst ? sb + j0 + q : first_seq;
+                                first_start = fst ? pa : first_start;
+                                n_mem += take ? 1u : 0u;
+                                mn = take ? min(mn, ln) : mn;
+                                mx = take ? max(mx, ln) : mx;
+                                sl += take ? ln : 0u;
                             }
                         }
+                        cw_wave_sync();
                     }
                     const bool by_anchor = n_mem > 0 && seg > 0 && seg < m && mn == mx && mx <= k; /* all pieces = first mx bases of anchor a */
                     const bool single = n_mem == 1;
@@ -455,6 +540,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     cw_wave_sync();
                 }
                 if (!over && q_cnt) flush();
+                if (lane == 0) atomicAdd(&sc.ctr->prof[49], t_flush);
                 if (over) { new_status = CW_WIN_OVERFLOW; why = CW_WHY_TASKS; }
                 else n_segs_out = m + 1;
             }

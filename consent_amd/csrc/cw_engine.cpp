@@ -100,7 +100,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
-    p.ablock_units = ((uint64_t)n_seqs * (2ull * CW_TMAX + 2 + CW_TMAX / 8) + (uint64_t)n_windows * (CW_TMAX * (4ull + 8 + 8) + 256)) / 16 + 64;
+    p.ablock_units = ((uint64_t)n_seqs * (2ull * CW_TMAX + 2 + CW_TMAX / 8) + (uint64_t)n_windows * (CW_TMAX * (4ull + 8 + 8 + 8) + 256)) / 16 + 64;
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);

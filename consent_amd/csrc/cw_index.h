@@ -41,9 +41,12 @@
 __host__ __device__ __forceinline__ uint32_t cw_ab_np(uint32_t N) { uint32_t Np = (N + 1u) & ~1u; if (((Np >> 1) & 1u) == 0u) Np += 2u; return Np; }
 __host__ __device__ __forceinline__ uint64_t cw_ab_align(uint64_t x) { return (x + 15ull) & ~15ull; }
 #define CW_AB_HDR 64u
-__host__ __device__ __forceinline__ uint64_t cw_ab_bytes(uint32_t A, uint32_t N, uint32_t n_dirty) {
+#define CW_AB_ROWS_MAX 254u /* correction rows (anchors that are out of order in some dirty sequence) a block can carry */
+__host__ __device__ __forceinline__ uint32_t cw_ab_ap(uint32_t A) { return (A + 15u) & ~15u; } /* bytes per correction row */
+__host__ __device__ __forceinline__ uint64_t cw_ab_bytes(uint32_t A, uint32_t N, uint32_t n_dirty, uint32_t n_rows = 0) {
     const uint32_t Np = cw_ab_np(N), Nw = (N + 63u) >> 6;
-    return CW_AB_HDR + cw_ab_align((uint64_t)A * 4) + cw_ab_align((uint64_t)A * Nw * 8) + cw_ab_align((uint64_t)n_dirty * 2) + cw_ab_align((uint64_t)A * Np * 2);
+    return CW_AB_HDR + cw_ab_align((uint64_t)A * 4) + cw_ab_align((uint64_t)A * Nw * 8) + cw_ab_align((uint64_t)n_dirty * 2) + cw_ab_align((uint64_t)A * 8) +
+           (n_rows ? cw_ab_align((uint64_t)A) + (uint64_t)n_rows * cw_ab_ap(A) : 0ull) + cw_ab_align((uint64_t)A * Np * 2);
 }
 
 __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch sc, cw_params prm, uint64_t solid_total_cap,
@@ -586,40 +589,53 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 
         /* A sequence whose anchor positions increase with the anchor index ("clean") satisfies pos(a) < pos(b) for every
            pair a < b it holds, so its contribution to score(a,b) is one bit of presence(a) & presence(b); only the few
-           sequences with an out-of-order (spurious) anchor hit need their positions compared.  Exact, and ~20x cheaper
-           than comparing positions for all N sequences. */
-        uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available) */
+           sequences with an out-of-order (spurious) anchor hit ("dirty") need positions compared -- and of those only the pairs
+           that involve one of the sequence's out-of-order anchors: take away the anchors whose position is not above every
+           earlier one (or, scanning from the end, not below every later one: whichever set is smaller) and what is left of the
+           sequence is increasing again, so it goes into the presence bits like a clean one; the anchors taken away are one bit per
+           dirty sequence in the anchor's "bad" mask, and the chain kernel compares positions for exactly those.  Exact. */
+        uint8_t* clean = (uint8_t*)seen;                               /* N flags (2 KiB available): 1 clean, 0 dirty (forward), 2 dirty (backward); later 0x80 = dirty with masks */
+        uint8_t* didx = clean + 1024;                                  /* sequence -> index in the dirty list (piles of at most 1024 sequences) */
         unsigned long long* pres = (unsigned long long*)(P_lds + (pg ? 0 : (((size_t)(tfit ? nk0 : A) * Np + 3u) & ~(size_t)3u))); /* A x Nw, 8-byte aligned */
         uint16_t* dirty = (uint16_t*)(pres + (size_t)A * Nw);          /* up to N ids */
+        unsigned long long* badm = (unsigned long long*)(lds + (((size_t)((uint8_t*)(dirty + N) - lds) + 7u) & ~(size_t)7u)); /* A masks over the dirty list */
         const bool use_bits = N <= 2048u && ((uint8_t*)(dirty + N) <= lds + CW_IDX_STAGE_OFF);
+        bool has_bm = false, has_delta = false;
+        uint32_t n_rows = 0;
+        uint32_t W = 1;                                                                 /* 64-bit words per mask: dirty sequences / 64 (at most 4) */
+        uint8_t* rowid = (uint8_t*)(badm + (size_t)A * 4);                              /* anchor -> correction row, 0xFF none */
+        uint16_t* rowanc = (uint16_t*)(lds + (((size_t)(rowid + A - lds) + 1u) & ~(size_t)1u)); /* correction row -> anchor */
+        /* one pass of one wave over sequence s's column of the matrix, anchors in ascending (fwd) or descending order: the anchors that do
+           not set a new record.  MARK: set bit d of their masks; else: count them */
+        auto scan_seq = [&](const uint32_t s, const bool fwd, const bool mark, const uint32_t d) -> uint32_t {
+            int run = -1;
+            uint32_t n_bad = 0;
+            for (uint32_t a0 = 0; a0 < A; a0 += 64) {
+                const uint32_t ai = a0 + lane;
+                const uint32_t a = fwd ? ai : A - 1u - ai;
+                const uint32_t pv = ai < A ? PRD(PROW(a) * Np + s) : (uint32_t)CW_NONE16;
+                const int v = pv != CW_NONE16 ? (fwd ? (int)pv : (int)(0xFFFEu - pv)) : -1;
+                const int inc = cw_wave_scan_max(v);
+                int before = cw_wave_shr1(inc, -1);
+                before = max(before, run);
+                const bool bad = v >= 0 && v <= before;
+                if (mark) { if (bad) atomicOr(&badm[(size_t)a * W + (d >> 6)], 1ull << (d & 63u)); }
+                else n_bad += (uint32_t)__popcll(__ballot(bad));
+                run = max(run, cw_lane_value(inc, 63));
+            }
+            return n_bad;
+        };
         if (use_bits) {
             for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
-                int run = -1;
-                bool bad = false;
-                for (uint32_t a0 = 0; a0 < A; a0 += 64) {
-                    const uint32_t a = a0 + lane;
-                    const uint32_t pv = a < A ? PRD(PROW(a) * Np + s) : (uint32_t)CW_NONE16;
-                    const int v = pv != CW_NONE16 ? (int)pv : -1;
-                    const int inc = cw_wave_scan_max(v);
-                    int before = cw_wave_shr1(inc, -1);
-                    before = max(before, run);
-                    bad = bad || (__ballot(v >= 0 && v <= before) != 0ull);
-                    run = max(run, cw_lane_value(inc, 63));
-                }
-                if (lane == 0) clean[s] = bad ? 0 : 1;
+                const uint32_t nf = scan_seq(s, true, false, 0);
+                uint32_t c = 1;
+                if (nf) c = scan_seq(s, false, false, 0) < nf ? 2u : 0u;
+                if (lane == 0) clean[s] = (uint8_t)c;
             }
             if (tid == 0) misc[3] = 0;
             __syncthreads();
-            for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
-                for (uint32_t w = 0; w < Nw; ++w) {
-                    const uint32_t s = w * 64 + lane;
-                    const bool on = s < N && PRD(PROW(a) * Np + s) != CW_NONE16 && clean[s];
-                    const unsigned long long bal = __ballot(on);
-                    if (lane == 0) pres[(size_t)a * Nw + w] = bal;
-                }
-            }
             for (uint32_t s = tid; s < N; s += CW_IDX_THREADS)
-                if (!clean[s]) dirty[atomicAdd(&misc[3], 1u)] = (uint16_t)s;
+                if (clean[s] != 1) dirty[atomicAdd(&misc[3], 1u)] = (uint16_t)s;
             __syncthreads();
             /* the dirty list must not depend on thread timing: sort the few ids (insertion sort by one thread) */
             if (tid == 0) {
@@ -629,6 +645,46 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     uint32_t y = x;
                     while (y > 0 && dirty[y - 1] > v) { dirty[y] = dirty[y - 1]; --y; }
                     dirty[y] = v;
+                }
+            }
+            __syncthreads();
+            const uint32_t nd = misc[3];
+            /* One spurious anchor can make most of a deep pile dirty, so the masks may be up to four words (256 dirty sequences; the index of
+               a dirty sequence is a byte per sequence: piles of at most 1024).  The chain kernel's fallback without correction rows knows
+               one-word masks only: wider ones are used only if the rows can be produced. */
+            W = (nd + 63u) >> 6;
+            if (W == 0u) W = 1u;
+            const bool masks = nd > 0 && nd <= 255u /* a row entry is a byte */ && W <= (N <= 1024u ? 4u : 1u) && (uint8_t*)(rowanc + CW_AB_ROWS_MAX) <= lds + CW_IDX_STAGE_OFF;
+            if (masks) {
+                for (uint32_t i = tid; i < A * W; i += CW_IDX_THREADS) badm[i] = 0ull;
+                __syncthreads();
+                for (uint32_t d = wave; d < nd; d += CW_IDX_WAVES) { const uint32_t s = dirty[d]; scan_seq(s, clean[s] == 0, true, d); }
+                __syncthreads();
+                /* correction rows: the anchors with a non-empty mask, numbered in anchor order */
+                uint32_t ok = 0;
+                if ((uint32_t)tid < A) for (uint32_t x = 0; x < W; ++x) ok |= badm[(size_t)tid * W + x] != 0ull ? 1u : 0u;
+                const uint32_t off = cw_block_exscan(ok, misc + 16, &n_rows);
+                has_delta = n_rows >= 1u && n_rows <= CW_AB_ROWS_MAX && cw_ab_bytes(A, N, nd, n_rows) <= ((uint64_t)wi->ab_cap << 4);
+                has_bm = W == 1u || has_delta;
+                if (has_delta) {
+                    if ((uint32_t)tid < A) rowid[tid] = ok ? (uint8_t)off : (uint8_t)0xFF;
+                    if (ok) rowanc[off] = (uint16_t)tid;
+                } else n_rows = 0;
+                if (has_bm && (uint32_t)tid < nd) { const uint32_t s = dirty[tid]; clean[s] = (uint8_t)0x80u; if (N <= 1024u) didx[s] = (uint8_t)tid; else clean[s] = (uint8_t)(0x80u | (uint32_t)tid); }
+                __syncthreads();
+            }
+            for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
+                for (uint32_t w = 0; w < Nw; ++w) {
+                    const uint32_t s = w * 64 + lane;
+                    const uint32_t c = s < N ? (uint32_t)clean[s] : 0u;
+                    bool good = c == 1u;
+                    if (has_bm && (c & 0x80u)) { /* a dirty sequence counts where it is in order */
+                        const uint32_t d = N <= 1024u ? (uint32_t)didx[s] : (c & 63u);
+                        good = !((badm[(size_t)a * W + (d >> 6)] >> (d & 63u)) & 1ull);
+                    }
+                    const bool on = s < N && PRD(PROW(a) * Np + s) != CW_NONE16 && good;
+                    const unsigned long long bal = __ballot(on);
+                    if (lane == 0) pres[(size_t)a * Nw + w] = bal;
                 }
             }
             __syncthreads();
@@ -642,7 +698,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            window with one wave per window and many windows per CU. */
         {
             uint8_t* blk = sc.ablock + ((size_t)wi->ab_base << 4);
-            if (cw_ab_bytes(A, N, n_dirty) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
+            if (cw_ab_bytes(A, N, n_dirty, n_rows) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
                 if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_MATRIX; sc.ctr->any_overflow = 1; }
                 __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
                 continue;
@@ -651,12 +707,44 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             uint32_t* ckey = (uint32_t*)(blk + CW_AB_HDR);
             unsigned long long* gpres = (unsigned long long*)((uint8_t*)ckey + cw_ab_align((uint64_t)A * 4));
             uint16_t* gdirty = (uint16_t*)((uint8_t*)gpres + cw_ab_align((uint64_t)A * Nw * 8));
-            uint16_t* gP = (uint16_t*)((uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
-            if (tid == 0) { hdr[0] = A; hdr[1] = N; hdr[2] = n_dirty; hdr[3] = use_bits ? 1u : 0u; }
+            unsigned long long* gbadm = (unsigned long long*)((uint8_t*)gdirty + cw_ab_align((uint64_t)n_dirty * 2));
+            uint8_t* growid = (uint8_t*)gbadm + cw_ab_align((uint64_t)A * 8);
+            uint8_t* gdelta = growid + cw_ab_align((uint64_t)A);
+            const uint32_t Ap = cw_ab_ap(A);
+            uint16_t* gP = (uint16_t*)(n_rows ? gdelta + (size_t)n_rows * Ap : growid);
+            if (tid == 0) { hdr[0] = A; hdr[1] = N; hdr[2] = n_dirty; hdr[3] = (use_bits ? 1u : 0u) | (has_bm && W == 1u ? 2u : 0u) | (has_delta ? 4u : 0u); hdr[4] = n_rows; }
             for (uint32_t a = tid; a < A; a += CW_IDX_THREADS) ckey[a] = tkey[cand_tp[a]];
             if (use_bits) {
                 for (uint32_t i = tid; i < A * Nw; i += CW_IDX_THREADS) gpres[i] = pres[i];
                 for (uint32_t i = tid; i < n_dirty; i += CW_IDX_THREADS) gdirty[i] = dirty[i];
+                if (has_bm && W == 1u) for (uint32_t a = tid; a < A; a += CW_IDX_THREADS) gbadm[a] = badm[a];
+                if (has_delta) {
+                    /* Correction row of anchor x: for every other anchor y, how many of the dirty sequences in which x is out of order have
+                       the pair in template order (the smaller anchor in front).  A pair that is out of order at both ends in one sequence is
+                       counted in the row of its smaller anchor only.  The chain kernel adds row(a)[b] + row(b)[a] to the presence count. */
+                    for (uint32_t a = tid; a < A; a += CW_IDX_THREADS) growid[a] = rowid[a];
+                    for (uint32_t r = wave; r < n_rows; r += CW_IDX_WAVES) {
+                        const uint32_t x = rowanc[r];
+                        for (uint32_t y0 = 0; y0 < Ap; y0 += 64) {
+                            const uint32_t y = y0 + lane;
+                            uint32_t cnt = 0;
+                            if (y < A && y != x) {
+                                for (uint32_t wd = 0; wd < W; ++wd) {
+                                    const unsigned long long bmx = badm[(size_t)x * W + wd], bmy = badm[(size_t)y * W + wd];
+                                    unsigned long long mm = y < x ? bmx & ~bmy : bmx;
+                                    while (mm) {
+                                        const uint32_t d = wd * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
+                                        mm &= mm - 1ull;
+                                        const uint32_t sd = dirty[d];
+                                        const uint32_t px = PRD(PROW(x) * Np + sd), py = PRD(PROW(y) * Np + sd);
+                                        cnt += y > x ? ((px < py && py != CW_NONE16) ? 1u : 0u) : (py < px ? 1u : 0u); /* px is a hit: x is out of order in sd */
+                                    }
+                                }
+                            }
+                            if (y < Ap) gdelta[(size_t)r * Ap + y] = (uint8_t)cnt;
+                        }
+                    }
+                }
             }
             {   /* rows are Np (even) u16: copy as u32 pairs, row by row (the rows of the anchors when the matrix is per template k-mer) */
                 const uint32_t* src = (const uint32_t*)(pg ? P_glb : P_lds);
