@@ -381,6 +381,8 @@ def main():
               "Mcycles: stage-in", round(float(prof[48]) / 1e6, 1), "(part of idx.chain) segment flush", round(float(prof[49]) / 1e6, 1), "(part of idx.segments)", file=sys.stderr)
         print("tier L: chunk-rows", int(prof[46]), "rows", int(prof[47]), "fill cycles per chunk-row", float(prof[8 + 5 * 3 + 1]) / max(1, int(prof[46])), file=sys.stderr)
         print("chain kernel: windows with bad masks", int(prof[52]), "with correction rows", int(prof[50]), "rows", int(prof[51]), "windows on the slow path", int(prof[53]), "Mcycles there", round(float(prof[54]) / 1e6, 1), file=sys.stderr)
+        print("index kernel detail, Mcycles:", {n: round(float(prof[i]) / 1e6, 1) for n, i in (("stage+clear", 55), ("count pass", 0), ("export scan", 56), ("export write", 2), ("tplhash", 7), ("support pass", 3),
+              ("candidates", 58), ("P fill", 59), ("clean scan", 60), ("dirty+masks", 61), ("presence", 62), ("hand-over", 4))}, file=sys.stderr)
         print("stage ms", {k: round(v, 2) for k, v in eng.timings().items()}, file=sys.stderr)
         print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
     if rank == 0:

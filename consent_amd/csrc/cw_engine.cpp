@@ -335,6 +335,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     CW_HIP(hipMemsetAsync(base + p.sbusy[1], 0, p.sbusy[4] + (size_t)p.tier[4].slots * 4 - p.sbusy[1], st)); /* every slab free */
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
+    cw_setup_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(db, sc, e->prm);
     cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "index");

@@ -26,6 +26,7 @@
 #define CW_TMAX 1024 /* template k-mer slots */
 #define CW_EX_SLOTS 1024 /* in LDS; a pile that saturates more keys than this is counted again with the table in global memory */
 #define CW_EX_BITS 10
+#define CW_EXP_SLOTS 8 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 /* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
@@ -49,6 +50,19 @@ __host__ __device__ __forceinline__ uint64_t cw_ab_bytes(uint32_t A, uint32_t N,
            (n_rows ? cw_ab_align((uint64_t)A) + (uint64_t)n_rows * cw_ab_ap(A) : 0ull) + cw_ab_align((uint64_t)A * Np * 2);
 }
 
+/* one wave per window: the pile's k-mer count (the sum over its sequences), read coalesced; the single work-group of cw_setup_kernel
+   then only scans per-window numbers (walking the sequences there, one thread per window, took 1.9 ms of a depth-150 batch) */
+__global__ void __launch_bounds__(256) cw_setup_need_kernel(DevBatch b, DevScratch sc, cw_params prm) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= b.n_windows) return;
+    const uint32_t s0 = b.win_first_seq[w], s1 = b.win_first_seq[w + 1];
+    uint32_t nk = 0;
+    for (uint32_t s = s0 + lane; s < s1; s += 64) { const uint32_t l = b.seq_len[s]; nk += l >= prm.k ? l - prm.k + 1 : 0; }
+    nk = (uint32_t)cw_wave_sum((int)nk);
+    if (lane == 0) { WinInfo* wi = &sc.win[w]; wi->n_seqs = s1 - s0; wi->tpl_len = s1 > s0 ? b.seq_len[s0] : 0; wi->n_kmers = nk; }
+}
+
 __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch sc, cw_params prm, uint64_t solid_total_cap,
                                                          uint64_t seg_total_cap, uint64_t arena_total_cap) {
     __shared__ uint32_t part[4][1024];
@@ -61,13 +75,7 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
         uint32_t need_solid = 0, need_seg = 0, need_arena = 0, need_ab = 0;
         uint32_t nk = 0, tl = 0, ns = 0;
         if (w < b.n_windows) {
-            const uint32_t s0 = b.win_first_seq[w], s1 = b.win_first_seq[w + 1];
-            ns = s1 - s0;
-            for (uint32_t s = s0; s < s1; ++s) {
-                uint32_t l = b.seq_len[s];
-                if (l >= prm.k) nk += l - prm.k + 1;
-            }
-            tl = ns ? b.seq_len[s0] : 0;
+            ns = sc.win[w].n_seqs; tl = sc.win[w].tpl_len; nk = sc.win[w].n_kmers; /* cw_setup_need_kernel */
             need_solid = nk / prm.solid + 1;
             need_seg = (tl >= prm.k) ? tl - prm.k + 3 : 1;
             need_arena = 16 * tl + 4096;
@@ -260,6 +268,28 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }                                                                                                           \
         }
 
+/* the same pass, two sequences at a time and one k-mer per thread: the sequences of a pile are copies of one stretch of the genome, so
+   threads that work on the same positions of different sequences update the same counters at the same moment (eight-way with
+   CW_IDX_PASS_BLOCK: most compare-and-swap rounds of the count pass were retries) */
+#define CW_IDX_KMERS1(...)                                                                                              \
+                const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;                                \
+                for (uint32_t p = (uint32_t)tid & 511u; p < nk; p += 512u) {                                            \
+                    const uint32_t wi_ = p >> 4;                                                                        \
+                    uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);               \
+                    x_ <<= 2u * (p & 15u);                                                                              \
+                    const uint32_t key = (uint32_t)(x_ >> (64u - 2u * k));                                              \
+                    __VA_ARGS__                                                                                         \
+                }
+#define CW_IDX_PASS_BLOCK2(...)                                                                                         \
+        for (uint32_t sp = 0; sp < N; sp += 2) {                                                                        \
+            const uint32_t s = sp + ((uint32_t)tid >> 9);                                                               \
+            if (s < N) {                                                                                                \
+                if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS1(__VA_ARGS__) } \
+                else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
+                       const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS1(__VA_ARGS__) }           \
+            }                                                                                                           \
+        }
+
         CW_PROF_T0();
         /* ================= phase A: counts ================= */
         if (!direct) {
@@ -348,7 +378,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in a small hash table (key + 1 in the
            high half, the overflow count in the low half), so that a key's exact count is its nibble, plus its overflow when the nibble is 15 */
 #define CW_IDX_COUNT_PASS(EXTAB, EXSLOTS, EXBITS)                                                                       \
-        CW_IDX_PASS_BLOCK({                                                                                             \
+        CW_IDX_PASS_BLOCK2({                                                                                            \
             const uint32_t wd = key >> 3, sh = (key & 7) * 4;                                                           \
             uint32_t old = tab[wd];                                                                                     \
             bool sat = false;                                                                                           \
@@ -373,6 +403,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
+        CW_PROF(sc.ctr, 55, tid == 0);
         CW_IDX_COUNT_PASS(ex, CW_EX_SLOTS, CW_EX_BITS)
         __syncthreads();
         if (flags[0]) { /* rare (deep polishing piles): everything again, saturated keys into this work-group's global table */
@@ -400,8 +431,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             const uint32_t keys_per_word = n_keys >= 8 ? 8 : n_keys;
             const uint32_t wpt = (nib_words + CW_IDX_THREADS - 1) / CW_IDX_THREADS;
             const uint32_t w_beg = min(nib_words, (uint32_t)tid * wpt), w_cnt = min(nib_words, w_beg + wpt) - w_beg;
-            uint32_t lk[8], lc[8];
-            uint32_t mine = 0;
+            uint32_t lk[CW_EXP_SLOTS]; /* key (18 bits: this is the k <= 9 path) | count << 18; a count that does not pack sends the thread to the re-walk below */
+            bool wide = false;
+            uint32_t mine = 0, n_first = 0xFFFFFFFFu; /* keys found before the rotated walk wrapped to the thread's first word */
             auto ex_lookup = [&](const uint32_t key) -> uint32_t { /* occurrences beyond the 15th */
                 if (big_ex) {
                     uint32_t slot = cw_hash32(key) >> (32 - 18);
@@ -431,7 +463,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     if (nib == 15u) c = 15u + ex_lookup(key); /* exactly 15 occurrences leave no entry */
                     if (c < prm.solid) continue;
 #pragma unroll
-                    for (int z = 0; z < 8; ++z) if ((uint32_t)z == mine) { lk[z] = key; lc[z] = c; }
+                    for (int z = 0; z < CW_EXP_SLOTS; ++z) if ((uint32_t)z == mine) lk[z] = key | (c << 18);
+                    wide = wide || c >= (1u << 14);
                     mine++;
                 }
             };
@@ -440,6 +473,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t nq = w_cnt >> 2, q0 = (uint32_t)tid % nq; /* one division per thread */
                 for (uint32_t i = 0; i < nq; ++i) {
                     uint32_t r = i + q0;
+                    if (r == nq) n_first = mine;
                     r = r >= nq ? r - nq : r;
                     const uint32_t wd = w_beg + 4u * r;
                     const uint4 v4 = *(const uint4*)&tab[wd];
@@ -450,23 +484,29 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t r0 = w_cnt ? (uint32_t)tid % w_cnt : 0u;
                 for (uint32_t i = 0; i < w_cnt; ++i) {
                     uint32_t r = i + r0;
+                    if (r == w_cnt) n_first = mine;
                     r = r >= w_cnt ? r - w_cnt : r;
                     scan_word(tab[w_beg + r], w_beg + r);
                 }
             }
-            if (mine > 8) flags[1] = 1; /* more than the register slots hold: the whole block re-walks in key order */
+            CW_PROF(sc.ctr, 56, tid == 0);
             uint32_t total;
             const uint32_t off = cw_block_exscan(mine, scan_tmp, &total);
             const bool fits = total <= wi->solid_cap;
-            if (fits && flags[1]) {
+            if (n_first > mine) n_first = mine; /* never wrapped */
+            if (fits && (mine > CW_EXP_SLOTS || wide)) { /* more than the register slots hold (deep piles: a few threads per window): this thread walks its words again, in key order */
                 uint32_t o = wi->solid_base + off;
                 for (uint32_t i = 0; i < w_cnt && mine; ++i) {
                     const uint32_t wd = w_beg + i;
                     const uint32_t v = tab[wd];
                     if (v == 0) continue;
-                    for (uint32_t q = 0; q < keys_per_word; ++q) {
+                    uint32_t cand = ((((v & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 4) | (((((v >> 4) & 0x0F0F0F0Fu) + add) & 0x10101010u) >> 3);
+                    if (keys_per_word < 8) cand &= (1u << (8 * ((keys_per_word + 1) / 2))) - 1u;
+                    while (cand) { /* see scan_word */
+                        const uint32_t bpos = (uint32_t)__ffs((int)cand) - 1u;
+                        cand &= cand - 1u;
+                        const uint32_t q = (bpos >> 3) * 2u + (bpos & 1u);
                         const uint32_t nib = (v >> (4 * q)) & 15u;
-                        if (!nib) continue;
                         const uint32_t key = wd * 8 + q;
                         uint32_t c = nib;
                         if (nib == 15u) c = 15u + ex_lookup(key);
@@ -474,14 +514,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     }
                 }
             } else if (fits && mine) {
+                /* found order = the words from the rotation point to the thread's last word, then from its first word: two ascending runs, the
+                   second one below the first */
 #pragma unroll
-                for (int z = 0; z < 8; ++z) {
+                for (int z = 0; z < CW_EXP_SLOTS; ++z) {
                     if ((uint32_t)z < mine) {
-                        uint32_t rank = 0;
-#pragma unroll
-                        for (int y = 0; y < 8; ++y) rank += ((uint32_t)y < mine && lk[y] < lk[z]) ? 1u : 0u;
-                        sc.solid_key[wi->solid_base + off + rank] = lk[z];
-                        sc.solid_cnt[wi->solid_base + off + rank] = lc[z];
+                        const uint32_t pos = (uint32_t)z < n_first ? (uint32_t)z + (mine - n_first) : (uint32_t)z - n_first;
+                        sc.solid_key[wi->solid_base + off + pos] = lk[z] & 0x3FFFFu;
+                        sc.solid_cnt[wi->solid_base + off + pos] = lk[z] >> 18;
                     }
                 }
             }
@@ -517,6 +557,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            table lookup per k-mer) is not needed.  Otherwise the matrix has one row per anchor and is filled by that second pass. */
         const bool tfit = (uint64_t)nk0 * Np * 2 + (uint64_t)nk0 * Nw * 8 + (uint64_t)N * 2 + 16 <= (uint64_t)p_cap * 2;
         if (tfit) for (uint32_t i = tid; i < nk0 * Np; i += CW_IDX_THREADS) P_lds[i] = (uint16_t)CW_NONE16;
+        /* When the matrix per template k-mer does not fit (depth > ~100), the support pass also writes every hit (template k-mer, sequence,
+           position: 10 + 12 + 10 bits) to a list in this work-group's global scratch, and the anchors' rows are filled from the list: the
+           second pass over the pile's k-mers (extraction and a table lookup each, nine in ten for nothing) is only taken when a hit does not
+           pack or the list overflows.  (The scratch is the one of phase A's global exact table, which is exported by now.) */
+        uint32_t* const hitlist = (uint32_t*)(sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS);
+        const uint32_t hit_cap = CW_EXG_SLOTS * 2u;
+        const bool hl = !tfit && N <= 4096u;
+        if (tid == 0) { misc[4] = 0; misc[5] = 0; }
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
         for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; lvl_head[i] = -1; }
         if (tid == 0) lvl_head[CW_TMAX] = -1;
@@ -547,6 +595,10 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 if (old & bit) trep[e] = 1;
                 else atomicAdd(&tsup[e], 1u);
                 if (tfit) P_lds[(uint32_t)e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
+                else if (hl) {
+                    if (p < 1024u) { const uint32_t hi_ = atomicAdd(&misc[4], 1u); if (hi_ < hit_cap) hitlist[hi_] = ((uint32_t)e << 22) | (s << 10) | p; }
+                    else misc[5] = 1;
+                }
             })
             cw_wave_sync();
         }
@@ -564,6 +616,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (ok) { tcand[tid] = (int16_t)off; cand_tp[off] = (uint16_t)tid; }
         }
         __syncthreads();
+        CW_PROF(sc.ctr, 58, tid == 0);
         /* LDS needs: the matrix (A*Np u16) + presence bitsets (A*Nw u64) + dirty list (N u16) */
         const bool pg = !tfit && (uint64_t)A * Np * 2 + (uint64_t)A * Nw * 8 + (uint64_t)N * 2 + 16 > (uint64_t)p_cap * 2;
         if (pg && (uint64_t)A * Np > sc.p_fallback_elems) {
@@ -573,9 +626,20 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         }
 /* matrix row of anchor a */
 #define PROW(a) (tfit ? (uint32_t)cand_tp[a] : (uint32_t)(a))
+        const uint32_t n_hits = misc[4];
+        const bool from_list = hl && n_hits <= hit_cap && misc[5] == 0u;
         if (!tfit) {
             for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the list was written by the other waves of this work-group, through L2 */
             __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (from_list) {
+                for (uint32_t i = tid; i < n_hits; i += CW_IDX_THREADS) {
+                    const uint32_t h = hitlist[i];
+                    const int a = tcand[h >> 22];
+                    if (a >= 0) PWR((uint32_t)a * Np + ((h >> 10) & 4095u), h & 1023u);
+                }
+            } else
             for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
                 CW_IDX_PASS_SEQ({
                     const int e = cw_tpl_lookup(th, tkey, key);
@@ -586,6 +650,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
             __syncthreads();
         }
+        CW_PROF(sc.ctr, 59, tid == 0);
 
         /* A sequence whose anchor positions increase with the anchor index ("clean") satisfies pos(a) < pos(b) for every
            pair a < b it holds, so its contribution to score(a,b) is one bit of presence(a) & presence(b); only the few
@@ -634,6 +699,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
             if (tid == 0) misc[3] = 0;
             __syncthreads();
+            CW_PROF(sc.ctr, 60, tid == 0);
             for (uint32_t s = tid; s < N; s += CW_IDX_THREADS)
                 if (clean[s] != 1) dirty[atomicAdd(&misc[3], 1u)] = (uint16_t)s;
             __syncthreads();
@@ -673,6 +739,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 if (has_bm && (uint32_t)tid < nd) { const uint32_t s = dirty[tid]; clean[s] = (uint8_t)0x80u; if (N <= 1024u) didx[s] = (uint8_t)tid; else clean[s] = (uint8_t)(0x80u | (uint32_t)tid); }
                 __syncthreads();
             }
+            CW_PROF(sc.ctr, 61, tid == 0);
             for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
                 for (uint32_t w = 0; w < Nw; ++w) {
                     const uint32_t s = w * 64 + lane;
@@ -690,6 +757,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             __syncthreads();
         }
         const uint32_t n_dirty = use_bits ? misc[3] : 0u;
+        CW_PROF(sc.ctr, 62, tid == 0);
 
         /* ================= hand-over: the window's anchor block =================
            Chaining is a serial recurrence over the anchors: one wave's work.  Doing it here would idle 15 of this
@@ -772,5 +840,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 #undef CW_IDX_PASS_BLOCK
 #undef CW_IDX_KMERS4
 #undef CW_IDX_KMERS4_WAVE
+#undef CW_IDX_KMERS1
+#undef CW_IDX_PASS_BLOCK2
 
 #endif
