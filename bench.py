@@ -171,16 +171,23 @@ def main():
     stage_ms = {}
     n_over = n_tpl = 0
     t0 = time.perf_counter()
+    host_ms = [0.0, 0.0]
     for i in range(args.steps):
+        _h0 = time.perf_counter()
         engines[i % ne].run_device(batches[(args.warmup + i) % n_batches], rs[i % ne])
+        _h1 = time.perf_counter()
+        host_ms[0] += (_h1 - _h0) * 1e3
         if ne == 1 or i >= args.steps - ne:  # with several engines only their last steps are read (reading waits for the step)
             for k, v in engines[i % ne].timings().items() if ne == 1 else ():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
                 stage_ms.setdefault(k, []).append(v)
+        host_ms[1] += (time.perf_counter() - _h1) * 1e3
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if os.environ.get("CW_PROFILE"):
+        print("host ms per step: enqueue", round(host_ms[0] / args.steps, 3), "wait + read stage timings", round(host_ms[1] / args.steps, 3), file=sys.stderr)
     if ne > 1:
         for k, v in engines[(args.steps - 1) % ne].timings().items():
             stage_ms.setdefault(k, []).append(v)
@@ -383,6 +390,9 @@ def main():
         print("chain kernel: windows with bad masks", int(prof[52]), "with correction rows", int(prof[50]), "rows", int(prof[51]), "windows on the slow path", int(prof[53]), "Mcycles there", round(float(prof[54]) / 1e6, 1), file=sys.stderr)
         print("index kernel detail, Mcycles:", {n: round(float(prof[i]) / 1e6, 1) for n, i in (("stage+clear", 55), ("count pass", 0), ("export scan", 56), ("export write", 2), ("tplhash", 7), ("support pass", 3),
               ("candidates", 58), ("P fill", 59), ("clean scan", 60), ("dirty+masks", 61), ("presence", 62), ("hand-over", 4))}, file=sys.stderr)
+        print("GPU idle between the batch before and this one (wall clock, finish kernel end -> setup kernel start): ms", round(float(prof[57]) * 1e-5, 3), file=sys.stderr)
+        for _k, _v in stage_ms.items():
+            print(f"per-step {_k} ms (HIP events):", [round(v, 2) for v in _v], file=sys.stderr)
         print("stage ms", {k: round(v, 2) for k, v in eng.timings().items()}, file=sys.stderr)
         print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
     if rank == 0:

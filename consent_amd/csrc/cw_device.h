@@ -129,6 +129,7 @@ struct DevScratch {
     uint4* task_dbg;               /* NULL unless CW_TASK_TRACE is set: per task (start, duration) in 1024-cycle units, tier|rc|pass, wave */
     uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
+    unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */

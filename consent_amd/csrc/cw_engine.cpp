@@ -223,6 +223,7 @@ void cw_destroy(cw_engine* e) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (e->xscratch) (void)hipFree(e->xscratch);
+    if (e->step_clock) (void)hipFree(e->step_clock);
     if (e->stitch_scratch) (void)hipFree(e->stitch_scratch);
     if (e->host_fb) (void)hipHostFree(e->host_fb);
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
@@ -262,6 +263,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     e->last_ctr_off = p.ctr;
     int rc = ensure(&e->scratch, &e->scratch_bytes, p.total);
     if (rc) return rc;
+    if (!e->step_clock) { CW_HIP(hipMalloc((void**)&e->step_clock, 16)); CW_HIP(hipMemset(e->step_clock, 0, 16)); }
     uint8_t* base = (uint8_t*)e->scratch;
 
     DevBatch db;
@@ -287,6 +289,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.p_fallback = (uint16_t*)(base + p.pfall); sc.p_fallback_elems = p.pfall_elems;
     sc.ablock = base + p.ablock; sc.ablock_units = p.ablock_units;
     sc.ex_fallback = (unsigned long long*)(base + p.exg);
+    sc.step_clock = e->step_clock;
     sc.task_dbg = getenv("CW_TASK_TRACE") ? (uint4*)(base + p.tdbg) : nullptr;
     e->last_tasks_off = p.tasks; e->last_tdbg_off = p.tdbg; e->last_task_cap = p.task_cap;
     if (sc.task_dbg) CW_HIP(hipMemsetAsync(sc.task_dbg, 0, (size_t)p.task_cap * 16, st));

@@ -45,6 +45,16 @@ struct FinCtx {
     uint32_t s0, N;
 };
 
+/* The key table is in LDS (staged) or in the scratch arena, the visited bitmap in LDS or in the wave's global slot: said with the address
+   space at every access, or the compiler merges the two arms into flat_ loads (LDS data at global-memory latency). */
+typedef __attribute__((address_space(3))) const uint32_t* fin_l32;
+typedef __attribute__((address_space(1))) const uint32_t* fin_g32;
+typedef __attribute__((address_space(3))) const uint16_t* fin_l16;
+typedef __attribute__((address_space(3))) uint32_t* fin_l32w;
+typedef __attribute__((address_space(1))) uint32_t* fin_g32w;
+__device__ __forceinline__ uint32_t fin_skey(const FinCtx& c, uint32_t i) { return c.staged ? ((fin_l32)c.skey)[i] : ((fin_g32)c.skey)[i]; }
+__device__ __forceinline__ uint32_t fin_scnt(const FinCtx& c, uint32_t i) { return c.scnt16 ? (uint32_t)((fin_l16)c.scnt16)[i] : ((fin_g32)c.scnt)[i]; }
+
 __device__ __forceinline__ bool fin_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
 __device__ __forceinline__ uint32_t fin_code(uint8_t c) {
     switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; default: return 3; }
@@ -60,7 +70,7 @@ __device__ __forceinline__ int fin_find(const FinCtx& c, uint32_t key) {
     int lo = 0, hi = (int)c.n_solid - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
-        const uint32_t v = c.skey[mid];
+        const uint32_t v = fin_skey(c, (uint32_t)mid);
         if (v == key) return mid;
         if (v < key) lo = mid + 1; else hi = mid - 1;
     }
@@ -74,13 +84,14 @@ __device__ __forceinline__ int fin_find4(const FinCtx& c, uint32_t key_g, int la
     const int g = lane >> 4, l = lane & 15;
     const uint32_t n = c.n_solid;
     const uint32_t pv = (uint32_t)l * 64u;
-    const bool ge = pv < n && key_g >= c.skey[pv];
+    const fin_l32 sk = (fin_l32)c.skey; /* only called with the table staged */
+    const bool ge = pv < n && key_g >= sk[pv];
     const uint32_t bits = (uint32_t)(__ballot(ge) >> (16 * g)) & 0xFFFFu;
     int mine = -1;
     if (bits) {
         const uint32_t base = ((uint32_t)__popc(bits) - 1u) * 64u + (uint32_t)l * 4u;
         if (base < n) {
-            const uint4 kk = *(const uint4*)(c.skey + base); /* the staging area is padded to a multiple of four words */
+            uint4 kk; kk.x = sk[base]; kk.y = sk[base + 1u]; kk.z = sk[base + 2u]; kk.w = sk[base + 3u]; /* one ds_read_b128: 16-byte aligned */ /* the staging area is padded to a multiple of four words */
             mine = kk.x == key_g ? (int)base : (base + 1 < n && kk.y == key_g) ? (int)base + 1 : (base + 2 < n && kk.z == key_g) ? (int)base + 2
                    : (base + 3 < n && kk.w == key_g) ? (int)base + 3 : -1;
         }
@@ -95,7 +106,7 @@ __device__ __forceinline__ int fin_find4(const FinCtx& c, uint32_t key_g, int la
 __device__ uint32_t fin_count_scan(const FinCtx& c, uint32_t key, int lane);
 __device__ uint32_t fin_count_exact(const FinCtx& c, uint32_t key, int lane) {
     int idx = fin_find(c, key);
-    if (idx >= 0) return c.scnt16 ? (uint32_t)c.scnt16[idx] : c.scnt[idx];
+    if (idx >= 0) return fin_scnt(c, (uint32_t)idx);
     return fin_count_scan(c, key, lane);
 }
 /* a k-mer below the solidity threshold is not in the table: count it in the pile */
@@ -127,13 +138,13 @@ __device__ int fin_neighbours(const FinCtx& c, uint32_t key, int left, uint32_t*
         const int ig = fin_find4(c, cg, lane);
         idx = __shfl(ig, (lane & 3) * 16);
         cand = (uint32_t)__shfl((int)cg, (lane & 3) * 16);
-        if (lane < 4 && idx >= 0) cnt = c.scnt16 ? (uint32_t)c.scnt16[idx] : c.scnt[idx];
+        if (lane < 4 && idx >= 0) cnt = fin_scnt(c, (uint32_t)idx);
         if (lane >= 4) idx = -1;
     } else if (lane < 4) {
         if (!left) cand = ((key << 2) & c.kmask) | (uint32_t)lane;
         else cand = ((uint32_t)(3 - lane) << (2 * (c.k - 1))) | (key >> 2);
         idx = fin_find(c, cand);
-        if (idx >= 0) cnt = c.scnt[idx];
+        if (idx >= 0) cnt = ((fin_g32)c.scnt)[idx];
     }
     const bool ok = lane < 4 && idx >= 0; /* table holds exactly the k-mers with count >= solid */
     const unsigned long long bal = __ballot(ok);
@@ -165,6 +176,7 @@ struct FinLds {
     uint8_t* alt;    /* edit target         */
     uint8_t* path;   /* link() path / extension scratch */
     uint32_t* vis;
+    bool vis_glb;    /* vis is the wave's slot in global memory (deep polishing piles), else LDS */
     uint32_t* f_nbk; /* frames: 4 keys      */
     uint32_t* f_nbi; /*         4 indices   */
     uint32_t* f_meta;/*         n | it<<8 | plen<<16 */
@@ -172,6 +184,10 @@ struct FinLds {
     uint32_t* f_key;
     uint32_t* tmp;   /* 64 words            */
 };
+
+__device__ __forceinline__ uint32_t fin_vis_get(const FinLds& M, uint32_t w) { return M.vis_glb ? ((fin_g32)M.vis)[w] : ((fin_l32)M.vis)[w]; }
+__device__ __forceinline__ void fin_vis_or(const FinLds& M, uint32_t w, uint32_t bits) { if (M.vis_glb) ((fin_g32w)M.vis)[w] |= bits; else ((fin_l32w)M.vis)[w] |= bits; }
+__device__ __forceinline__ void fin_vis_clear(const FinLds& M, uint32_t w) { if (M.vis_glb) ((fin_g32w)M.vis)[w] = 0u; else ((fin_l32w)M.vis)[w] = 0u; }
 
 /*
  * link (DBG.cpp:99-169) without recursion.  path[] starts as the k characters of src; on success returns
@@ -196,11 +212,11 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
             /* ---- linear stretch (DBG.cpp:119-138) ---- */
             while (!found && n == 1 && it < n && dist <= max_len) {
                 const uint32_t ck = nbk[0], ci = nbi[0];
-                const bool seen = (M.vis[ci >> 5] >> (ci & 31)) & 1u;
+                const bool seen = (fin_vis_get(M, ci >> 5) >> (ci & 31)) & 1u;
                 found = (ck == dst);
                 if (!found && !seen) {
                     if (plen + 2 > CW_FIN_CB) return -1;
-                    if (lane == 0) { M.vis[ci >> 5] |= 1u << (ci & 31); M.path[plen] = "ACGT"[ck & 3u]; }
+                    if (lane == 0) { fin_vis_or(M, ci >> 5, 1u << (ci & 31)); M.path[plen] = "ACGT"[ck & 3u]; }
                     plen++; dist++;
                     cw_wave_sync();
                     n = fin_neighbours(c, ck, 0, nbk, nbi, lane);
@@ -223,13 +239,13 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
             bool descended = false;
             while (!found && n > 1 && it < n && dist <= max_len) {
                 const uint32_t ck = nbk[it], ci = nbi[it];
-                const bool seen = (M.vis[ci >> 5] >> (ci & 31)) & 1u;
+                const bool seen = (fin_vis_get(M, ci >> 5) >> (ci & 31)) & 1u;
                 found = (ck == dst);
                 if (!found && !seen) {
                     if (depth + 1 >= CW_FIN_FRAMES || plen + 2 > CW_FIN_CB) return -1;
                     branches++;
                     if (lane == 0) {
-                        M.vis[ci >> 5] |= 1u << (ci & 31);
+                        fin_vis_or(M, ci >> 5, 1u << (ci & 31));
                         for (int q = 0; q < 4; ++q) { M.f_nbk[depth * 4 + q] = nbk[q]; M.f_nbi[depth * 4 + q] = nbi[q]; }
                         M.f_meta[depth] = (uint32_t)n | ((uint32_t)it << 8) | (plen << 16);
                         M.f_dist[depth] = dist; M.f_key[depth] = cur;
@@ -317,8 +333,8 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
                 const int is = fin_find4(c, ksg, lane), id = fin_find4(c, kdg, lane);
                 for (int q = 0; q < 4; ++q) {
                     const int iq = __builtin_amdgcn_readlane(is, q * 16), jq = __builtin_amdgcn_readlane(id, q * 16);
-                    cs[q] = iq >= 0 ? (c.scnt16 ? (uint32_t)c.scnt16[iq] : c.scnt[iq]) : fin_count_scan(c, ks[q], lane);
-                    cd[q] = jq >= 0 ? (c.scnt16 ? (uint32_t)c.scnt16[jq] : c.scnt[jq]) : fin_count_scan(c, kd[q], lane);
+                    cs[q] = iq >= 0 ? fin_scnt(c, (uint32_t)iq) : fin_count_scan(c, ks[q], lane);
+                    cd[q] = jq >= 0 ? fin_scnt(c, (uint32_t)jq) : fin_count_scan(c, kd[q], lane);
                 }
             } else {
                 for (int q = 0; q < 4; ++q) { cs[q] = fin_count_exact(c, ks[q], lane); cd[q] = fin_count_exact(c, kd[q], lane); }
@@ -426,7 +442,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
     uint8_t* buf0 = slab; uint8_t* buf1 = slab + CW_FIN_CB;
     M.path = slab + 2 * CW_FIN_CB;
     uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CW_FIN_CB);
-    M.vis = vis_lds;
+    M.vis = vis_lds; M.vis_glb = false;
     M.f_nbk = vis_lds + CW_FIN_VIS_WORDS;
     M.f_nbi = M.f_nbk + CW_FIN_FRAMES * 4;
     M.f_meta = M.f_nbi + CW_FIN_FRAMES * 4;
@@ -479,7 +495,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
             /* the visited bitmap of link(): in LDS for up to 32768 solid k-mers (every correction pile); the piles of assembly polishing are
                as deep as the coverage and can hold more: then this wave's slot in global memory */
             const bool vis_glb = wi.n_solid > 32u * CW_FIN_VIS_WORDS;
-            M.vis = vis_glb ? sc.fin_vis + (size_t)(blockIdx.x * CW_FIN_WAVES + wave) * sc.fin_vis_words : vis_lds;
+            M.vis = vis_glb ? sc.fin_vis + (size_t)(blockIdx.x * CW_FIN_WAVES + wave) * sc.fin_vis_words : vis_lds; M.vis_glb = vis_glb;
             if (bad || wi.n_solid > 32u * sc.fin_vis_words) { status = CW_WIN_OVERFLOW; why = bad ? CW_WHY_FIN_LEN : CW_WHY_FIN_SOLID; }
             else {
                 len = (int)total;
@@ -515,7 +531,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                     }
                     cw_wave_sync();
                     { uint8_t* sw = M.s; M.s = M.alt; M.alt = sw; }
-                    for (uint32_t q = lane; q < (wi.n_solid + 31) / 32; q += 64) M.vis[q] = 0;
+                    for (uint32_t q = lane; q < (wi.n_solid + 31) / 32; q += 64) fin_vis_clear(M, q);
                     cw_wave_sync();
                     len = fin_polish(c, M, (uint32_t)len, lane);
                     if (len < 0) { status = CW_WIN_OVERFLOW; why = CW_WHY_FIN_POLISH; len = 0; }
@@ -544,6 +560,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
         }
         cw_wave_sync();
     }
+    if (lane == 0) atomicMax(sc.step_clock, (unsigned long long)wall_clock64()); /* when this batch ended (see cw_setup_need_kernel) */
 }
 
 #endif

@@ -20,6 +20,8 @@
 
 #include "cw_device.h"
 
+typedef __attribute__((address_space(3))) const uint32_t* cw_l32; /* a pile's words staged in LDS ... */
+typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or where the batch has them */
 #define CW_IDX_THREADS 1024
 #define CW_IDX_WAVES 16
 #define CW_IDX_LDS_BYTES 163840
@@ -55,6 +57,7 @@ __host__ __device__ __forceinline__ uint64_t cw_ab_bytes(uint32_t A, uint32_t N,
 __global__ void __launch_bounds__(256) cw_setup_need_kernel(DevBatch b, DevScratch sc, cw_params prm) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[57] = wall_clock64() - sc.step_clock[0]; /* 10 ns units since the batch before ended */
     if (w >= b.n_windows) return;
     const uint32_t s0 = b.win_first_seq[w], s1 = b.win_first_seq[w + 1];
     uint32_t nk = 0;
@@ -190,8 +193,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
        (high-identity deep piles: every template k-mer is an anchor).  Accessors pick the address space with a
        block-uniform branch so that the common case keeps ds_ instructions. */
     uint16_t* const P_glb = sc.p_fallback + (size_t)blockIdx.x * sc.p_fallback_elems;
-#define PRD(i) (pg ? (uint32_t)P_glb[i] : (uint32_t)P_lds[i])
-#define PWR(i, v) do { if (pg) P_glb[i] = (uint16_t)(v); else P_lds[i] = (uint16_t)(v); } while (0)
+    /* (address spaces said explicitly: otherwise the two arms are merged into flat_ accesses, LDS data at global-memory latency) */
+    typedef __attribute__((address_space(3))) uint16_t* cw_l16w;
+    typedef __attribute__((address_space(1))) uint16_t* cw_g16w;
+#define PRD(i) (pg ? (uint32_t)((cw_g16w)P_glb)[i] : (uint32_t)((cw_l16w)P_lds)[i])
+#define PWR(i, v) do { if (pg) ((cw_g16w)P_glb)[i] = (uint16_t)(v); else ((cw_l16w)P_lds)[i] = (uint16_t)(v); } while (0)
 
     for (;;) {
         __syncthreads();
@@ -240,9 +246,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     }                                                                                                   \
                 }
 #define CW_IDX_PASS_SEQ(...)                                                                                            \
-        if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS4_WAVE(__VA_ARGS__) } \
+        if (stw) { const uint32_t len = s_len[s]; const cw_l32 words = (cw_l32)(s_words + s_off[s]); CW_IDX_KMERS4_WAVE(__VA_ARGS__) } \
         else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                                 \
-               const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS4_WAVE(__VA_ARGS__) }
+               const cw_g32 words = (cw_g32)(b.bases + b.seq_word_off[s0 + s]); CW_IDX_KMERS4_WAVE(__VA_ARGS__) }
 /* one pass over the pile, work-group wide: eight sequences at a time, 128 threads each, four consecutive k-mers per thread out of one
    64-bit window of the packed bases; BODY sees s, p and key (a `continue` in BODY goes to the next k-mer) */
 #define CW_IDX_KMERS4(...)                                                                                              \
@@ -262,9 +268,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t sp = 0; sp < N; sp += 8) {                                                                        \
             const uint32_t s = sp + ((uint32_t)tid >> 7);                                                               \
             if (s < N) {                                                                                                \
-                if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS4(__VA_ARGS__) } \
+                if (stw) { const uint32_t len = s_len[s]; const cw_l32 words = (cw_l32)(s_words + s_off[s]); CW_IDX_KMERS4(__VA_ARGS__) } \
                 else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
-                       const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS4(__VA_ARGS__) }           \
+                       const cw_g32 words = (cw_g32)(b.bases + b.seq_word_off[s0 + s]); CW_IDX_KMERS4(__VA_ARGS__) }           \
             }                                                                                                           \
         }
 
@@ -284,9 +290,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         for (uint32_t sp = 0; sp < N; sp += 2) {                                                                        \
             const uint32_t s = sp + ((uint32_t)tid >> 9);                                                               \
             if (s < N) {                                                                                                \
-                if (stw) { const uint32_t len = s_len[s]; const uint32_t* words = s_words + s_off[s]; CW_IDX_KMERS1(__VA_ARGS__) } \
+                if (stw) { const uint32_t len = s_len[s]; const cw_l32 words = (cw_l32)(s_words + s_off[s]); CW_IDX_KMERS1(__VA_ARGS__) } \
                 else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
-                       const uint32_t* words = b.bases + b.seq_word_off[s0 + s]; CW_IDX_KMERS1(__VA_ARGS__) }           \
+                       const cw_g32 words = (cw_g32)(b.bases + b.seq_word_off[s0 + s]); CW_IDX_KMERS1(__VA_ARGS__) }           \
             }                                                                                                           \
         }
 

@@ -41,6 +41,7 @@ struct cw_engine {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     cw_slot slot[CW_SLOTS];
+    unsigned long long* step_clock = nullptr; /* see DevScratch */
     void* xscratch = nullptr; /* pile-extraction scratch */
     size_t xscratch_bytes = 0;
     void* stitch_scratch = nullptr; /* banded-traceback directions of cw_stitch_device, per wave */

@@ -20,7 +20,7 @@ n_win = 16384
 eng = ca.Engine(ca.Params(9, 4, 8, 2, msa))
 lib = eng.lib
 dev = torch.device("cuda", 0)
-spec = ca.SynthSpec.pacbio(n_win, depth)
+spec = ca.SynthSpec.pacbio(n_win, depth, first_window=int(os.environ.get("CW_TRACE_BATCH", "0")) * n_win)  # CW_TRACE_BATCH: which of bench.py's batches
 ns, nw = C.c_uint32(), C.c_uint64()
 lib.cw_synth_sizes(C.byref(spec), C.byref(ns), C.byref(nw))
 t = [torch.zeros(n_win + 1, dtype=torch.int32, device=dev), torch.zeros(ns.value, dtype=torch.int32, device=dev), torch.zeros(ns.value, dtype=torch.int64, device=dev),
