@@ -405,12 +405,60 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 slot = (slot + 1) & ((EXSLOTS) - 1);                                                                    \
             }                                                                                                           \
         })
+        /* First attempt: the thread that takes a key's counter from 14 to 15 enters the key into the LDS hash table (count 0), and every
+           later occurrence only appends the key to a list in this work-group's global scratch; after the pass the list is added up with
+           all threads busy, one lookup and one fire-and-forget add per entry.  (Counting the later occurrences in the table as they came
+           -- a compare-and-swap and an add per occurrence, a fifth of the lanes active, the probe loop as long as its slowest lane -- was
+           70 % of the count pass of a depth-150 pile.)  If the table or the list overflows, the pass is redone the old way with the table
+           in global memory. */
+        uint32_t* const ovl = (uint32_t*)exg;
+        const uint32_t ovl_cap = CW_EXG_SLOTS * 2u;
         for (uint32_t i = tid; i < nib_words; i += CW_IDX_THREADS) tab[i] = 0;
         for (uint32_t i = tid; i < CW_EX_SLOTS; i += CW_IDX_THREADS) ex[i] = 0ull;
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
         CW_PROF(sc.ctr, 55, tid == 0);
-        CW_IDX_COUNT_PASS(ex, CW_EX_SLOTS, CW_EX_BITS)
+        CW_IDX_PASS_BLOCK2({
+            const uint32_t wd = key >> 3, sh = (key & 7) * 4;
+            uint32_t old = tab[wd];
+            bool sat = false;
+            for (;;) {
+                if (((old >> sh) & 15u) == 15u) { sat = true; break; }
+                uint32_t prev = atomicCAS(&tab[wd], old, old + (1u << sh));
+                if (prev == old) break;
+                old = prev;
+            }
+            if (sat) { /* flags[2]: the list's cursor */
+                const uint32_t oi = atomicAdd(&flags[2], 1u);
+                if (oi < ovl_cap) ovl[oi] = key;
+                continue;
+            }
+            if (((old >> sh) & 15u) != 14u) continue;
+            uint32_t slot = cw_hash32(key) >> (32 - CW_EX_BITS); /* this increment was the fifteenth: the key's entry */
+            const unsigned long long fresh = (unsigned long long)(key + 1) << 32;
+            for (uint32_t probe = 0;; ++probe) {
+                if (probe >= CW_EX_SLOTS) { flags[0] = 1; break; }
+                if (atomicCAS(&ex[slot], 0ull, fresh) == 0ull) break;
+                slot = (slot + 1) & (CW_EX_SLOTS - 1);
+            }
+        })
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the list: global memory written and read by this work-group only (one CU, one L1) */
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (flags[2] > ovl_cap) flags[0] = 1; /* every thread stores the same value */
+        __syncthreads();
+        if (!flags[0]) {
+            const uint32_t n_ovl = flags[2];
+            for (uint32_t i = tid; i < n_ovl; i += CW_IDX_THREADS) {
+                const uint32_t key = ovl[i];
+                uint32_t slot = cw_hash32(key) >> (32 - CW_EX_BITS), probe = 0;
+                while ((uint32_t)(ex[slot] >> 32) != key + 1 && probe < CW_EX_SLOTS) { slot = (slot + 1) & (CW_EX_SLOTS - 1); ++probe; } /* it is there: entered before the list got the key */
+                if (probe < CW_EX_SLOTS) atomicAdd(&ex[slot], 1ull);
+                else flags[3] = 1; /* cannot happen; if it does, the old way decides */
+            }
+        }
+        __syncthreads();
+        if (flags[3]) flags[0] = 1;
         __syncthreads();
         if (flags[0]) { /* rare (deep polishing piles): everything again, saturated keys into this work-group's global table */
             __syncthreads(); /* everybody has read the flag before it is cleared */
@@ -636,9 +684,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const bool from_list = hl && n_hits <= hit_cap && misc[5] == 0u;
         if (!tfit) {
             for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the list was written by the other waves of this work-group, through L2 */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the list was written by the other waves of this work-group (same CU, same L1) */
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (from_list) {
                 for (uint32_t i = tid; i < n_hits; i += CW_IDX_THREADS) {
                     const uint32_t h = hitlist[i];
