@@ -636,24 +636,49 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         }
         __syncthreads();
         CW_PROF(sc.ctr, 7, tid == 0);
-        /* support + repeat detection: one wave per sequence */
+        /* support + repeat detection: one wave per sequence, four consecutive k-mers per lane out of one 64-bit window of the packed bases.  The
+           first probes of the four template-table lookups are requested together (nine in ten end there: not a template k-mer), then the hits
+           are settled one by one. */
+        auto support_seq = [&](auto words, const uint32_t len, const uint32_t s, uint32_t* my_seen) {
+            const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;
+            for (uint32_t p0 = (uint32_t)lane * 4u; p0 < nk; p0 += 256u) {
+                const uint32_t wi_ = p0 >> 4;
+                uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);
+                x_ <<= 2u * (p0 & 15u);
+                uint32_t key4[4], slot4[4], e1[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) { key4[q] = (uint32_t)(x_ >> (64u - 2u * k)); slot4[q] = cw_hash32(key4[q]) >> (32 - 11); }
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) e1[q] = p0 + q < nk ? th[slot4[q]] : 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    uint32_t ee = e1[q], slot = slot4[q];
+                    int e = -1;
+                    while (ee != 0u) { /* cw_tpl_lookup from its second step on */
+                        if (tkey[ee - 1] == key4[q]) { e = (int)ee - 1; break; }
+                        slot = (slot + 1) & (CW_TH_SLOTS - 1);
+                        ee = th[slot];
+                    }
+                    if (e < 0) continue;
+                    const uint32_t p = p0 + q;
+                    const uint32_t bit = 1u << (e & 31);
+                    const uint32_t old = atomicOr(&my_seen[e >> 5], bit);
+                    if (old & bit) trep[e] = 1;
+                    else atomicAdd(&tsup[e], 1u);
+                    if (tfit) P_lds[(uint32_t)e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
+                    else if (hl) {
+                        if (p < 1024u) { const uint32_t hi_ = atomicAdd(&misc[4], 1u); if (hi_ < hit_cap) hitlist[hi_] = ((uint32_t)e << 22) | (s << 10) | p; }
+                        else misc[5] = 1;
+                    }
+                }
+            }
+        };
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
             uint32_t* my_seen = seen + wave * 32;
             if (lane < 32) my_seen[lane] = 0;
             cw_wave_sync();
-            CW_IDX_PASS_SEQ({
-                const int e = cw_tpl_lookup(th, tkey, key);
-                if (e < 0) continue;
-                const uint32_t bit = 1u << (e & 31);
-                const uint32_t old = atomicOr(&my_seen[e >> 5], bit);
-                if (old & bit) trep[e] = 1;
-                else atomicAdd(&tsup[e], 1u);
-                if (tfit) P_lds[(uint32_t)e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
-                else if (hl) {
-                    if (p < 1024u) { const uint32_t hi_ = atomicAdd(&misc[4], 1u); if (hi_ < hit_cap) hitlist[hi_] = ((uint32_t)e << 22) | (s << 10) | p; }
-                    else misc[5] = 1;
-                }
-            })
+            if (stw) support_seq((cw_l32)(s_words + s_off[s]), s_len[s], s, my_seen);
+            else support_seq((cw_g32)(b.bases + b.seq_word_off[s0 + s]), stm ? s_len[s] : b.seq_len[s0 + s], s, my_seen);
             cw_wave_sync();
         }
         __syncthreads();
