@@ -216,10 +216,14 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
 }
 
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
-    /* one instantiation for every query length (chunks beyond the query are skipped by a scalar branch): with 4-, 8- and 16-chunk
-       variants side by side the 8-chunk one returned garbage rows on gfx950 (ROCm 7.2 hipcc), each of them alone is correct --
-       tests/test_gpu_stitch.py::test_stitch_long_consensuses_use_the_wide_sweeps keeps an eye on it */
-    return st_sweep_pk<CW_ST_QMAX / 128>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
+    /* Two instantiations: eight chunks for consensuses up to 1024 positions (every 500-base window), sixteen beyond; chunks beyond the
+       query are skipped by a scalar branch.  Round 1 had 4-, 8- and 16-chunk variants side by side and the 8-chunk one returned garbage
+       rows on gfx950 (ROCm 7.2 hipcc), each of them alone being correct; this pair is clean (tests/test_gpu_stitch.py::
+       test_stitch_long_consensuses_use_the_wide_sweeps, tools/fuzz_pipeline.py) and brings the kernel from 260 to 256 VGPRs, i.e. from
+       one to two waves per SIMD */
+    m = st_uni(m);
+    if (m <= 1024) return st_sweep_pk<8>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    return st_sweep_pk<CW_ST_QMAX / 128>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 }
 
 /* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
