@@ -55,7 +55,7 @@ struct DevBuf {
     int ensure(size_t bytes) {
         if (bytes <= cap) return CW_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        const size_t want = bytes + bytes / 8 + 256;
+        const size_t want = bytes + bytes / 2 + 256; /* half again: a regrowth is a hipFree + hipMalloc, both of which wait for the device (and for the other worker's kernels on it) */
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return CW_E_NOMEM; }
         cap = want;
         return CW_OK;
@@ -69,6 +69,7 @@ struct Shared {
     const cw_read_index* index = nullptr;
     cw_read_set host_reads{};
     uint64_t read_words = 0;
+    double t_start = 0; /* now_ms() when the run began (inspection output) */
     bool do_trim = true;
     bool skip_on_capacity = false;
     /* job queue (producer -> workers) */
@@ -303,6 +304,8 @@ struct Worker {
         j.ms_extract = t1 - t0; j.ms_consensus = t2 - t1; j.ms_stitch = t4 - t2;
         windows += n_win; reads += n_piles; jobs++;
         ms_extract += j.ms_extract; ms_consensus += j.ms_consensus; ms_stitch += j.ms_stitch;
+        if (const char* tv = getenv("CW_DRIVER_TIMING")) if (tv[0] == '2') /* inspection: when each job's phases ran, per worker */
+            fprintf(stderr, "[job %llu] worker %p windows %u: start %.1f extract %.1f consensus %.1f stitch %.1f ms\n", (unsigned long long)j.seq, (void*)this, n_win, t0 - sh.t_start, t1 - t0, t2 - t1, t4 - t2);
     }
 };
 
@@ -378,6 +381,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     const double t_begin = now_ms();
     Shared sh;
     sh.a = a;
+    sh.t_start = now_ms();
     const bool has_proof = a->proof_file && a->proof_file[0];
     sh.do_trim = !a->polishing && !has_proof; /* CONSENT-correction.cpp:17,69-73; CONSENT-polishing.cpp:19 */
     if (const char* oc = getenv("CW_ON_CAPACITY")) sh.skip_on_capacity = strcmp(oc, "skip") == 0;

@@ -142,6 +142,35 @@ def test_high_identity_deep_piles_use_the_global_anchor_matrix(engines):
     assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:3])
 
 
+def test_out_of_order_anchors_in_most_of_a_deep_pile(engines):
+    """Round 2's chain scoring: sequences with an out-of-order anchor stay in the presence bits except at those anchors, whose pairs come
+    from correction rows.  Here two unique stretches of the window are exchanged in most sequences (150 dirty sequences: masks of three
+    words, a handful of rows), in a few (masks of one word), and shifted as a block (dozens of out-of-order anchors per sequence: more
+    rows than fit LDS, read from the block); plus 1000-base windows at depth 110, whose hit positions do not pack into the hit list."""
+    rng = random.Random(29)
+    truth = rand_seq(rng, 1100)
+    t500 = truth[:500]
+
+    def swapped(s, a, b, n):
+        return s[:a] + s[b : b + n] + s[a + n : b] + s[a : a + n] + s[b + n :]
+
+    def block_moved(s, a, b, n):  # the stretch s[a:a+n] taken out and put in again at b
+        rest = s[:a] + s[a + n :]
+        return rest[:b] + s[a : a + n] + rest[b:]
+
+    piles = [
+        [t500] + [mutate(rng, swapped(t500, 100, 330, 24), 0.03) for _ in range(150)],
+        [t500] + [mutate(rng, t500, 0.06) for _ in range(90)] + [mutate(rng, swapped(t500, 60, 400, 30), 0.04) for _ in range(12)],
+        [t500] + [mutate(rng, t500, 0.05) for _ in range(70)] + [mutate(rng, block_moved(t500, 80, 300, 90), 0.03) for _ in range(40)],
+        [truth[:1000]] + [mutate(rng, truth[:1000], 0.08) for _ in range(110)],
+    ]
+    prm = (9, 4, 8, 2, 150)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=4)
+    assert_same(got, exp, len(piles), "out-of-order anchors")
+
+
 def test_pile_layout_in_memory_does_not_matter(engines):
     """The index kernel stages a pile in LDS when its sequences lie front to back in `bases`; any other layout (here: sequences stored
     in reverse order, with gaps) takes the global-memory path and must give the same results."""

@@ -133,7 +133,7 @@ def main():
                 "-r", fa, "-M", "150", "-p", "x"]
     for rep in range(args.reps):
         t0 = time.perf_counter()
-        out = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, CW_DRIVER_STATS="1", CW_DRIVER_TIMING="1", CW_ON_CAPACITY="skip"))
+        out = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, CW_DRIVER_STATS="1", CW_DRIVER_TIMING=os.environ.get("CW_DRIVER_TIMING", "1"), CW_ON_CAPACITY="skip"))
         wall = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-2000:]
     st = json.loads([l for l in out.stderr.splitlines() if l.startswith("{")][-1])
