@@ -115,10 +115,10 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
 int ensure(void** ptr, size_t* have, size_t need) {
     if (*have >= need) return CW_OK;
     if (*ptr) { if (hipFree(*ptr) != hipSuccess) return CW_E_NO_DEVICE; *ptr = nullptr; *have = 0; }
-    /* a quarter more than asked for: hipFree + hipMalloc of a multi-gigabyte arena wait for the device and take up to seconds with a second
+    /* a quarter more than asked for (bounded): hipFree + hipMalloc of a multi-gigabyte arena wait for the device and take up to seconds with a second
        engine at work on it, and the batches of a run differ by a few percent (the native driver's jobs: one regrowth instead of one per
        larger job -- the difference between 1.7 and 3-4 s for the E. coli-scale set) */
-    size_t want = need + need / 4;
+    size_t want = need + (need / 4 < ((size_t)1 << 30) ? need / 4 : ((size_t)1 << 30)); /* at most 1 GiB on top: several engines share a device */
     if (hipMalloc(ptr, want) != hipSuccess) {
         (void)hipGetLastError();
         want = need;

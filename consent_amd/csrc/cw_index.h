@@ -28,7 +28,7 @@ typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or wher
 #define CW_TMAX 1024 /* template k-mer slots */
 #define CW_EX_SLOTS 1024 /* in LDS; a pile that saturates more keys than this is counted again with the table in global memory */
 #define CW_EX_BITS 10
-#define CW_EXP_SLOTS 8 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
+#define CW_EXP_SLOTS 12 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 /* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
@@ -782,17 +782,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             for (uint32_t s = tid; s < N; s += CW_IDX_THREADS)
                 if (clean[s] != 1) dirty[atomicAdd(&misc[3], 1u)] = (uint16_t)s;
             __syncthreads();
-            /* the dirty list must not depend on thread timing: sort the few ids (insertion sort by one thread) */
-            if (tid == 0) {
-                const uint32_t nd = misc[3];
-                for (uint32_t x = 1; x < nd; ++x) {
-                    const uint16_t v = dirty[x];
-                    uint32_t y = x;
-                    while (y > 0 && dirty[y - 1] > v) { dirty[y] = dirty[y - 1]; --y; }
-                    dirty[y] = v;
-                }
-            }
-            __syncthreads();
+            /* (the order of the dirty list depends on thread timing and nothing else depends on it: every use is a sum or a bit per entry) */
             const uint32_t nd = misc[3];
             /* One spurious anchor can make most of a deep pile dirty, so the masks may be up to four words (256 dirty sequences; the index of
                a dirty sequence is a byte per sequence: piles of at most 1024).  The chain kernel's fallback without correction rows knows
