@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const uint32_t s0 = b.win_first_seq[w];
         const uint32_t N = wi->n_seqs;
         const uint32_t L0 = wi->tpl_len;
+        /* read once: a store to the solid table may alias *wi as far as the compiler knows, and every use inside a store loop would be a
+           dependent global load (the export's write loop: 24 of them per thread, ~50 k cycles per window) */
+        const uint32_t w_solid_base = wi->solid_base, w_solid_cap = wi->solid_cap, w_ab_cap = wi->ab_cap, w_ab_base = wi->ab_base, w_n_kmers = wi->n_kmers;
         /* stage the pile (see CW_IDX_STAGE_OFF): stm = lengths and offsets are in LDS, stw = the words too */
         const bool stm = N <= CW_IDX_STAGE_N;
         bool stw = false;
@@ -305,7 +308,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                slice; at the end the slice is bitonic-sorted by key in LDS. ---- */
             unsigned long long* hs_tab = (unsigned long long*)lds; /* 16384 slots = 128 KiB */
             const uint32_t HS = 16384u;
-            const uint32_t P_ = (wi->n_kmers + HS / 2 - 1) / (HS / 2) ? (wi->n_kmers + HS / 2 - 1) / (HS / 2) : 1u;
+            const uint32_t P_ = (w_n_kmers + HS / 2 - 1) / (HS / 2) ? (w_n_kmers + HS / 2 - 1) / (HS / 2) : 1u;
             uint32_t written = 0;
             bool fits = true;
             if (tid < 8) flags[tid] = 0;
@@ -330,9 +333,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) mine += ((uint32_t)hs_tab[i] >= prm.solid) ? 1u : 0u;
                 uint32_t total;
                 const uint32_t off = cw_block_exscan(mine, scan_tmp, &total);
-                if (written + total > wi->solid_cap || flags[0]) fits = false;
+                if (written + total > w_solid_cap || flags[0]) fits = false;
                 if (fits && mine) {
-                    uint32_t o = wi->solid_base + written + off;
+                    uint32_t o = w_solid_base + written + off;
                     for (uint32_t i = tid; i < HS; i += CW_IDX_THREADS) {
                         const unsigned long long e = hs_tab[i];
                         if ((uint32_t)e >= prm.solid) { sc.solid_key[o] = (uint32_t)(e >> 32); sc.solid_cnt[o] = (uint32_t)e; o++; }
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (!fits) continue;
             if (written > 1) {
                 for (uint32_t x = tid; x < np2; x += CW_IDX_THREADS)
-                    hs_tab[x] = x < written ? (((unsigned long long)sc.solid_key[wi->solid_base + x] << 32) | sc.solid_cnt[wi->solid_base + x]) : ~0ull;
+                    hs_tab[x] = x < written ? (((unsigned long long)sc.solid_key[w_solid_base + x] << 32) | sc.solid_cnt[w_solid_base + x]) : ~0ull;
                 __syncthreads();
                 for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
                     for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -370,8 +373,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     }
                 }
                 for (uint32_t x = tid; x < written; x += CW_IDX_THREADS) {
-                    sc.solid_key[wi->solid_base + x] = (uint32_t)(hs_tab[x] >> 32);
-                    sc.solid_cnt[wi->solid_base + x] = (uint32_t)hs_tab[x];
+                    sc.solid_key[w_solid_base + x] = (uint32_t)(hs_tab[x] >> 32);
+                    sc.solid_cnt[w_solid_base + x] = (uint32_t)hs_tab[x];
                 }
                 __syncthreads();
             }
@@ -546,10 +549,10 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             CW_PROF(sc.ctr, 56, tid == 0);
             uint32_t total;
             const uint32_t off = cw_block_exscan(mine, scan_tmp, &total);
-            const bool fits = total <= wi->solid_cap;
+            const bool fits = total <= w_solid_cap;
             if (n_first > mine) n_first = mine; /* never wrapped */
             if (fits && (mine > CW_EXP_SLOTS || wide)) { /* more than the register slots hold (deep piles: a few threads per window): this thread walks its words again, in key order */
-                uint32_t o = wi->solid_base + off;
+                uint32_t o = w_solid_base + off;
                 for (uint32_t i = 0; i < w_cnt && mine; ++i) {
                     const uint32_t wd = w_beg + i;
                     const uint32_t v = tab[wd];
@@ -574,8 +577,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 for (int z = 0; z < CW_EXP_SLOTS; ++z) {
                     if ((uint32_t)z < mine) {
                         const uint32_t pos = (uint32_t)z < n_first ? (uint32_t)z + (mine - n_first) : (uint32_t)z - n_first;
-                        sc.solid_key[wi->solid_base + off + pos] = lk[z] & 0x3FFFFu;
-                        sc.solid_cnt[wi->solid_base + off + pos] = lk[z] >> 18;
+                        sc.solid_key[w_solid_base + off + pos] = lk[z] & 0x3FFFFu;
+                        sc.solid_cnt[w_solid_base + off + pos] = lk[z] >> 18;
                     }
                 }
             }
@@ -799,7 +802,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 uint32_t ok = 0;
                 if ((uint32_t)tid < A) for (uint32_t x = 0; x < W; ++x) ok |= badm[(size_t)tid * W + x] != 0ull ? 1u : 0u;
                 const uint32_t off = cw_block_exscan(ok, misc + 16, &n_rows);
-                has_delta = n_rows >= 1u && n_rows <= CW_AB_ROWS_MAX && cw_ab_bytes(A, N, nd, n_rows) <= ((uint64_t)wi->ab_cap << 4);
+                has_delta = n_rows >= 1u && n_rows <= CW_AB_ROWS_MAX && cw_ab_bytes(A, N, nd, n_rows) <= ((uint64_t)w_ab_cap << 4);
                 has_bm = W == 1u || has_delta;
                 if (has_delta) {
                     if ((uint32_t)tid < A) rowid[tid] = ok ? (uint8_t)off : (uint8_t)0xFF;
@@ -834,8 +837,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            presence bitsets, the dirty list and the position matrix go to HBM/L2 and cw_chain_kernel finishes the
            window with one wave per window and many windows per CU. */
         {
-            uint8_t* blk = sc.ablock + ((size_t)wi->ab_base << 4);
-            if (cw_ab_bytes(A, N, n_dirty, n_rows) > ((uint64_t)wi->ab_cap << 4)) { /* cannot happen: sized from the template length */
+            uint8_t* blk = sc.ablock + ((size_t)w_ab_base << 4);
+            if (cw_ab_bytes(A, N, n_dirty, n_rows) > ((uint64_t)w_ab_cap << 4)) { /* cannot happen: sized from the template length */
                 if (tid == 0) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_MATRIX; sc.ctr->any_overflow = 1; }
                 __builtin_amdgcn_wave_barrier(); /* the wave meets again before the back edge (see cw_stitch.h) */
                 continue;
