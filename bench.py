@@ -24,6 +24,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Must be in the environment before the HIP runtime starts (i.e. before torch is imported): HIP multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4).  Two engines have eight kernel streams (main + three tier streams each); with four
+# queues a stream of the second engine lands behind the first engine's long-running tier-L kernel and the batches do not overlap.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WORKLOADS = {
     # name: (depth, maxMSA, windows per step per GPU)
@@ -80,7 +84,8 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "1")), help="engines per GPU taking the steps in turn (each has its own scratch and streams)")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "2")),
+                    help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
     ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
 
@@ -174,13 +179,17 @@ def main():
     host_ms = [0.0, 0.0]
     for i in range(args.steps):
         _h0 = time.perf_counter()
+        if ne > 1 and i >= ne:  # HIP events of this engine's previous step (step i - ne: done or nearly so, step i - 1 keeps the GPU busy meanwhile)
+            for k, v in engines[i % ne].timings().items():
+                stage_ms.setdefault(k, []).append(v)
+        _h2 = time.perf_counter()
         engines[i % ne].run_device(batches[(args.warmup + i) % n_batches], rs[i % ne])
         _h1 = time.perf_counter()
-        host_ms[0] += (_h1 - _h0) * 1e3
-        if ne == 1 or i >= args.steps - ne:  # with several engines only their last steps are read (reading waits for the step)
-            for k, v in engines[i % ne].timings().items() if ne == 1 else ():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
+        host_ms[0] += (_h1 - _h2) * 1e3
+        if ne == 1:
+            for k, v in engines[0].timings().items():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
                 stage_ms.setdefault(k, []).append(v)
-        host_ms[1] += (time.perf_counter() - _h1) * 1e3
+        host_ms[1] += (time.perf_counter() - _h1 + _h2 - _h0) * 1e3
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -189,19 +198,21 @@ def main():
     if os.environ.get("CW_PROFILE"):
         print("host ms per step: enqueue", round(host_ms[0] / args.steps, 3), "wait + read stage timings", round(host_ms[1] / args.steps, 3), file=sys.stderr)
     if ne > 1:
-        for k, v in engines[(args.steps - 1) % ne].timings().items():
-            stage_ms.setdefault(k, []).append(v)
+        for j in range(max(0, args.steps - ne), args.steps):  # the last step of every engine
+            for k, v in engines[j % ne].timings().items():
+                stage_ms.setdefault(k, []).append(v)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     last = (args.warmup + args.steps - 1) % n_batches
-    status = t_stat.cpu().numpy()
+    r_last = ([(t_cons, t_clen, t_stat, t_solid, t_slen)] + keep_r)[(args.steps - 1) % ne]  # the result arrays the last step wrote
+    status = r_last[2].cpu().numpy()
     n_over = int((status == ca.WIN_OVERFLOW).sum())
     n_tpl = int((status == ca.WIN_TEMPLATE).sum())
-    clen = t_clen.cpu().numpy()
-    slen = t_slen.cpu().numpy()
+    clen = r_last[1].cpu().numpy()
+    slen = r_last[4].cpu().numpy()
     seq_len = keep[last][1].cpu().numpy()
     alg_bytes = algorithmic_bytes(seq_len, n_win, clen, slen)
     stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
@@ -237,6 +248,8 @@ def main():
             "windows_per_step_per_gpu": n_win,
             "distinct_windows_per_run": n_win * world * min(args.steps, max(1, n_batches - args.warmup)),
             "sharding": "windows by rank, no collective",
+            "engines_per_gpu": ne,
+            "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "overflow_windows": n_over,
             "template_fallback_windows": n_tpl,
         },

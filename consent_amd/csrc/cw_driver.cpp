@@ -385,6 +385,11 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     const bool has_proof = a->proof_file && a->proof_file[0];
     sh.do_trim = !a->polishing && !has_proof; /* CONSENT-correction.cpp:17,69-73; CONSENT-polishing.cpp:19 */
     if (const char* oc = getenv("CW_ON_CAPACITY")) sh.skip_on_capacity = strcmp(oc, "skip") == 0;
+    /* HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime starts.  Two
+       workers per device have a dozen kernel and copy streams; with four queues one worker's stream lands behind the other's
+       long-running tier-L kernel (E. coli-scale run: 1.68-2.84 s with 4 queues, 1.57-1.58 s with 12).  No effect if the caller's
+       process has already started HIP; never overrides the caller's own setting. */
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
 
     /* ---- indexReads (+ the proof file into the same index) ---- */
     cw_read_index* index = nullptr;
