@@ -28,6 +28,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <cctype>
 #include <cstdio>
@@ -70,41 +72,150 @@ bool parse_int(const std::string& tok, long* out) {
     return true;
 }
 
-struct PafLine {
-    std::string q_name, t_name;
+/* One PAF line as the pile reader needs it: numbers parsed, names as spans of the mapped file, the target already looked up.
+ * kind: 0 = an overlap, 1 = a blank line, 2 = malformed (reported when the reader reaches it, as a sequential parse would). */
+struct PafRec {
+    const char* q_name;
+    uint32_t q_name_len;
+    int32_t t_id;         /* index of the target name in the read index, -1 = unknown name */
     uint32_t q_len, q_start, q_end, strand, t_len, t_start, t_end, res_matches;
-    bool operator<(const PafLine& o) const { return res_matches < o.res_matches; } /* Overlap.h:90-96 */
+    uint32_t kind;
+    bool operator<(const PafRec& o) const { return res_matches < o.res_matches; } /* Overlap.h:90-96 */
 };
 
-bool parse_paf(const std::string& line, PafLine* o) {
-    std::string tok[12];
-    size_t p = 0;
-    for (int f = 0; f < 12; ++f) {
-        if (p > line.size()) return false;
-        const size_t e = line.find('\t', p);
-        tok[f] = line.substr(p, e == std::string::npos ? std::string::npos : e - p);
-        p = e == std::string::npos ? line.size() + 1 : e + 1;
+/* std::stoi as the reference uses it (strtol: leading blanks, optional sign, digits; anything after is ignored; no digits = error)
+ * on a token of the mapped file, which is not NUL-terminated */
+bool parse_int_span(const char* b, const char* e, long* out) {
+    char buf[64];
+    const size_t n = (size_t)(e - b);
+    if (n >= 1 && n <= 9) {                      /* the usual token: nothing but digits (same value as strtol gives) */
+        long v = 0;
+        size_t i = 0;
+        for (; i < n && (unsigned)(b[i] - '0') <= 9u; ++i) v = v * 10 + (b[i] - '0');
+        if (i == n) { *out = v; return true; }
     }
-    long v[10];
-    const int num[10] = {1, 2, 3, 6, 7, 8, 9, 10, 11, 0};
+    if (n < sizeof buf) {
+        memcpy(buf, b, n);
+        buf[n] = 0;
+        char* end = nullptr;
+        const long v = strtol(buf, &end, 10);
+        if (end == buf) return false;
+        *out = v;
+        return true;
+    }
+    return parse_int(std::string(b, e), out);
+}
+
+/* Overlap(std::string) (src/Overlap.h:26-58): twelve tab-separated fields; ends made inclusive (:39, :49) */
+void parse_paf_line(const char* b, const char* e, const cw_read_index* idx, PafRec* o) {
+    o->kind = 2;
+    const char* tb[12];
+    const char* te[12];
+    const char* p = b;
+    for (int f = 0; f < 12; ++f) {
+        if (p > e) return;                       /* fewer than twelve fields */
+        const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
+        tb[f] = p; te[f] = t ? t : e;
+        p = t ? t + 1 : e + 1;
+    }
+    long v[9];
+    const int num[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
     for (int i = 0; i < 9; ++i)
-        if (!parse_int(tok[num[i]], &v[i])) return false;
-    o->q_name = tok[0]; o->t_name = tok[5];
-    o->q_len = (uint32_t)v[0]; o->q_start = (uint32_t)v[1]; o->q_end = (uint32_t)(v[2] - 1);   /* Overlap.h:39 */
-    o->strand = tok[4] == "+" ? 0u : 1u;
-    o->t_len = (uint32_t)v[3]; o->t_start = (uint32_t)v[4]; o->t_end = (uint32_t)(v[5] - 1);   /* Overlap.h:49 */
+        if (!parse_int_span(tb[num[i]], te[num[i]], &v[i])) return;
+    o->q_name = tb[0]; o->q_name_len = (uint32_t)(te[0] - tb[0]);
+    o->q_len = (uint32_t)v[0]; o->q_start = (uint32_t)v[1]; o->q_end = (uint32_t)(v[2] - 1);
+    o->strand = (te[4] - tb[4] == 1 && *tb[4] == '+') ? 0u : 1u;
+    o->t_len = (uint32_t)v[3]; o->t_start = (uint32_t)v[4]; o->t_end = (uint32_t)(v[5] - 1);
     o->res_matches = (uint32_t)v[6];
-    return true;
+    auto it = idx->by_name.find(std::string(tb[5], te[5]));
+    o->t_id = it == idx->by_name.end() ? -1 : (int32_t)it->second;
+    o->kind = 0;
 }
 
 } // namespace
 
+/* The PAF is mapped and cut into blocks at line ends; parser threads take blocks in file order and stay at most `window` blocks
+ * ahead of the reader, which walks the parsed records strictly in file order (so piles, blank-line handling and the place where a
+ * malformed line is reported are those of a sequential getline loop). */
 struct cw_paf_reader {
-    std::ifstream f;
-    const cw_read_index* idx;
-    uint32_t max_support;
-    bool bad, has_pending;
-    std::string pending;
+    const cw_read_index* idx = nullptr;
+    uint32_t max_support = 0;
+    bool bad = false;
+    const char* data = nullptr;
+    size_t size = 0;
+    bool mapped = false;
+    std::string owned;                       /* the whole input when it cannot be mapped (a pipe) */
+    std::vector<size_t> cut;                 /* block b = [cut[b], cut[b+1]) */
+    std::vector<std::vector<PafRec>> blocks;
+    std::vector<char> ready;
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_ready, cv_room;
+    size_t next_block = 0, consumed = 0, window = 4;
+    bool stop = false, failed = false;
+    size_t cur_block = 0, cur_rec = 0;       /* reader position */
+    std::vector<PafRec> pile;
+
+    void parse_block(size_t b, std::vector<PafRec>& out) const {
+        const char* p = data + cut[b];
+        const char* end = data + cut[b + 1];
+        out.reserve((size_t)(end - p) / 48 + 4);
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* le = nl ? nl : end;      /* a last line without a newline simply ends */
+            PafRec r{};
+            if (le == p) r.kind = 1;
+            else parse_paf_line(p, le, idx, &r);
+            out.push_back(r);
+            p = nl ? nl + 1 : end;
+        }
+    }
+    void parser_main() {
+        for (;;) {
+            size_t b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_room.wait(lk, [&] { return stop || next_block >= blocks.size() || next_block < consumed + window; });
+                if (stop || next_block >= blocks.size()) return;
+                b = next_block++;
+            }
+            std::vector<PafRec> recs;
+            bool ok = true;
+            try { parse_block(b, recs); } catch (...) { ok = false; }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                blocks[b].swap(recs);
+                ready[b] = 1;
+                if (!ok) failed = true;
+            }
+            cv_ready.notify_all();
+        }
+    }
+    /* the next record in file order, or nullptr at the end of the file */
+    const PafRec* peek() {
+        for (;;) {
+            if (cur_block >= blocks.size()) return nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_ready.wait(lk, [&] { return ready[cur_block] != 0; });
+                if (failed) throw std::bad_alloc();
+            }
+            if (cur_rec < blocks[cur_block].size()) return &blocks[cur_block][cur_rec];
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                std::vector<PafRec>().swap(blocks[cur_block]);
+                consumed = ++cur_block;
+                cur_rec = 0;
+            }
+            cv_room.notify_all();
+        }
+    }
+    ~cw_paf_reader() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_room.notify_all();
+        for (auto& t : threads) t.join();
+        if (mapped && data) munmap((void*)data, size);
+    }
 };
 
 extern "C" {
@@ -264,9 +375,50 @@ int cw_paf_open(const char* path, const cw_read_index* idx, uint32_t max_support
     *out = nullptr;
     cw_paf_reader* r = new (std::nothrow) cw_paf_reader();
     if (!r) return CW_E_NOMEM;
-    r->f.open(path);
-    if (!r->f) { delete r; return CW_E_INVALID; }
-    r->idx = idx; r->max_support = max_support; r->bad = false; r->has_pending = false;
+    r->idx = idx; r->max_support = max_support;
+    try {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { delete r; return CW_E_INVALID; }
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            r->size = (size_t)st.st_size;
+            if (r->size) {
+                void* m = mmap(nullptr, r->size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { close(fd); delete r; return CW_E_INVALID; }
+                (void)madvise(m, r->size, MADV_SEQUENTIAL);
+                r->data = (const char*)m; r->mapped = true;
+            }
+        } else {                                  /* a pipe or a device: read it to its end */
+            char buf[1 << 16];
+            ssize_t k;
+            while ((k = read(fd, buf, sizeof buf)) > 0) r->owned.append(buf, (size_t)k);
+            r->data = r->owned.data(); r->size = r->owned.size();
+        }
+        close(fd);
+        /* blocks of ~4 MiB, cut after a newline */
+        size_t block = 4u << 20;
+        if (const char* env = getenv("CW_PAF_BLOCK")) { const long v = atol(env); if (v >= 64) block = (size_t)v; }
+        r->cut.push_back(0);
+        while (r->cut.back() < r->size) {
+            size_t e = r->cut.back() + block;
+            if (e >= r->size) e = r->size;
+            else {
+                const char* nl = (const char*)memchr(r->data + e, '\n', r->size - e);
+                e = nl ? (size_t)(nl - r->data) + 1 : r->size;
+            }
+            r->cut.push_back(e);
+        }
+        const size_t nb = r->cut.size() - 1;
+        r->blocks.resize(nb);
+        r->ready.assign(nb, 0);
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt > 8) nt = 8;
+        if (const char* env = getenv("CW_HOST_THREADS")) { const int v = atoi(env); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+        if (nt < 1) nt = 1;
+        if (nt > nb) nt = (unsigned)nb;
+        r->window = 2 * (size_t)nt + 1;
+        for (unsigned t = 0; t < nt; ++t) r->threads.emplace_back([r] { r->parser_main(); });
+    } catch (...) { delete r; return CW_E_NOMEM; }
     *out = r;
     return CW_OK;
 }
@@ -279,34 +431,30 @@ int cw_paf_next_pile(cw_paf_reader* r, uint32_t* tpl_read, uint32_t* tpl_len, cw
     *n = 0;
     if (r->bad) return CW_E_INVALID;
     try {
-        std::vector<PafLine> cur;
-        std::string line;
-        PafLine al;
-        /* One line of look-ahead instead of the reference's seekg(-len-1): the same piles for any file whose lines end in a
+        std::vector<PafRec>& cur = r->pile;
+        cur.clear();
+        /* One record of look-ahead instead of the reference's seekg(-len-1): the same piles for any file whose lines end in a
            newline.  A blank line closes the current pile and is skipped (the reference returns an empty pile there and its
            driver asks again, CONSENT-correction.cpp:88-91). */
         for (;;) {
-            if (r->has_pending) { line.swap(r->pending); r->has_pending = false; }
-            else {
-                line.clear();
-                if (!std::getline(r->f, line) && line.empty()) break;
-            }
-            if (line.empty()) { if (!cur.empty()) break; else continue; }
-            if (!parse_paf(line, &al)) { r->bad = true; return CW_E_INVALID; }
-            if (cur.empty() || al.q_name == cur[0].q_name) cur.push_back(al);
-            else { r->pending.swap(line); r->has_pending = true; break; }
+            const PafRec* al = r->peek();
+            if (!al) break;
+            if (al->kind == 1) { ++r->cur_rec; if (!cur.empty()) break; else continue; }
+            if (al->kind == 2) { r->bad = true; return CW_E_INVALID; }
+            if (cur.empty() || (al->q_name_len == cur[0].q_name_len && memcmp(al->q_name, cur[0].q_name, al->q_name_len) == 0)) { cur.push_back(*al); ++r->cur_rec; }
+            else break;
         }
         if (cur.empty()) return CW_OK; /* end of the stream */
         std::sort(cur.rbegin(), cur.rend());                   /* alignmentPiles.cpp:43 / :53 */
         if (cur.size() > r->max_support) cur.resize(r->max_support);
-        const int32_t q = cw_read_index_find(r->idx, cur[0].q_name.c_str());
+        const int32_t q = cw_read_index_find(r->idx, std::string(cur[0].q_name, cur[0].q_name_len).c_str());
         if (q < 0) { r->bad = true; return CW_E_INVALID; }
         *tpl_read = (uint32_t)q;
         if (tpl_len) *tpl_len = cur[0].q_len;
         *n = (uint32_t)cur.size();
         if (cur.size() > cap || !out) return CW_E_CAPACITY;  /* the pile is consumed: size the buffer for max_support */
         for (size_t i = 0; i < cur.size(); ++i) {
-            const int32_t t = cw_read_index_find(r->idx, cur[i].t_name.c_str());
+            const int32_t t = cur[i].t_id;
             if (t < 0) { r->bad = true; return CW_E_INVALID; }
             /* the reference clamps target coordinates with the PAF's tLength (alignmentWindows.cpp:121-129) and slices the indexed read;
                downstream (cw_extract_piles_device) there is only the indexed length, so a PAF that disagrees with the read file is

@@ -86,9 +86,14 @@ def write_paf(path, rng, names, lens, n_piles, blank_lines=False):
     return rows
 
 
+@pytest.mark.parametrize("block", [0, 64, 700])
 @pytest.mark.parametrize("max_support,blank", [(150, False), (7, False), (150, True), (1, False)])
-def test_paf_piles_match_reference(tmp_path, max_support, blank):
+def test_paf_piles_match_reference(tmp_path, monkeypatch, max_support, blank, block):
+    """block > 0: the mapped file is cut into blocks of that many bytes (piles straddle them) parsed by five threads ahead of the reader"""
     r = need_ref()
+    if block:
+        monkeypatch.setenv("CW_PAF_BLOCK", str(block))
+        monkeypatch.setenv("CW_HOST_THREADS", "5")
     rng = random.Random(5 + max_support)
     fa = str(tmp_path / "reads.fa")
     names, seqs = write_reads(fa, rng, 12)
@@ -125,6 +130,24 @@ def test_paf_errors_are_loud(tmp_path):
     open(short, "w").write("a\t10\t0\t5\t+\tb\n")
     with pytest.raises(ca.EngineError):
         list(ca.PafReader(short, ix))
+    # a malformed line is reported when the reader reaches it, not earlier: the piles before it are delivered (blocks parsed ahead)
+    late = str(tmp_path / "late.paf")
+    good = "a\t10\t0\t5\t+\tb\t10\t0\t5\t5\t5\t60\n"
+    open(late, "w").write(good + good.replace("a\t10", "b\t10", 1).replace("\tb\t", "\ta\t") + "a\tx\n" + good)
+    os.environ["CW_PAF_BLOCK"] = "64"
+    try:
+        it = iter(ca.PafReader(late, ix))
+        assert ix.names[next(it)[0]] == "a"
+        with pytest.raises(ca.EngineError):  # pile "b" ends at the malformed line: a sequential getline loop fails there too
+            next(it)
+    finally:
+        del os.environ["CW_PAF_BLOCK"]
+    empty = str(tmp_path / "empty.paf")
+    open(empty, "w").write("")
+    assert list(ca.PafReader(empty, ix)) == []
+    nonl = str(tmp_path / "nonl.paf")
+    open(nonl, "w").write(good.rstrip("\n"))
+    assert len(list(ca.PafReader(nonl, ix))) == 1
     with pytest.raises(ca.EngineError):
         ca.ReadIndex(str(tmp_path / "missing.fa"))
 
