@@ -177,13 +177,29 @@ def main():
     n_over = n_tpl = 0
     t0 = time.perf_counter()
     host_ms = [0.0, 0.0]
+    ran = [0] * ne  # steps handed to each engine
+    e_last = 0
     for i in range(args.steps):
         _h0 = time.perf_counter()
-        if ne > 1 and i >= ne:  # HIP events of this engine's previous step (step i - ne: done or nearly so, step i - 1 keeps the GPU busy meanwhile)
-            for k, v in engines[i % ne].timings().items():
-                stage_ms.setdefault(k, []).append(v)
+        if ne == 1:
+            k_ = 0
+        else:  # the engine that is free takes the step (an engine still in a long tier-L tail does not hold up the others)
+            k_ = None
+            while k_ is None:
+                for c_ in range(ne):
+                    c2 = (e_last + 1 + c_) % ne
+                    if engines[c2].idle():
+                        k_ = c2
+                        break
+                else:
+                    time.sleep(5e-5)
+            if ran[k_]:  # HIP events of that engine's previous step (complete: no wait)
+                for k, v in engines[k_].timings().items():
+                    stage_ms.setdefault(k, []).append(v)
         _h2 = time.perf_counter()
-        engines[i % ne].run_device(batches[(args.warmup + i) % n_batches], rs[i % ne])
+        engines[k_].run_device(batches[(args.warmup + i) % n_batches], rs[k_])
+        e_last = k_
+        ran[k_] += 1
         _h1 = time.perf_counter()
         host_ms[0] += (_h1 - _h2) * 1e3
         if ne == 1:
@@ -198,16 +214,17 @@ def main():
     if os.environ.get("CW_PROFILE"):
         print("host ms per step: enqueue", round(host_ms[0] / args.steps, 3), "wait + read stage timings", round(host_ms[1] / args.steps, 3), file=sys.stderr)
     if ne > 1:
-        for j in range(max(0, args.steps - ne), args.steps):  # the last step of every engine
-            for k, v in engines[j % ne].timings().items():
-                stage_ms.setdefault(k, []).append(v)
+        for c_ in range(ne):  # the last step of every engine
+            if ran[c_]:
+                for k, v in engines[c_].timings().items():
+                    stage_ms.setdefault(k, []).append(v)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     last = (args.warmup + args.steps - 1) % n_batches
-    r_last = ([(t_cons, t_clen, t_stat, t_solid, t_slen)] + keep_r)[(args.steps - 1) % ne]  # the result arrays the last step wrote
+    r_last = ([(t_cons, t_clen, t_stat, t_solid, t_slen)] + keep_r)[e_last]  # the result arrays the last step wrote
     status = r_last[2].cpu().numpy()
     n_over = int((status == ca.WIN_OVERFLOW).sum())
     n_tpl = int((status == ca.WIN_TEMPLATE).sum())

@@ -362,7 +362,21 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
-    cw_sort_tier_kernel<<<4, 1024, CW_SORT_LDS_CLS, st>>>(sc); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
+    auto knob_u = [](const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) { const char* v = getenv(name); if (!v) return dflt; const long x = atol(v); return x >= (long)lo && x <= (long)hi ? (uint32_t)x : dflt; };
+    /* Launch shapes chosen for two batches in flight on one GPU (two engines, or the driver's two workers): while the other batch's
+       persistent tier kernels hold the LDS of every CU, a work-group that needs most of a CU waits for tens of milliseconds in the
+       middle of this batch's chain (rocprofv3 timeline, depth 150: tier sort 0.45 -> 13-34 ms, tier Q 8.7 -> 55-94 ms with tier S
+       queued behind it, the two overflow passes 0.05 -> 12-32 ms).  So: the sort keeps 16 KB of classes in LDS instead of 128 (the
+       rest are recomputed), tier Q runs as two-wave work-groups (38 KB; the same 8 waves per CU when it has the machine to itself),
+       and the overflow passes -- normally a handful of tasks -- are 64 / 16 work-groups instead of two per CU.  Alone on the GPU the
+       step time is unchanged. */
+    const uint32_t sort_lds = knob_u("CW_SORT_LDS", 16384, 0, CW_SORT_LDS_CLS);
+    const uint32_t q_waves = knob_u("CW_Q_WAVES", 2, 1, CW_POAQ_WAVES);          /* waves per tier-Q work-group (four tasks per wave) */
+    const uint32_t q_grid = (uint32_t)cus * CW_POAQ_WAVES / q_waves;
+    const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64, 1, (uint32_t)cus * 2);
+    const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
+    const uint32_t big_wgs = knob_u("CW_BIG_WGS", big_cap < 16 ? big_cap : 16, 1, big_cap);
+    cw_sort_tier_kernel<<<4, 1024, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     const char* ph_env = getenv("CW_PHASES");
@@ -371,7 +385,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (phases == 2) {
         /* experiment: tier Q, then S + M1 + M2 side by side, then tier L alone with every hand-over already on its list */
         sid = stage_begin(e, st, "poa_q");
-        cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, st>>>(db, sc);
+        cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, st>>>(db, sc);
         stage_end(e, st, sid);
         CW_HIP(hipEventRecord(e->ev_fork, st));
         for (int i = 0; i < 2; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
@@ -409,7 +423,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     hipStream_t ms = e->stream;
     if (ms != st) CW_HIP(hipStreamWaitEvent(ms, e->ev_fork, 0));
     sid = stage_begin(e, ms, "poa_q");
-    cw_poa_q_kernel<<<(uint32_t)cus, 64 * CW_POAQ_WAVES, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES, ms>>>(db, sc); /* four tasks per wave, one work-group per CU */
+    cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, ms>>>(db, sc); /* four tasks per wave, one work-group per CU */
     stage_end(e, ms, sid);
     sid = stage_begin(e, ms, "poa");
     cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, ms>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
@@ -419,8 +433,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
     sid = stage_begin(e, st, "poa_overflow");
-    cw_poa_slab_kernel<L_ARGS, 1><<<(uint32_t)cus * 2, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
-    cw_poa_big_kernel<<<p.tier[4].slots / CW_POA_WAVES, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
+    cw_poa_slab_kernel<L_ARGS, 1><<<pass1_wgs, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
+    cw_poa_big_kernel<<<big_wgs, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "finish");
     {
@@ -448,6 +462,18 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     if (!e) return CW_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     return run_device_locked(e, batch, res, hip_stream);
+}
+
+int cw_poll(cw_engine* e) {
+    if (!e) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->timings_valid) return 1;
+    if (hipSetDevice(e->device) != hipSuccess) return CW_E_NO_DEVICE;
+    const hipError_t q = hipEventQuery(e->ev_end);
+    if (q == hipSuccess) return 1;
+    if (q == hipErrorNotReady) return 0;
+    (void)hipGetLastError();
+    return CW_E_NO_DEVICE;
 }
 
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages) {

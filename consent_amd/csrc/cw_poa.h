@@ -1135,10 +1135,10 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t l
     }
     return (CW_SORT_CLASSES - 1) - (c < CW_SORT_CLASSES ? c : CW_SORT_CLASSES - 1); /* class 0 = the largest */
 }
-__global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
+__global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint32_t lds_cls) {
     __shared__ uint32_t cnt[16][CW_SORT_CLASSES];
     __shared__ uint32_t tot_c[CW_SORT_CLASSES];
-    extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* CW_SORT_LDS_CLS bytes */
+    extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* lds_cls bytes (<= CW_SORT_LDS_CLS) */
     const int tier = blockIdx.x == 3 ? 0 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list */
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
             if (ti[j] != 0xFFFFFFFFu) {
                 const uint32_t c = cw_sort_class(nm[j].x, nm[j].y, tier);
                 atomicAdd(&cnt[wave][c], 1u);
-                if (x < CW_SORT_LDS_CLS) cls_lds[x] = (uint8_t)c;
+                if (x < lds_cls) cls_lds[x] = (uint8_t)c;
             }
         }
     }
@@ -1184,7 +1184,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc) {
             const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane;
             if (ti[j] != 0xFFFFFFFFu) {
                 uint32_t c;
-                if (x < CW_SORT_LDS_CLS) c = cls_lds[x];
+                if (x < lds_cls) c = cls_lds[x];
                 else { const uint2 v = *(const uint2*)&sc.tasks[ti[j]].n_members; c = cw_sort_class(v.x, v.y, tier); }
                 tmp[atomicAdd(&cnt[wave][c], 1u)] = ti[j];
             }

@@ -109,6 +109,8 @@ def load_library():
     lib.cw_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.cw_host_free.argtypes = [C.c_void_p]
     lib.cw_host_free.restype = None
+    lib.cw_poll.argtypes = [C.c_void_p]
+    lib.cw_poll.restype = C.c_int
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -487,6 +489,13 @@ class Engine:
         torch.cuda.synchronize(dev)
         out, olen, ost = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy()
         return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode("latin-1"), int(ost[i])) for i in range(len(jb))]
+
+    def idle(self):
+        """cw_poll: True when the last run_device on this engine has completed (never blocks)."""
+        rc = self.lib.cw_poll(self.handle)
+        if rc < 0:
+            _check(self.lib, rc, "cw_poll")
+        return rc == 1
 
     def timings(self):
         ms = (C.c_float * 16)()

@@ -133,6 +133,10 @@ void cw_host_free(void* ptr);
  * NULL = the engine's own stream); statuses are checked by the caller after synchronising.  */
 int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* result, void* hip_stream);
 
+/* 1 when everything the last cw_run_device on this engine launched has completed (or nothing was launched yet), 0 while it is
+ * still running; never blocks.  For callers that keep several engines busy and hand the next batch to whichever is free. */
+int cw_poll(cw_engine* e);
+
 /* Milliseconds spent in each device stage of the last cw_run / cw_run_device on this engine, measured
  * with HIP events on the launch stream.  n_stages entries are written (at most cap); names are static. */
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages);
