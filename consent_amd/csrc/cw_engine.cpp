@@ -371,12 +371,13 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        and the overflow passes -- normally a handful of tasks -- are 64 / 16 work-groups instead of two per CU.  Alone on the GPU the
        step time is unchanged. */
     const uint32_t sort_lds = knob_u("CW_SORT_LDS", 16384, 0, CW_SORT_LDS_CLS);
+    const uint32_t sort_thr = knob_u("CW_SORT_THREADS", 256, 128, 1024) / 64 * 64;
     const uint32_t q_waves = knob_u("CW_Q_WAVES", 2, 1, CW_POAQ_WAVES);          /* waves per tier-Q work-group (four tasks per wave) */
     const uint32_t q_grid = (uint32_t)cus * CW_POAQ_WAVES / q_waves;
     const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64, 1, (uint32_t)cus * 2);
     const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
     const uint32_t big_wgs = knob_u("CW_BIG_WGS", big_cap < 16 ? big_cap : 16, 1, big_cap);
-    cw_sort_tier_kernel<<<4, 1024, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
+    cw_sort_tier_kernel<<<4, sort_thr, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     const char* ph_env = getenv("CW_PHASES");

@@ -1142,13 +1142,14 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
     const int tier = blockIdx.x == 3 ? 0 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list */
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
+    const uint32_t nthr = blockDim.x, nwv = nthr >> 6; /* 4 .. 16 waves: a small work-group finds room beside another batch's persistent kernels */
     uint32_t* list = sc.tier_list[tier];
     uint32_t* tmp = sc.over_list[tier];
     if (n < 2) return;
-    for (uint32_t x = threadIdx.x; x < 16 * CW_SORT_CLASSES; x += 1024) (&cnt[0][0])[x] = 0;
+    for (uint32_t x = threadIdx.x; x < 16 * CW_SORT_CLASSES; x += nthr) (&cnt[0][0])[x] = 0;
     __syncthreads();
     /* every wave owns a contiguous slice of the list in both passes; eight entries per lane in flight (two dependent global reads each) */
-    const uint32_t per = (n + 15u) / 16u, lo = min(n, (uint32_t)wave * per), hi = min(n, lo + per);
+    const uint32_t per = (n + nwv - 1u) / nwv, lo = min(n, (uint32_t)wave * per), hi = min(n, lo + per);
     for (uint32_t x0 = lo; x0 < hi; x0 += 512) {
         uint32_t ti[8];
         uint2 nm[8];
@@ -1167,12 +1168,12 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
         }
     }
     __syncthreads();
-    if (threadIdx.x < CW_SORT_CLASSES) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += cnt[w][threadIdx.x]; tot_c[threadIdx.x] = t; }
+    if (threadIdx.x < CW_SORT_CLASSES) { uint32_t t = 0; for (uint32_t w = 0; w < nwv; ++w) t += cnt[w][threadIdx.x]; tot_c[threadIdx.x] = t; }
     __syncthreads();
     if (threadIdx.x < CW_SORT_CLASSES) { /* class-major, then wave: exclusive offsets */
         uint32_t before = 0;
         for (uint32_t c = 0; c < threadIdx.x; ++c) before += tot_c[c];
-        for (int w = 0; w < 16; ++w) { const uint32_t k = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = before; before += k; }
+        for (uint32_t w = 0; w < nwv; ++w) { const uint32_t k = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = before; before += k; }
     }
     __syncthreads();
     for (uint32_t x0 = lo; x0 < hi; x0 += 512) {
@@ -1192,10 +1193,10 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
     }
     __threadfence_block();
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < n; x += 1024) list[x] = tmp[x];
+    for (uint32_t x = threadIdx.x; x < n; x += nthr) list[x] = tmp[x];
     if (tier == 3) { /* the live queue of tier L: an entry is its own flag */
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < n; x += 1024) tmp[x] = 0xFFFFFFFFu;
+        for (uint32_t x = threadIdx.x; x < n; x += nthr) tmp[x] = 0xFFFFFFFFu;
     }
 }
 
