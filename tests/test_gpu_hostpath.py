@@ -127,3 +127,58 @@ def test_bench_gpus_2_spawns_two_ranks_without_a_launcher():
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["distinct_windows_per_run"] == 2 * 2 * 256
     assert j["value"] > 0 and "roofline" in j
+
+
+def test_two_engines_take_batches_in_turn_and_cw_poll_tells_which_is_free():
+    """Two engines on one GPU, each with a batch in flight on its own streams (what bench.py does): cw_poll never blocks, turns 1 once
+    the batch is done, and every result equals the oracle's."""
+    import time
+
+    import torch
+
+    dev = torch.device("cuda", 0)
+    prm = ca.Params(9, 4, 8, 2, 150)
+    engs = [ca.Engine(prm), ca.Engine(prm)]
+    assert all(e.idle() for e in engs)  # nothing launched yet
+    hbs = [synth_host(ca.SynthSpec.pacbio(96, 60, first_window=5000 * i)) for i in range(4)]
+    exp = [oracle_lib.oracle_run(prm, hb, want_solid=True)[0] for hb in hbs]
+
+    def up(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+
+    def launch(e, hb):
+        res = alloc_results(hb, True, prm.solid, prm.k)
+        t_in = (up(hb.win_first_seq, np.int32), up(hb.seq_len, np.int32), up(hb.seq_word_off, np.int64), up(np.concatenate([hb.bases, np.zeros(4, np.uint32)]), np.int32))
+        t_out = [torch.zeros(len(res.cons), dtype=torch.uint8, device=dev), up(res.cons_off, np.int64), torch.zeros(hb.n_windows, dtype=torch.int32, device=dev),
+                 torch.full((hb.n_windows,), 255, dtype=torch.uint8, device=dev), torch.zeros(len(res.solid), dtype=torch.int32, device=dev), up(res.solid_off, np.int64),
+                 torch.zeros(hb.n_windows, dtype=torch.int32, device=dev)]
+        torch.cuda.synchronize(dev)  # the engine launches on its own stream
+        b = Batch(hb.n_windows, len(hb.seq_len), len(hb.bases), *[t.data_ptr() for t in t_in])
+        r = Result(*[t.data_ptr() for t in t_out])
+        e.run_device(b, r)
+
+        def fetch():
+            res.cons[:] = t_out[0].cpu().numpy()
+            res.cons_len[:] = t_out[2].cpu().numpy().view(np.uint32)
+            res.status[:] = t_out[3].cpu().numpy()
+            res.solid[:] = t_out[4].cpu().numpy().view(np.uint32)
+            res.solid_len[:] = t_out[6].cpu().numpy().view(np.uint32)
+            return res
+
+        return fetch, (t_in, t_out, b, r)
+
+    got, pending, nxt = [None] * 4, {}, 0
+    t_end = time.time() + 120
+    while (nxt < 4 or pending) and time.time() < t_end:
+        for k, e in enumerate(engs):
+            if not e.idle():
+                continue
+            if k in pending:
+                i, (fetch, _keep) = pending.pop(k)
+                got[i] = fetch()
+            if nxt < 4:
+                pending[k] = (nxt, launch(e, hbs[nxt]))
+                nxt += 1
+    assert not pending and all(g is not None for g in got)
+    for i in range(4):
+        same(got[i], exp[i], hbs[i].n_windows)
