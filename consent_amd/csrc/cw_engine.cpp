@@ -698,10 +698,12 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const bool want_trace = getenv("CW_STITCH_TRACE") != nullptr;
-    int rc = ensure(&e->xscratch, &e->xscratch_bytes, 256 + (want_trace ? (size_t)batch->n_windows * 32 : 0));
+    const size_t trace_bytes = want_trace ? (size_t)batch->n_windows * 32 : 0;
+    int rc = ensure(&e->xscratch, &e->xscratch_bytes, 256 + trace_bytes + (size_t)n_reads * 4);
     if (rc) return rc;
     CW_HIP(hipMemsetAsync(e->xscratch, 0, 16, st));
     StitchArgs a;
+    a.order = (uint32_t*)((uint8_t*)e->xscratch + 256 + trace_bytes);
     a.trace = want_trace ? (uint32_t*)((uint8_t*)e->xscratch + 256) : nullptr;
     if (want_trace) CW_HIP(hipMemsetAsync(a.trace, 0xFF, (size_t)batch->n_windows * 32, st));
     a.reads = *reads; a.jobs = jobs; a.n_reads = n_reads; a.win_pos = win_pos;
@@ -720,6 +722,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs * CW_ST_WAVES * a.dir_bytes);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
+    cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
     cw_stitch_kernel<<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
     CW_HIP(hipGetLastError());
     return CW_OK;

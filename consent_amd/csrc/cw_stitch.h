@@ -47,6 +47,7 @@ struct StitchArgs {
     uint32_t* out_len;
     uint8_t* read_status; /* 0 ok, 1 dropped (dropRead), 2 capacity */
     uint32_t* cursor;
+    uint32_t* order;     /* reads in the order the waves take them: most windows first (cw_stitch_order_kernel) */
     int8_t* dir_scratch; /* dir_bytes per wave of the grid */
     uint32_t dir_bytes;
     uint32_t* trace; /* debug: 8 words per window, NULL in production */
@@ -354,6 +355,23 @@ __device__ __forceinline__ int st_nb_solid(const uint8_t* s, int len, const uint
     return st_uni(cw_wave_sum(nb));
 }
 
+/* A read is a serial chain of its windows on one wave, so the launch lasts as long as its longest read takes from the moment it is
+ * picked up: hand the reads out longest first (counting sort by window count, most windows first; the order inside a class does not
+ * matter -- every read writes only its own output slot). */
+__global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
+    __shared__ uint32_t hist[1024];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_reads; i += 1024) atomicAdd(&hist[min(a.jobs[i].win_count, 1023u)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { /* exclusive offsets, largest class first */
+        uint32_t run = 0;
+        for (int c = 1023; c >= 0; --c) { const uint32_t k = hist[c]; hist[c] = run; run += k; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_reads; i += 1024) a.order[atomicAdd(&hist[min(a.jobs[i].win_count, 1023u)], 1u)] = i;
+}
+
 __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -370,6 +388,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
         if (lane == 0) ri = atomicAdd(a.cursor, 1u);
         ri = (uint32_t)cw_lane_value((int)ri, 0);
         if (ri >= a.n_reads) break;
+        ri = st_uni(a.order[ri]);
         cw_stitch_read jb = a.jobs[ri];
         jb.read = st_uni(jb.read); jb.win_first = st_uni(jb.win_first); jb.win_count = st_uni(jb.win_count);
         const uint32_t rlen = st_uni(a.reads.read_len[jb.read]);
