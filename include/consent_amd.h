@@ -105,7 +105,12 @@ const char* cw_strerror(int status);
  * host thread or per device (any number of engines may share a GPU; results do not depend on how windows are spread over engines,
  * batches or GPUs).  cw_run_device is asynchronous: the caller's device buffers must stay valid, and the engine's next call on
  * another stream must be ordered by the caller, until that stream has been synchronised.  The host feeders (cw_index_reads,
- * cw_paf_*) keep their state in their own handles: one thread per handle. */
+ * cw_paf_*) keep their state in their own handles: one thread per handle (cw_paf_open starts parser threads of its own; they end in
+ * cw_paf_close, which must come before cw_read_index_free of the index it was opened with).
+ * Several engines on one GPU: an engine launches on four streams of its own.  The HIP runtime maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime starts; with more engine streams than queues one engine's
+ * kernels queue behind another's long-running ones.  Set GPU_MAX_HW_QUEUES >= 4 x engines per GPU in the process environment (8 for
+ * the usual two; cw_run_correction and bench.py do so themselves unless the variable is already set). */
 int cw_create(const cw_params* params, int device, cw_engine** out);
 void cw_destroy(cw_engine* e);
 
