@@ -391,6 +391,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
        long-running tier-L kernel (E. coli-scale run: 1.68-2.84 s with 4 queues, 1.57-1.58 s with 12).  No effect if the caller's
        process has already started HIP; never overrides the caller's own setting. */
     setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    /* the HIP runtime takes ~0.1 s to start (first call of the process): let it start while the reads are indexed */
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([] { if (getenv("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
 
     /* ---- indexReads (+ the proof file into the same index) ---- */
     cw_read_index* index = nullptr;
@@ -404,6 +406,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     sh.index = index;
     cw_read_index_view(index, &sh.host_reads, &sh.read_words);
     const double t_indexed = now_ms();
+    hip_warm.t.join();
 
     /* ---- devices: explicit list, or CW_DEVICES="0,1,..." (an id may repeat: several engines on one GPU), or the first
             min(nb_threads, device count) devices ---- */
