@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <map>
 #include <string>
 #include <thread>
@@ -110,14 +111,15 @@ struct Worker {
     uint64_t windows = 0, reads = 0, jobs = 0;
     double ms_extract = 0, ms_consensus = 0, ms_stitch = 0;
 
-    int init(const Shared& sh) {
-        if (hipSetDevice(device) != hipSuccess) return CW_E_NO_DEVICE;
-        const cw_driver_args& a = *sh.a;
-        cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
-        int rc = cw_create(&prm, device, &eng);
-        if (rc != CW_OK) return rc;
-        if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
+    /* The 2-bit read set is uploaded once per DEVICE: the first worker on a device owns the copy and publishes it, the others on that
+       device (two workers per GPU by default) wait for it and use the same buffers. */
+    std::promise<int> reads_ready;            /* set by an owner, in every path out of init() */
+    std::shared_future<int> reads_of_owner;   /* valid in a worker that borrows another worker's copy */
+    const Worker* owner = nullptr;
+
+    int upload_reads(const Shared& sh) {
         const uint32_t n = sh.host_reads.n_reads;
+        int rc;
         if ((rc = rd_len.ensure((size_t)n * 4 + 4)) || (rc = rd_off.ensure((size_t)n * 8 + 8)) || (rc = rd_bases.ensure((size_t)sh.read_words * 4 + 8))) return rc;
         if (hipMemcpy(rd_len.p, sh.host_reads.read_len, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(rd_off.p, sh.host_reads.read_word_off, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
@@ -128,6 +130,26 @@ struct Worker {
         dev_reads.read_len = rd_len.as<uint32_t>();
         dev_reads.read_word_off = rd_off.as<uint64_t>();
         dev_reads.bases = rd_bases.as<uint32_t>();
+        return CW_OK;
+    }
+
+    int init(const Shared& sh) {
+        int rc = CW_OK;
+        if (hipSetDevice(device) != hipSuccess) rc = CW_E_NO_DEVICE;
+        if (!owner) { /* the copy first: the borrowers' engines are being created meanwhile */
+            if (rc == CW_OK) rc = upload_reads(sh);
+            reads_ready.set_value(rc);
+        }
+        if (rc != CW_OK) return rc;
+        const cw_driver_args& a = *sh.a;
+        cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
+        rc = cw_create(&prm, device, &eng);
+        if (rc != CW_OK) return rc;
+        if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
+        if (owner) {
+            if ((rc = reads_of_owner.get()) != CW_OK) return rc;
+            dev_reads = owner->dev_reads;
+        }
         return CW_OK;
     }
 
@@ -428,7 +450,16 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     for (int d : devs) if (d < 0 || d >= n_dev) { cw_read_index_free(index); return CW_E_INVALID; }
 
     std::vector<Worker> workers(devs.size());
-    for (size_t i = 0; i < devs.size(); ++i) workers[i].device = devs[i];
+    for (size_t i = 0; i < devs.size(); ++i) {
+        workers[i].device = devs[i];
+        for (size_t o = 0; o < i; ++o)
+            if (!workers[o].owner && workers[o].device == devs[i]) { workers[i].owner = &workers[o]; break; }
+    }
+    {   /* one future per owner, shared by its borrowers */
+        std::vector<std::shared_future<int>> fut(devs.size());
+        for (size_t i = 0; i < devs.size(); ++i) if (!workers[i].owner) fut[i] = workers[i].reads_ready.get_future().share();
+        for (size_t i = 0; i < devs.size(); ++i) if (workers[i].owner) workers[i].reads_of_owner = fut[(size_t)(workers[i].owner - &workers[0])];
+    }
     sh.queue_cap = 2 * devs.size() + 1;
     /* Engines and read-set uploads start on the worker threads themselves (all devices at once) while this thread already parses the
        alignments: creating two engines with their scratch takes 0.2-0.3 s, during which the producer fills the queue */
