@@ -179,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     host_ms = [0.0, 0.0]
     ran = [0] * ne  # steps handed to each engine
+    stagger = os.environ.get("CW_BENCH_STAGGER", "0") != "0"  # measured slower (82.9 vs 79.9 ms at depth 150): tier S ends as late as tier L, there is no tail to run under
     e_last = 0
     for i in range(args.steps):
         _h0 = time.perf_counter()
@@ -187,9 +188,11 @@ def main():
         else:  # the engine that is free takes the step (an engine still in a long tier-L tail does not hold up the others)
             k_ = None
             while k_ is None:
+                ph = [e_.phase() for e_ in engines]
                 for c_ in range(ne):
                     c2 = (e_last + 1 + c_) % ne
-                    if engines[c2].idle():
+                    # a free engine takes the step; with CW_BENCH_STAGGER=1 only once every other engine is free or in its tail
+                    if ph[c2] == 1 and (not stagger or all(ph[o_] in (1, 2) for o_ in range(ne) if o_ != c2)):
                         k_ = c2
                         break
                 else:

@@ -470,11 +470,21 @@ int cw_poll(cw_engine* e) {
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->timings_valid) return 1;
     if (hipSetDevice(e->device) != hipSuccess) return CW_E_NO_DEVICE;
-    const hipError_t q = hipEventQuery(e->ev_end);
+    hipError_t q = hipEventQuery(e->ev_end);
     if (q == hipSuccess) return 1;
-    if (q == hipErrorNotReady) return 0;
-    (void)hipGetLastError();
-    return CW_E_NO_DEVICE;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return CW_E_NO_DEVICE; }
+    /* still running: has it left the part that fills the GPU?  (tiers S, M1 and M2 done; what is left is tier L's long tasks, a
+       handful of waves, and the finish kernel) */
+    int bulk = 0, done = 0;
+    for (int i = 0; i < e->n_stages; ++i) {
+        const char* n = e->stage_name[i];
+        if (strcmp(n, "poa") && strcmp(n, "poa_m1") && strcmp(n, "poa_m2")) continue;
+        ++bulk;
+        q = hipEventQuery(e->ev1[i]);
+        if (q == hipSuccess) ++done;
+        else if (q != hipErrorNotReady) { (void)hipGetLastError(); return CW_E_NO_DEVICE; }
+    }
+    return bulk && done == bulk ? 2 : 0;
 }
 
 int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n_stages) {

@@ -497,6 +497,13 @@ class Engine:
             _check(self.lib, rc, "cw_poll")
         return rc == 1
 
+    def phase(self):
+        """cw_poll as it is: 1 done / nothing launched, 2 running but in its tail, 0 running."""
+        rc = self.lib.cw_poll(self.handle)
+        if rc < 0:
+            _check(self.lib, rc, "cw_poll")
+        return rc
+
     def timings(self):
         ms = (C.c_float * 16)()
         names = (C.c_char_p * 16)()

@@ -139,7 +139,10 @@ void cw_host_free(void* ptr);
 int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* result, void* hip_stream);
 
 /* 1 when everything the last cw_run_device on this engine launched has completed (or nothing was launched yet), 0 while it is
- * still running; never blocks.  For callers that keep several engines busy and hand the next batch to whichever is free. */
+ * still running, 2 while it is running but past the part that fills the GPU (what is left is the tail: a few long alignment tasks on
+ * one wave each, then the finish kernel); never blocks.  For callers that keep several engines busy: hand the next batch to an
+ * engine that returns 1.  (Waiting for the other engine to reach 2 before starting -- batches staggered instead of side by side --
+ * halves a batch's latency and measured 4 % less throughput at depth 150: bench.py, CW_BENCH_STAGGER.) */
 int cw_poll(cw_engine* e);
 
 /* Milliseconds spent in each device stage of the last cw_run / cw_run_device on this engine, measured
