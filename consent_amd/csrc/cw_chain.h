@@ -386,7 +386,23 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     const bool cap_ok = (uint64_t)tb + (uint32_t)__popcll(pm) <= sc.task_cap && (uint64_t)mb + m_total <= sc.member_cap &&
                                         b1 + (uint32_t)__popcll(tm1) <= sc.list_cap && b2 + (uint32_t)__popcll(tm2) <= sc.list_cap &&
                                         b3 + (uint32_t)__popcll(tm3) <= sc.list_cap && bq + (uint32_t)__popcll(tmq) <= sc.list_cap;
-                    if (!cap_ok) { over = true; }
+                    if (!cap_ok) {
+                        /* The counters have advanced and are never rolled back; consumers clamp them to the capacities and walk every slot
+                           below.  Whatever this flush reserved inside a capacity is therefore given a neutral content -- a finished task
+                           without members, list entries naming the batch's permanent neutral task (tasks[task_cap], cw_setup_kernel) -- or the
+                           tier kernels would run the records a previous batch left there. */
+                        over = true;
+                        const uint32_t n_t = (uint32_t)__popcll(pm);
+                        for (uint32_t x = lane; x < n_t; x += 64)
+                            if ((uint64_t)tb + x < sc.task_cap) { PoaTask t; t.window = w; t.seg_slot = seg_base; t.member_off = 0; t.n_members = 0; t.max_len = 0; t.out_off = 0; t.out_cap = 0; t.state = 1u; sc.tasks[tb + x] = t; }
+                        const uint32_t lb[4] = {bq, b1, b2, b3};
+                        const unsigned long long lm[4] = {tmq, tm1, tm2, tm3};
+                        for (int li = 0; li < 4; ++li) {
+                            const uint32_t n_l = (uint32_t)__popcll(lm[li]);
+                            for (uint32_t x = lane; x < n_l; x += 64)
+                                if ((uint64_t)lb[li] + x < sc.list_cap) sc.tier_list[li][lb[li] + x] = sc.task_cap;
+                        }
+                    }
                     else {
                         const uint32_t t_idx = tb + (uint32_t)__popcll(pm & below);
                         const uint32_t m_off = mb + (uint32_t)minc - (poa ? e_n : 0u);

@@ -89,14 +89,16 @@ struct Shared {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+/* An error leaves process() while copies may still be queued on `st` whose host side are locals of process() and vectors of the Job:
+   wait for the stream before they go out of scope (a late copy would write into freed memory -- exactly when the device misbehaves). */
 #define DRV_HIP(expr, job, what)                                                        \
     do {                                                                                \
-        if ((expr) != hipSuccess) { (job).rc = CW_E_NO_DEVICE; (job).err = what; return; } \
+        if ((expr) != hipSuccess) { (job).rc = CW_E_NO_DEVICE; (job).err = what; if (st) (void)hipStreamSynchronize(st); return; } \
     } while (0)
 #define DRV_RC(expr, job, what)                                                         \
     do {                                                                                \
         const int _rc = (expr);                                                         \
-        if (_rc != CW_OK) { (job).rc = _rc; (job).err = what; return; }                 \
+        if (_rc != CW_OK) { (job).rc = _rc; (job).err = what; if (st) (void)hipStreamSynchronize(st); return; } \
     } while (0)
 
 struct Worker {
@@ -183,7 +185,7 @@ struct Worker {
         uint64_t n_words = 0;
         int rc = cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>(), j.wj.data(), n_win, a.mer_size, nullptr, nullptr, nullptr,
                                  nullptr, 0, 0, &n_seqs, &n_words, st);
-        if (rc != CW_OK && rc != CW_E_CAPACITY) { j.rc = rc; j.err = "cw_extract_piles_device (sizing)"; return; }
+        if (rc != CW_OK && rc != CW_E_CAPACITY) { j.rc = rc; j.err = "cw_extract_piles_device (sizing)"; (void)hipStreamSynchronize(st); return; }
         DRV_RC(b_wfs.ensure((size_t)(n_win + 1) * 4), j, "device memory (batch)");
         DRV_RC(b_len.ensure((size_t)n_seqs * 4 + 4), j, "device memory (batch)");
         DRV_RC(b_off.ensure((size_t)n_seqs * 8 + 8), j, "device memory (batch)");
@@ -400,7 +402,7 @@ void emitter_main(Shared* sh, int out_fd, const uint64_t* n_jobs_total, const bo
 extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_stats* stats) {
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!a || !a->alignment_file || !a->reads_file || out_fd < 0) return CW_E_INVALID;
-    if (a->window_size == 0 || a->window_overlap >= a->window_size || a->mer_size < 2 || a->mer_size > 16 || a->solid_thresh < 1 || a->max_msa < 1) return CW_E_INVALID;
+    if (a->window_size == 0 || a->window_overlap >= a->window_size || a->mer_size < 2 || a->mer_size > 16 || a->solid_thresh < 1 || a->max_msa < 1 || a->max_support < 1) return CW_E_INVALID;
     const double t_begin = now_ms();
     Shared sh;
     sh.a = a;
@@ -408,11 +410,10 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     const bool has_proof = a->proof_file && a->proof_file[0];
     sh.do_trim = !a->polishing && !has_proof; /* CONSENT-correction.cpp:17,69-73; CONSENT-polishing.cpp:19 */
     if (const char* oc = getenv("CW_ON_CAPACITY")) sh.skip_on_capacity = strcmp(oc, "skip") == 0;
-    /* HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime starts.  Two
-       workers per device have a dozen kernel and copy streams; with four queues one worker's stream lands behind the other's
-       long-running tier-L kernel (E. coli-scale run: 1.68-2.84 s with 4 queues, 1.57-1.58 s with 12).  No effect if the caller's
-       process has already started HIP; never overrides the caller's own setting. */
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    /* GPU_MAX_HW_QUEUES (hardware queues HIP spreads a process's streams over, default 4, read when the runtime starts) is the HOST
+       PROCESS's business: bin/CONSENT-* set it to 12 in main() before anything touches HIP, consent_amd/pipeline.py before the library is
+       loaded; an embedding application does the same (include/consent_amd.h "Threading").  A library call does not change its caller's
+       environment. */
     /* the HIP runtime takes ~0.1 s to start (first call of the process): let it start while the reads are indexed */
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([] { if (getenv("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
 

@@ -82,6 +82,9 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     uint64_t tc = 64ull * n_windows + 1024, mc = 2048ull * n_windows + 4096;
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
+    /* test aid: shrink the two heuristic capacities so that the overflow path of the chain kernel's task emission can be exercised */
+    if (const char* v = getenv("CW_TASK_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.task_cap) p.task_cap = (uint32_t)x; }
+    if (const char* v = getenv("CW_MEMBER_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.member_cap) p.member_cap = (uint32_t)x; }
     tier_config(cus, big_slots, p.tier);
     size_t o = 0;
     auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
@@ -91,7 +94,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.seg_off, p.seg_cap * 4);
     put(p.seg_len, p.seg_cap * 4);
     put(p.arena, p.arena_cap);
-    put(p.tasks, (size_t)p.task_cap * sizeof(PoaTask));
+    put(p.tasks, ((size_t)p.task_cap + 1) * sizeof(PoaTask)); /* + the batch's neutral task at index task_cap (cw_setup_kernel; cw_chain.h "cap_ok") */
     put(p.members, (size_t)p.member_cap * sizeof(PoaMember));
     put(p.ctr, sizeof(BatchCounters));
     for (int t = 0; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4); /* list 0 = tier Q */
@@ -780,7 +783,7 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     if (si < 0) return CW_E_INVALID; /* CW_SLOTS batches are in flight already: cw_wait one of them first */
     cw_slot& sl = e->slot[si];
     sl.res = *r; sl.n_windows = W; sl.want_solid = want_solid;
-    if (W == 0) { sl.busy = true; *ticket = si; return CW_OK; }
+    if (W == 0) { sl.busy = true; sl.waiting = false; *ticket = si; return CW_OK; }
     CW_HIP(hipSetDevice(e->device));
 
     size_t o = 0;
@@ -837,7 +840,7 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     cw_pack_copy_kernel<<<(W + 3) / 4, 256, 0, st>>>(pa);
     CW_HIP(hipGetLastError());
     CW_HIP(hipEventRecord(sl.ev_done, st));
-    sl.busy = true;
+    sl.busy = true; sl.waiting = false;
     *ticket = si;
     return CW_OK;
 }
@@ -847,18 +850,19 @@ int cw_wait(cw_engine* e, int ticket) {
     cw_slot& sl = e->slot[ticket];
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (!sl.busy) return CW_E_INVALID;
+        if (!sl.busy || sl.waiting) return CW_E_INVALID; /* a ticket is waited for once: a second waiter would race on the staging buffers */
         if (sl.n_windows == 0) { sl.busy = false; return CW_OK; }
+        sl.waiting = true;
     }
     /* the slot belongs to this ticket until busy is cleared; other threads may submit meanwhile */
-    if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(sl.ev_done) != hipSuccess) return CW_E_NO_DEVICE;
+    auto fail = [&](int code) { std::lock_guard<std::mutex> lk(e->mu); sl.busy = false; sl.waiting = false; return code; };
+    if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(sl.ev_done) != hipSuccess) return fail(CW_E_NO_DEVICE);
     const uint32_t W = sl.n_windows;
     const cw_result& r = sl.res;
     uint8_t* dout = (uint8_t*)sl.dev_out;
     hipStream_t co = e->copy_out;
     uint64_t tot[2] = {0, 0};
     int rc = CW_OK;
-    auto fail = [&](int code) { std::lock_guard<std::mutex> lk(e->mu); sl.busy = false; return code; };
     if (hipMemcpyAsync(tot, dout + sl.o_tot, 16, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.cons_len, dout + sl.o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.win_status, dout + sl.o_stat, W, hipMemcpyDeviceToHost, co) != hipSuccess ||

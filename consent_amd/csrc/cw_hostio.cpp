@@ -373,6 +373,7 @@ const char* cw_read_index_name(const cw_read_index* ix, uint32_t id) {
 int cw_paf_open(const char* path, const cw_read_index* idx, uint32_t max_support, cw_paf_reader** out) {
     if (!path || !idx || !out) return CW_E_INVALID;
     *out = nullptr;
+    if (max_support < 1) return CW_E_INVALID; /* the reference cuts the pile to maxSupport and then reads its first overlap (alignmentPiles.cpp:52-57): -S 0 is undefined there */
     cw_paf_reader* r = new (std::nothrow) cw_paf_reader();
     if (!r) return CW_E_NOMEM;
     r->idx = idx; r->max_support = max_support;

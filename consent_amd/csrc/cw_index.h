@@ -72,6 +72,10 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
     __shared__ uint64_t run[4];
     const int tid = threadIdx.x;
     if (tid < 4) run[tid] = 0;
+    if (tid == 0) { /* the neutral task: what a list entry names when the chain kernel ran out of task slots (finished, no members) */
+        PoaTask t; t.window = 0; t.seg_slot = 0; t.member_off = 0; t.n_members = 0; t.max_len = 0; t.out_off = 0; t.out_cap = 0; t.state = 1u;
+        sc.tasks[sc.task_cap] = t;
+    }
     __syncthreads();
     for (uint32_t w0 = 0; w0 < b.n_windows; w0 += 1024) {
         const uint32_t w = w0 + tid;

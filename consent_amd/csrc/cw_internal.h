@@ -16,6 +16,7 @@
    all slots share the engine's scratch and run in submission order on the compute stream */
 struct cw_slot {
     bool busy = false;
+    bool waiting = false; /* a cw_wait is in progress on this ticket */
     void* dev_in = nullptr;
     size_t dev_in_bytes = 0;
     void* dev_out = nullptr;

@@ -1029,6 +1029,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
+        if (t.n_members == 0) return; /* a neutral entry: the chain kernel ran out of task or list slots (cw_chain.h "cap_ok") */
         const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
         const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2)>(M, t, b, sc, lane, acc);
         const unsigned long long _t1 = __builtin_readcyclecounter();

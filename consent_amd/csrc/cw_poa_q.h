@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
         if (mi >= n_work) break;
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
+        if (t.n_members == 0) continue; /* a neutral entry (cw_chain.h "cap_ok") */
         const int rc = poaq_run(M, t, b, sc, gl, acc);
         if (gl == 0) poa_hand_over(sc, t, ti, rc, 0); /* rc 2: redone in tier S, whose kernel follows this one on the stream */
         cw_wave_sync();

@@ -12,7 +12,11 @@ import os
 import sys
 import tempfile
 
-from .engine import EngineError, load_library
+# Before the HIP runtime starts (the library is loaded lazily, below): the driver's two workers per GPU have a dozen streams and HIP spreads a
+# process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  The host process sets it, not the library; a caller's own value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+
+from .engine import EngineError, load_library  # noqa: E402
 
 
 class DriverArgs(C.Structure):
@@ -79,7 +83,7 @@ def correct_reads(reads_path, paf_path, out=None, *, min_support=3, max_support=
     return [(lines[i][1:], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
 
 
-USAGE = "Usage: %s [-a alignmentFile.paf] [-k merSize] [-s minSupportForGoodRegions] [-l minLengthForGoodRegions] [-f freqThresholdForKMers] [-e maxError] [-p freqThresholdForKPersFreqs] [-c freqThresholdForKPersCons] [-m mode (0 for regions, 1 for cluster)] [-j threadsNb] \n\n"
+USAGE = "Usage: %s -a overlaps.paf -r reads.fasta [-R reads.fasta] [-s N] [-S N] [-M N] [-l N] [-m N] [-k N] [-c N] [-A N] [-f N] [-j GPUs] (-i, -p accepted and ignored)\n\n"
 
 
 def main(argv=None, polishing=False):

@@ -325,6 +325,64 @@ def test_full_size_batch_properties(engines):
         assert r1.consensus(9000 + w) == exp.consensus(w)
 
 
+def test_full_size_batch_properties_depth_150(engines):
+    """BASELINE configs[2], the headline configuration, at its bench size (16384 windows, depth 150, maxMSA 150): every window finishes,
+    the consensus is near the truth length, the batch checksum is reproducible and equals the checksum of its two halves run on their own,
+    and a 256-window sample out of the middle of the batch is compared with the oracle."""
+    import zlib
+
+    prm = (9, 4, 8, 2, 150)
+    e = engines(*prm)
+    n = 16384
+    hb = synth_host(ca.SynthSpec.pacbio(n, 150))
+    r1 = e.run(hb, want_solid=False)
+    assert int((r1.status == ca.WIN_OVERFLOW).sum()) == 0
+    assert 450 < np.median(r1.cons_len.astype(np.int64)) < 550
+
+    def digest(res, count, crc=0):
+        for w in range(count):
+            crc = zlib.crc32(res.consensus(w).encode(), crc)
+        return crc
+
+    whole = digest(r1, n)
+    sample = synth_host(ca.SynthSpec.pacbio(256, 150, first_window=7000))
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), sample, threads=os.cpu_count() or 1)
+    for w in range(256):
+        assert r1.consensus(7000 + w) == exp.consensus(w), f"window {7000 + w} differs from the oracle"
+    del r1
+    assert digest(e.run(hb, want_solid=False), n) == whole
+    del hb
+    crc = 0
+    for first in (0, n // 2):
+        half = e.run(synth_host(ca.SynthSpec.pacbio(n // 2, 150, first_window=first)), want_solid=False)
+        crc = digest(half, n // 2, crc)
+    assert crc == whole
+
+
+def test_running_out_of_task_slots_flags_windows_and_never_runs_stale_tasks(engines, monkeypatch):
+    """The chain kernel's task / member / list capacities are heuristics (64 tasks and 2048 members per window).  With the capacity shrunk
+    (CW_TASK_CAP, CW_MEMBER_CAP: test aids read when a batch is planned) the windows that do not fit come back as overflow, every other window
+    is what the oracle says, and a second, different batch on the same engine -- whose reserved-but-unwritten slots hold the first batch's
+    records -- behaves the same way."""
+    prm = (9, 4, 8, 2, 20)
+    e = engines(*prm)
+    for first, depth in ((0, 30), (500, 12)):
+        hb = synth_host(ca.SynthSpec.pacbio(48, depth, first_window=first))
+        exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+        full = e.run(hb)
+        assert_same(full, exp, 48, "uncapped")
+        for env, val in (("CW_TASK_CAP", "200"), ("CW_MEMBER_CAP", "3000")):
+            monkeypatch.setenv(env, val)
+            got = e.run(hb)  # capacity overflow is a per-window status here (cw_run returns CW_E_CAPACITY, which Engine.run lets through)
+            monkeypatch.delenv(env)
+            n_over = int((got.status == ca.WIN_OVERFLOW).sum())
+            assert 0 < n_over < 48, (env, n_over)
+            for w in range(48):
+                if int(got.status[w]) != ca.WIN_OVERFLOW:
+                    assert got.consensus(w) == exp.consensus(w), f"{env}: window {w} differs"
+        assert_same(e.run(hb), exp, 48, "after the capped runs")
+
+
 def test_cpp_adapter_runs_on_the_gpu(tmp_path):
     """examples/operator_demo.cpp through include/consent_amd_adapter.hpp: the C++ host side of the boundary."""
     import subprocess
