@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "2")),
                     help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
+    ap.add_argument("--alone-steps", type=int, default=3, help="untimed steps after the timed region with ONE batch in flight: per-kernel HIP-event times that are work, not waiting (roofline.launch_ms)")
     ap.add_argument("--pcie-engines", type=int, default=1, help="engines the PCIe-inclusive leg spreads its host batches over")
     ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
@@ -106,7 +107,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CW_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; only a barrier and one max-reduce use it
+        # the data path has no collective (north_star: "no RCCL"): the barrier and the one max-reduce of the timing go over gloo;
+        # CW_BENCH_BACKEND=nccl (= RCCL on ROCm) remains for boxes where that is preferred
+        backend = os.environ.get("CW_BENCH_BACKEND", "gloo")
         try:
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -227,7 +230,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # --- kernel times with ONE batch in flight (untimed, after the clock stopped): with two engines a kernel's HIP-event span also holds
+    # the wait for CUs the other batch occupies, so "launch duration = work" is only true here.  This is what `roofline` is priced on and
+    # what the `--engines 1` rocprofv3 summary under profiles/ must agree with.
+    alone_ms = {}
+    n_alone = max(0, args.alone_steps)
+    for i in range(n_alone):
+        engines[0].run_device(batches[(args.warmup + i) % n_batches], rs[0])
+        for k, v in engines[0].timings().items():  # waits for the step
+            alone_ms.setdefault(k, []).append(v)
+    if ne == 1 and not alone_ms:
+        alone_ms = stage_ms
     last = (args.warmup + args.steps - 1) % n_batches
+    if n_alone:
+        last, e_last = (args.warmup + n_alone - 1) % n_batches, 0
     r_last = ([(t_cons, t_clen, t_stat, t_solid, t_slen)] + keep_r)[e_last]  # the result arrays the last step wrote
     status = r_last[2].cpu().numpy()
     n_over = int((status == ca.WIN_OVERFLOW).sum())
@@ -237,16 +253,16 @@ def main():
     seq_len = keep[last][1].cpu().numpy()
     alg_bytes = algorithmic_bytes(seq_len, n_win, clen, slen)
     stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
-    kern_avg = {k: v for k, v in stage_avg.items() if k != "total"}
-    # the dominant kernel is the launch that bounds the step: the longest one (the POA tier kernels run concurrently between one
-    # fork and one join, so the longest of them is what the stage waits for)
-    dom = max(kern_avg, key=kern_avg.get) if kern_avg else None
+    alone_avg = {k: float(np.mean(v)) for k, v in alone_ms.items()}
+    # The dominant kernel is the one that does the largest share of the work, by the wave-cycles the POA kernels count themselves
+    # (cw_debug_profile; the tier kernels run side by side between one fork and one join, so wall time does not tell them apart).
     tier_stage = ["poa", "poa_m1", "poa_m2", "poa_large"]
     busy_share = None
     _, prof = eng.profile()
     busy = [float(prof[8 + 5 * t : 13 + 5 * t].sum()) for t in range(4)]
     if sum(busy) > 0:
         busy_share = {tier_stage[t]: busy[t] / sum(busy) for t in range(4)}
+    dom = max(busy_share, key=busy_share.get) if busy_share else (max((k for k in alone_avg if k != "total"), key=alone_avg.get) if alone_avg else None)
     total_windows = n_win * world * args.steps
     value = total_windows / dt
 
@@ -275,36 +291,46 @@ def main():
             "template_fallback_windows": n_tpl,
         },
         "stage_ms": stage_avg,
+        "stage_ms_one_batch_in_flight": alone_avg,
     }
-    stage_kernel = {"index": "cw_index_kernel", "chain": "cw_chain_kernel", "poa": "cw_poa_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512",
+    stage_kernel = {"index": "cw_index_kernel", "chain": "cw_chain_kernel", "poa": "cw_poa_kernel", "poa_q": "cw_poa_q_kernel", "poa_h": "cw_poa_h_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512",
                     "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0>", "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
-    traffic, traffic_src = None, None
+    traffic, traffic_step, traffic_src, prof_whole = None, None, None, None
     prof_json = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
     if dom and os.path.exists(prof_json):
-        try:  # HBM-side bytes of the dominant kernel from the separate --pmc passes of the same command (tools/profile_round.sh)
+        try:  # HBM-side bytes from the separate --pmc passes of the same command with one engine (tools/profile_r03.sh, tools/summarize_r03.py)
             pj = json.load(open(prof_json))
             if pj.get("windows_per_step") == n_win:
+                traffic_src = os.path.relpath(prof_json, ROOT)
                 for name, k in pj["kernels"].items():
                     if stage_kernel.get(dom, "?") in name and "traffic_bytes_per_launch" in k:
-                        traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(prof_json, ROOT)
+                        traffic = k["traffic_bytes_per_launch"]
+                traffic_step = pj.get("traffic_bytes_per_step")
+                prof_whole = pj.get("whole_step")
         except Exception:
             pass
-    if dom:
-        # dominant kernel: algorithmic bytes of the whole path per launch / its own launch time (HIP events)
-        ach = alg_bytes / (stage_avg[dom] * 1e-3) / 1e9
+    if dom and dom in alone_avg:
+        # dominant kernel: algorithmic bytes of the batch / its launch duration with one batch in flight (HIP events on its own stream)
+        ach = alg_bytes / (alone_avg[dom] * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm",
             "kernel": dom,
             "kernel_symbol": stage_kernel.get(dom),
+            "kernel_chosen_by": "largest share of the POA wave-cycles (counted by the kernels)",
             "poa_tier_share_of_wave_cycles": busy_share,
             "achieved": ach,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_whole_step": traffic_step,
+            "traffic_whole_step_over_algorithmic": (traffic_step / alg_bytes) if traffic_step else None,
             "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_window": alg_bytes / n_win,
-            "launch_ms": stage_avg[dom],
+            "launch_ms": alone_avg[dom],
+            "launch_ms_two_batches_in_flight": stage_avg.get(dom),
+            "step_ms_one_batch_in_flight": alone_avg.get("total"),
             "frac_of_whole_step": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
 
@@ -395,7 +421,7 @@ def main():
         cdt = time.perf_counter() - t1
         for pr in procs:
             pr.join()
-        n_st = min(n_s, 256)
+        n_st = min(n_s, 256)  # windows byte-compared with the GPU (and counted for the secondary figures): the first n_st of the timed sample
         exp, ost = oracle_lib.oracle_run(prm, hb.slice(0, n_st), threads=min(cores, 32))
         # secondary, interpretable rates: the path is integer DP, far from the HBM roof by construction
         out["secondary"] = {
@@ -403,8 +429,13 @@ def main():
             "poa_alignments_per_window": ost["alignments"] / n_st,
             "poa_gcups": ost["dp_cells"] / n_st * value / 1e9,
             "kmers_per_window": ost["kmers"] / n_st,
-            "note": "cell and alignment counts from the oracle on the first windows of the workload; GCUPS = cells/window x windows/s",
+            "poa_alignments_per_sec": ost["alignments"] / n_st * value,
+            "note": f"cell, alignment and k-mer counts from the oracle on the first {n_st} windows of the workload (they include the segments both sides resolve without a POA); GCUPS = cells/window x windows/s",
         }
+        if prof_whole:  # from the SQ counter passes of the same command with one engine (profiles/latest_*.json, tools/summarize_r03.py)
+            out["secondary"]["valu_issue_frac"] = prof_whole.get("valu_issue_frac")
+            out["secondary"]["lds_bw_frac"] = prof_whole.get("lds_busy_frac")
+            out["secondary"]["counters_source"] = traffic_src
         # parity spot-check of the same windows on the GPU
         got = eng.run(hb.slice(0, n_st))
         same = all(got.consensus(w) == exp.consensus(w) and got.status[w] == exp.status[w] for w in range(n_st))
@@ -414,7 +445,8 @@ def main():
             "cores": cores,
             "kind": "port",
             "simd": False,
-            "sample": f"first {n_s} windows of the same workload, oracle/liboracle.so (scalar C++ restatement, -O3 -march=native, no SIMD POA: the real reference's spoa is vectorised), {len(procs)} single-thread worker processes (= usable cores: affinity capped by the cgroup CPU quota; the box shows {os.cpu_count()} logical CPUs), consensus stage only",
+            "gpu_compared_windows": n_st,
+            "sample": f"first {n_s} windows of the same workload (the first {n_st} of them also byte-compared with the GPU), oracle/liboracle.so (scalar C++ restatement, -O3 -march=native, no SIMD POA: the real reference's spoa is vectorised), {len(procs)} single-thread worker processes (= usable cores: affinity capped by the cgroup CPU quota; the box shows {os.cpu_count()} logical CPUs), consensus stage only",
             "gpu_identical_on_sample": bool(same),
         }
     if rank == 0 and os.environ.get("CW_PROFILE"):
