@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -74,6 +75,7 @@ struct Shared {
     double t_start = 0; /* now_ms() when the run began (inspection output) */
     bool do_trim = true;
     bool skip_on_capacity = false;
+    bool dry = false; /* CW_DRIVER_DRY: workers take the jobs and throw them away -- what the host side alone can feed (no device is touched) */
     /* job queue (producer -> workers) */
     std::mutex mu;
     std::condition_variable cv_work, cv_room, cv_done;
@@ -137,6 +139,7 @@ struct Worker {
 
     int init(const Shared& sh) {
         int rc = CW_OK;
+        if (sh.dry) { if (!owner) reads_ready.set_value(CW_OK); return CW_OK; }
         if (hipSetDevice(device) != hipSuccess) rc = CW_E_NO_DEVICE;
         if (!owner) { /* the copy first: the borrowers' engines are being created meanwhile */
             if (rc == CW_OK) rc = upload_reads(sh);
@@ -156,6 +159,7 @@ struct Worker {
     }
 
     void close() {
+        if (!eng && !st && !pin) return; /* nothing was created (dry run, or init failed early) */
         (void)hipSetDevice(device);
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
@@ -169,6 +173,7 @@ struct Worker {
         j.out.assign(n_piles, std::string());
         j.device = device;
         if (n_win == 0 || n_piles == 0) return;
+        if (sh.dry) { windows += n_win; reads += n_piles; jobs++; return; }
         const double t0 = now_ms();
         DRV_HIP(hipSetDevice(device), j, "hipSetDevice");
         DRV_RC(ovl.ensure(j.ovl.size() * sizeof(cw_overlap) + 64), j, "device memory (overlaps)");
@@ -415,7 +420,9 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
        loaded; an embedding application does the same (include/consent_amd.h "Threading").  A library call does not change its caller's
        environment. */
     /* the HIP runtime takes ~0.1 s to start (first call of the process): let it start while the reads are indexed */
-    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([] { if (getenv("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
+    if (const char* dr = getenv("CW_DRIVER_DRY")) sh.dry = dr[0] && dr[0] != '0';
+    const bool dry = sh.dry;
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([dry] { if (dry || getenv("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
 
     /* ---- indexReads (+ the proof file into the same index) ---- */
     cw_read_index* index = nullptr;
@@ -439,7 +446,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         for (const char* p = env; *p;) { char* e = nullptr; const long v = strtol(p, &e, 10); if (e == p) break; devs.push_back((int)v); p = *e == ',' ? e + 1 : e; }
     }
     int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { cw_read_index_free(index); fprintf(stderr, "[consent_amd] no HIP device: the engine has no CPU path\n"); return CW_E_NO_DEVICE; }
+    if (dry) { n_dev = a->nb_threads < 1 ? 1 : (int)a->nb_threads; for (int d : devs) n_dev = d + 1 > n_dev ? d + 1 : n_dev; } /* as many "devices" as were asked for */
+    else if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { cw_read_index_free(index); fprintf(stderr, "[consent_amd] no HIP device: the engine has no CPU path\n"); return CW_E_NO_DEVICE; }
     if (devs.empty()) {
         /* two workers (engine + buffers each) per device: while one job is in its re-assembly -- one wave per read, the longest read sets
            the time, most of the GPU idle -- the other worker's consensus kernels run (measured on one GPU: 717 -> 550 ms for 112 k windows) */
@@ -486,14 +494,25 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         });
     std::thread emitter(emitter_main, &sh, out_fd, &n_jobs_total, &producer_done, &records, &bases_out);
 
-    /* ---- producer: getNextReadPile -> getAlignmentWindowsPositions -> jobs ---- */
+    /* ---- producer: getNextReadPile -> getAlignmentWindowsPositions -> jobs ----
+       Piles are read in PAF order on this thread (the reader parses blocks of the file ahead on its own threads, cw_hostio.cpp) a
+       few hundred at a time; the window positions of one such round are computed on helper threads -- piles are independent -- while
+       this thread already reads the next round; jobs are then put together in pile order, so their contents do not depend on the
+       number of helpers.  One thread did all three before: 3 M windows/s, within 2x of what eight GPUs take. */
     const uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
     cw_paf_reader* paf = nullptr;
     rc = cw_paf_open(a->alignment_file, index, a->max_support, &paf);
     uint64_t n_piles = 0, n_windows = 0, n_overlaps = 0;
+    unsigned n_help = std::thread::hardware_concurrency() / 2;
+    if (n_help > 8) n_help = 8;
+    if (const char* env = getenv("CW_PRODUCER_THREADS")) { const int v = atoi(env); if (v >= 1 && v <= 64) n_help = (unsigned)v; }
+    if (n_help < 1) n_help = 1;
     if (rc == CW_OK) {
+        struct PileRec { uint32_t tpl, tpl_len, n, np; size_t ov_off; int rc; std::vector<uint32_t> wp; };
+        struct Round { std::vector<PileRec> piles; std::vector<cw_overlap> ov; size_t used = 0; bool last = false; };
+        Round rounds[2];
+        const size_t round_piles = 512, round_overlaps = 1u << 17;
         std::vector<cw_overlap> ov(a->max_support ? a->max_support : 1);
-        std::vector<uint32_t> wp;
         Job* cur = new Job();
         auto push_job = [&]() {
             if (cur->wj.empty()) return true;
@@ -507,47 +526,99 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
             cur = new Job();
             return true;
         };
-        for (;;) {
-            uint32_t tpl = 0, tpl_len = 0, n = 0;
-            const double tp0 = now_ms();
-            rc = cw_paf_next_pile(paf, &tpl, &tpl_len, ov.data(), nullptr, (uint32_t)ov.size(), &n);
-            ms_parse += now_ms() - tp0;
-            if (rc != CW_OK) { fprintf(stderr, "[consent_amd] %s: %s (malformed line, a name missing from the read file, or a length that disagrees with it)\n", a->alignment_file, cw_strerror(rc)); break; }
-            if (n == 0) break;
-            if (tpl_len != sh.host_reads.read_len[tpl]) {
-                fprintf(stderr, "[consent_amd] %s states length %u for %s, the read file has %u\n", a->alignment_file, tpl_len, cw_read_index_name(index, tpl), sh.host_reads.read_len[tpl]);
-                rc = CW_E_INVALID;
-                break;
+        /* stage 1 (this thread): the next piles of the file */
+        auto read_round = [&](Round& r) -> int {
+            r.used = 0; r.ov.clear(); r.last = false;
+            while (r.used < round_piles && r.ov.size() < round_overlaps) {
+                uint32_t tpl = 0, tpl_len = 0, n = 0;
+                const double tp0 = now_ms();
+                const int prc = cw_paf_next_pile(paf, &tpl, &tpl_len, ov.data(), nullptr, (uint32_t)ov.size(), &n);
+                ms_parse += now_ms() - tp0;
+                if (prc != CW_OK) { fprintf(stderr, "[consent_amd] %s: %s (malformed line, a name missing from the read file, or a length that disagrees with it)\n", a->alignment_file, cw_strerror(prc)); return prc; }
+                if (n == 0) { r.last = true; break; }
+                if (tpl_len != sh.host_reads.read_len[tpl]) {
+                    fprintf(stderr, "[consent_amd] %s states length %u for %s, the read file has %u\n", a->alignment_file, tpl_len, cw_read_index_name(index, tpl), sh.host_reads.read_len[tpl]);
+                    return CW_E_INVALID;
+                }
+                if (r.used == r.piles.size()) r.piles.emplace_back();
+                PileRec& p = r.piles[r.used++];
+                p.tpl = tpl; p.tpl_len = tpl_len; p.n = n; p.np = 0; p.rc = CW_OK; p.ov_off = r.ov.size();
+                r.ov.insert(r.ov.end(), ov.begin(), ov.begin() + n);
             }
-            uint32_t np = 0;
+            return CW_OK;
+        };
+        /* stage 2 (helpers): window positions of every pile of a round */
+        auto positions = [&](Round& r) {
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                    if (i >= r.used) return;
+                    PileRec& p = r.piles[i];
+                    p.wp.resize(2 * ((size_t)p.tpl_len / (a->window_size - a->window_overlap) + 8));
+                    uint32_t np = 0;
+                    int wrc = cw_window_positions(p.tpl_len, r.ov.data() + p.ov_off, p.n, a->min_support, a->window_size, (int32_t)a->window_overlap, p.wp.data(), (uint32_t)(p.wp.size() / 2), &np);
+                    if (wrc == CW_E_CAPACITY) { p.wp.resize(2 * (size_t)np); wrc = cw_window_positions(p.tpl_len, r.ov.data() + p.ov_off, p.n, a->min_support, a->window_size, (int32_t)a->window_overlap, p.wp.data(), np, &np); }
+                    p.np = np; p.rc = wrc;
+                }
+            };
+            const unsigned nt = (unsigned)std::min<size_t>(n_help, (r.used + 15) / 16);
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto& t : th) t.join();
+        };
+        /* stage 3 (this thread): jobs, in pile order */
+        auto assemble = [&](Round& r) -> int {
+            for (size_t i = 0; i < r.used; ++i) {
+                PileRec& p = r.piles[i];
+                if (p.rc != CW_OK) return p.rc;
+                ++n_piles;
+                const uint32_t np = p.np, n = p.n;
+                if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
+                if (np > CW_MAX_BATCH_WINDOWS) { fprintf(stderr, "[consent_amd] %s has %u windows; one job holds at most %u\n", cw_read_index_name(index, p.tpl), np, CW_MAX_BATCH_WINDOWS); return CW_E_CAPACITY; }
+                if (!cur->wj.empty() && cur->wj.size() + np > CW_MAX_BATCH_WINDOWS && !push_job()) return CW_E_INTERNAL;
+                cw_stitch_read sr_{p.tpl, (uint32_t)cur->wj.size(), np};
+                const uint32_t ovl_first = (uint32_t)cur->ovl.size();
+                cur->ovl.insert(cur->ovl.end(), r.ov.begin() + (ptrdiff_t)p.ov_off, r.ov.begin() + (ptrdiff_t)(p.ov_off + n));
+                for (uint32_t w = 0; w < np; ++w) {
+                    cur->wj.push_back(cw_window_job{p.tpl, p.wp[2 * w], p.wp[2 * w + 1], ovl_first, n});
+                    cur->win_pos.push_back(p.wp[2 * w]); cur->win_pos.push_back(p.wp[2 * w + 1]);
+                }
+                cur->sr.push_back(sr_);
+                cur->cost += (uint64_t)np * (n + 1);
+                n_windows += np; n_overlaps += n;
+                if (cur->wj.size() >= per_job && !push_job()) return CW_E_INTERNAL;
+            }
+            return CW_OK;
+        };
+        int k = 0;
+        rc = read_round(rounds[0]);
+        while (rc == CW_OK) {
+            Round& r = rounds[k];
+            int rrc = CW_OK;
             const double tw0 = now_ms();
-            wp.resize(2 * ((size_t)tpl_len / (a->window_size - a->window_overlap) + 8));
-            rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), (uint32_t)(wp.size() / 2), &np);
-            if (rc == CW_E_CAPACITY) { wp.resize(2 * (size_t)np); rc = cw_window_positions(tpl_len, ov.data(), n, a->min_support, a->window_size, (int32_t)a->window_overlap, wp.data(), np, &np); }
-            ms_windows += now_ms() - tw0;
-            if (rc != CW_OK) break;
-            ++n_piles;
-            if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
-            if (np > CW_MAX_BATCH_WINDOWS) { fprintf(stderr, "[consent_amd] %s has %u windows; one job holds at most %u\n", cw_read_index_name(index, tpl), np, CW_MAX_BATCH_WINDOWS); rc = CW_E_CAPACITY; break; }
-            if (!cur->wj.empty() && cur->wj.size() + np > CW_MAX_BATCH_WINDOWS && !push_job()) break;
-            cw_stitch_read s{tpl, (uint32_t)cur->wj.size(), np};
-            const uint32_t ovl_first = (uint32_t)cur->ovl.size();
-            cur->ovl.insert(cur->ovl.end(), ov.begin(), ov.begin() + n);
-            for (uint32_t i = 0; i < np; ++i) {
-                cur->wj.push_back(cw_window_job{tpl, wp[2 * i], wp[2 * i + 1], ovl_first, n});
-                cur->win_pos.push_back(wp[2 * i]); cur->win_pos.push_back(wp[2 * i + 1]);
+            if (r.last && r.used == 0) break;
+            if (r.last) positions(r); /* nothing left to read beside it */
+            else {
+                std::thread helper([&] { positions(r); });
+                rrc = read_round(rounds[k ^ 1]);
+                helper.join();
             }
-            cur->sr.push_back(s);
-            cur->cost += (uint64_t)np * (n + 1);
-            n_windows += np; n_overlaps += n;
-            if (cur->wj.size() >= per_job && !push_job()) break;
+            ms_windows += now_ms() - tw0; /* includes the reading that ran beside it */
+            rc = assemble(r);
+            if (rc == CW_E_INTERNAL && sh.abort) { rc = CW_OK; break; } /* a worker failed: its error is reported below */
+            if (rc == CW_OK) rc = rrc;
+            if (r.last) break;
+            k ^= 1;
         }
-        if (rc == CW_OK) push_job();
+        if (rc == CW_OK && !sh.abort) push_job();
         delete cur;
         cw_paf_close(paf);
     } else {
         fprintf(stderr, "[consent_amd] cannot open %s\n", a->alignment_file);
     }
+    const double t_produced = now_ms();
     {
         std::lock_guard<std::mutex> lk(sh.mu);
         producer_done = true;
@@ -575,8 +646,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         }
     }
     if (getenv("CW_DRIVER_STATS")) { /* counters on stderr; stdout stays pure FASTA */
-        fprintf(stderr, "{\"workers\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
-                devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
+        fprintf(stderr, "{\"dry\": %s, \"producer_threads\": %u, \"ms_producer\": %.1f, \"workers\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
+                dry ? "true" : "false", n_help, t_produced - t_indexed, devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
                 t_indexed - t_begin, *std::max_element(ms_init.begin(), ms_init.end()), ms_parse, ms_windows, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
         for (size_t i = 0; i < workers.size(); ++i)
             fprintf(stderr, "%s{\"device\": %d, \"windows\": %llu, \"jobs\": %llu, \"ms_extract\": %.1f, \"ms_consensus\": %.1f, \"ms_stitch\": %.1f}", i ? ", " : "", workers[i].device,

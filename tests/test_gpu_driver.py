@@ -187,3 +187,60 @@ def test_ont_profile_read_set_end_to_end(tmp_path):
     got = correct_reads(fa, paf, None, devices=[0, 0], windows_per_batch=16, **prm)
     want = oracle_pipeline(fa, paf, **prm)
     assert got == want and len(got) > 30
+
+
+def _sub_paf(paf, dst, names):
+    keep = set(names)
+    with open(dst, "w") as f:
+        for line in open(paf):
+            if line.split("\t", 1)[0] in keep:
+                f.write(line)
+    return str(dst)
+
+
+@pytest.mark.timeout(1200)
+def test_config4_mid_scale_ont_correction_with_an_oracle_sample(tmp_path):
+    """BASELINE configs[3] above toy size: a 200 kbp genome under 30x ONT-profile reads (750 reads of ~8 kbp, ~14 000 windows, several jobs
+    over two engines) through bin/CONSENT-correction with the wrapper's argv; 20 of the reads are corrected by the oracle pipeline as well
+    (a read's record depends on its own pile only) and must come out byte-identical; the producer's helper threads do not change the FASTA."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_bench as pb
+
+    fa, paf, _, n_reads, n_ovl = pb.generate(str(tmp_path), 200000, 30, "ont")
+    assert n_reads == 750 and n_ovl > 30000
+    argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", fa, "-M", 150, "-p", "x"]
+    got, err = run_bin("CONSENT-correction", argv, env={"CW_DRIVER_STATS": "1", "CW_DEVICES": "0,0"})
+    recs = dict(zip((l[1:] for l in got.split("\n")[0::2] if l), got.split("\n")[1::2]))
+    assert len(recs) > 700
+    import json
+    st = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])
+    assert st["windows"] > 10000 and st["piles"] == 750
+    one, _ = run_bin("CONSENT-correction", argv, env={"CW_PRODUCER_THREADS": "1", "CW_DEVICES": "0"})
+    assert one == got
+    names = [f"r{i}" for i in range(0, 750, 38)][:20]
+    want = oracle_pipeline(fa, _sub_paf(paf, tmp_path / "sample.paf", names), min_support=3, max_support=150, window_size=500, mer_size=9, common_kmers=8, min_anchors=2,
+                           solid_thresh=4, window_overlap=50, max_msa=150)
+    assert len(want) >= 18
+    for n, s in want:
+        assert recs[n] == s, n
+
+
+@pytest.mark.timeout(1200)
+def test_config5_ten_contig_polishing_with_an_oracle_sample(tmp_path):
+    """BASELINE configs[4] above toy size: ten contigs of 20 kbp (3 % errors) polished with 30x reads, CONSENT-polish:197 argv
+    (maxSupport 20000: a window looks at every overlap of its contig); two of the contigs are polished by the oracle as well."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_bench as pb
+
+    fa, paf, ctg, n_reads, n_ovl = pb.generate(str(tmp_path), 200000, 30, "pacbio", polish=10)
+    argv = ["-a", paf, "-s", 1, "-S", 20000, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", ctg, "-R", fa, "-M", 150, "-p", "x"]
+    got, _ = run_bin("CONSENT-polishing", argv, env={"CW_DEVICES": "0,0"})
+    recs = dict(zip((l[1:] for l in got.split("\n")[0::2] if l), got.split("\n")[1::2]))
+    assert len(recs) == 10 and all(len(s) > 15000 for s in recs.values())
+    want = oracle_polish(ctg, fa, _sub_paf(paf, tmp_path / "sample.paf", ["ctg3", "ctg8"]), min_support=1, max_support=20000, window_size=500, mer_size=9, common_kmers=8,
+                         min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150)
+    assert [n for n, _ in want] == ["ctg3", "ctg8"]
+    for n, s in want:
+        assert recs[n] == s, n

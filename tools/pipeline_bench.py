@@ -50,26 +50,18 @@ def span(r, a, b):
     return s, max(e, s + 1)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--genome", type=int, default=400000)
-    ap.add_argument("--cov", type=int, default=30)
-    ap.add_argument("--profile", choices=sorted(MIX), default="pacbio")
-    ap.add_argument("--polish", type=int, default=0, help="number of contigs: polish them with the reads instead of correcting the reads")
-    ap.add_argument("--read-len", type=int, default=8000)
-    ap.add_argument("--reps", type=int, default=2)
-    args = ap.parse_args()
-    glen, rlen, mix = args.genome, args.read_len, MIX[args.profile]
-    rng = np.random.default_rng(7)
+def generate(d, glen, cov, profile, polish=0, rlen=8000, seed=7):
+    """Writes reads.fa, ovl.paf (and contigs.fa when polishing) under d; returns (reads, paf, contigs or None, n_reads, n_overlaps)."""
+    mix = MIX[profile]
+    rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, glen)
-    n_reads = glen * args.cov // rlen
+    n_reads = glen * cov // rlen
     reads = []
     for i in range(n_reads):
         ln = int(min(glen - 1, max(1000, rng.lognormal(np.log(rlen), 0.35))))
         g0 = int(rng.integers(0, glen - ln))
         s, pos = noisy(rng, genome[g0 : g0 + ln], 0.12, mix)
         reads.append((g0, g0 + ln, pos, bool(rng.random() < 0.5), s))
-    d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
     os.makedirs(d, exist_ok=True)
     fa, paf, ctg_fa = os.path.join(d, "reads.fa"), os.path.join(d, "ovl.paf"), os.path.join(d, "contigs.fa")
     lut = np.frombuffer(b"ACGT", np.uint8)
@@ -82,10 +74,10 @@ def main():
     order = np.argsort([r[0] for r in reads])
     starts = np.array([reads[i][0] for i in order])
     n_lines = 0
-    if args.polish:
-        cuts = np.linspace(0, glen, args.polish + 1).astype(int)
+    if polish:
+        cuts = np.linspace(0, glen, polish + 1).astype(int)
         contigs = []
-        for c in range(args.polish):
+        for c in range(polish):
             s, pos = noisy(rng, genome[cuts[c] : cuts[c + 1]], 0.03, (0.3, 0.3))
             contigs.append((int(cuts[c]), int(cuts[c + 1]), pos, False, s))
         with open(ctg_fa, "w") as f:
@@ -121,8 +113,41 @@ def main():
                     ts, te = span(t, a, b)
                     f.write(f"r{qi}\t{len(q[4])}\t{qs}\t{qe}\t{'+' if q[3] == t[3] else '-'}\tr{ti}\t{len(t[4])}\t{ts}\t{te}\t{int((b - a) * 0.76)}\t{b - a}\t60\n")
                     n_lines += 1
-    print(f"data set: genome {glen}, {n_reads} {args.profile} reads ({os.path.getsize(fa) / 1e6:.0f} MB), {n_lines} overlaps ({os.path.getsize(paf) / 1e6:.0f} MB)"
-          + (f", {args.polish} contigs" if args.polish else ""), flush=True)
+    return fa, paf, (ctg_fa if polish else None), n_reads, n_lines
+
+
+def replicate(fa, paf, copies):
+    """`copies` independent copies of a read-correction data set (reads r<i> become c<k>r<i>, piles refer to their own copy): the same
+    piles `copies` times over -- a larger job list for the scaling runs without minutes of simulation.  Returns the new (reads, paf)."""
+    if copies <= 1:
+        return fa, paf
+    d = os.path.dirname(fa)
+    fa2, paf2 = os.path.join(d, f"reads_x{copies}.fa"), os.path.join(d, f"ovl_x{copies}.paf")
+    rd, pf = open(fa, "rb").read(), open(paf, "rb").read()
+    with open(fa2, "wb") as f, open(paf2, "wb") as g:
+        for k in range(copies):
+            tag = b"c%d" % k
+            f.write(rd.replace(b">r", b">" + tag + b"r"))
+            g.write(tag + pf.replace(b"\tr", b"\t" + tag + b"r").replace(b"\nr", b"\n" + tag + b"r"))
+    return fa2, paf2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=400000)
+    ap.add_argument("--cov", type=int, default=30)
+    ap.add_argument("--profile", choices=sorted(MIX), default="pacbio")
+    ap.add_argument("--polish", type=int, default=0, help="number of contigs: polish them with the reads instead of correcting the reads")
+    ap.add_argument("--read-len", type=int, default=8000)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--copies", type=int, default=1, help="read correction only: this many independent copies of the data set in one run")
+    args = ap.parse_args()
+    d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
+    fa, paf, ctg_fa, n_reads, n_lines = generate(d, args.genome, args.cov, args.profile, args.polish, args.read_len)
+    if not args.polish:
+        fa, paf = replicate(fa, paf, args.copies)
+    print(f"data set: genome {args.genome}, {n_reads} {args.profile} reads ({os.path.getsize(fa) / 1e6:.0f} MB), {n_lines} overlaps ({os.path.getsize(paf) / 1e6:.0f} MB)"
+          + (f", {args.polish} contigs" if args.polish else "") + (f", x{args.copies}" if args.copies > 1 else ""), flush=True)
 
     gpus = os.environ.get("CW_BENCH_GPUS", "1")
     if args.polish:  # CONSENT-polish:197
