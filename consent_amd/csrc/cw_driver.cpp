@@ -514,6 +514,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         const size_t round_piles = 512, round_overlaps = 1u << 17;
         std::vector<cw_overlap> ov(a->max_support ? a->max_support : 1);
         Job* cur = new Job();
+        uint64_t job_cost_cap = 1ull << 26;
+        if (const char* env = getenv("CW_JOB_COST_CAP")) { const long long v = atoll(env); if (v >= 1) job_cost_cap = (uint64_t)v; } /* test aid */
         auto push_job = [&]() {
             if (cur->wj.empty()) return true;
             cur->seq = n_jobs_total;
@@ -577,7 +579,10 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
                 const uint32_t np = p.np, n = p.n;
                 if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
                 if (np > CW_MAX_BATCH_WINDOWS) { fprintf(stderr, "[consent_amd] %s has %u windows; one job holds at most %u\n", cw_read_index_name(index, p.tpl), np, CW_MAX_BATCH_WINDOWS); return CW_E_CAPACITY; }
-                if (!cur->wj.empty() && cur->wj.size() + np > CW_MAX_BATCH_WINDOWS && !push_job()) return CW_E_INTERNAL;
+                /* a job's extraction scratch is one descriptor per (window, overlap of its pile): polishing with -S 20000 looks at every
+                   overlap of the contig for every window (alignmentWindows.cpp:105), so jobs are also cut by that product -- 2^26
+                   descriptors = 1 GiB; only a single pile larger than that still makes a larger job (a read's windows are never split) */
+                if (!cur->wj.empty() && (cur->wj.size() + np > CW_MAX_BATCH_WINDOWS || cur->cost + (uint64_t)np * (n + 1) > job_cost_cap) && !push_job()) return CW_E_INTERNAL;
                 cw_stitch_read sr_{p.tpl, (uint32_t)cur->wj.size(), np};
                 const uint32_t ovl_first = (uint32_t)cur->ovl.size();
                 cur->ovl.insert(cur->ovl.end(), r.ov.begin() + (ptrdiff_t)p.ov_off, r.ov.begin() + (ptrdiff_t)(p.ov_off + n));

@@ -18,10 +18,14 @@ CS = json.load(open(os.path.join(HERE, "golden", "consensus_small.json")))
 
 @pytest.fixture(scope="module")
 def engines():
-    cache = {}
+    cache = {}  # at most four engines alive: an engine holds ~10 GB of POA slabs whatever the batch size, and the module uses two dozen parameter sets
 
     def get(*prm):
-        if prm not in cache:
+        if prm in cache:
+            cache[prm] = cache.pop(prm)  # most recently used last
+        else:
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache))).close()
             cache[prm] = ca.Engine(ca.Params(*prm))
         return cache[prm]
 
