@@ -327,12 +327,12 @@ def main():
     alone_avg = {k: float(np.mean(v)) for k, v in alone_ms.items()}
     # The dominant kernel is the one that does the largest share of the work, by the wave-cycles the POA kernels count themselves
     # (cw_debug_profile; the tier kernels run side by side between one fork and one join, so wall time does not tell them apart).
-    tier_stage = ["poa", "poa_m1", "poa_m2", "poa_large"]
+    tier_stage = ["poa", "poa_m1", "poa_m2", "poa_large", "poa_q", "poa_h"]  # wave-cycles per tier kernel (tiers Q and H: as the first task of each wave saw them)
     busy_share = None
     _, prof = eng.profile()
-    busy = [float(prof[8 + 5 * t : 13 + 5 * t].sum()) for t in range(4)]
+    busy = [float(prof[8 + 5 * t : 13 + 5 * t].sum()) for t in range(4)] + [float(prof[28:33].sum()), float(prof[64:69].sum())]
     if sum(busy) > 0:
-        busy_share = {tier_stage[t]: busy[t] / sum(busy) for t in range(4)}
+        busy_share = {tier_stage[t]: busy[t] / sum(busy) for t in range(6)}
     dom = max(busy_share, key=busy_share.get) if busy_share else (max((k for k in alone_avg if k != "total"), key=alone_avg.get) if alone_avg else None)
     total_windows = n_win * world * args.steps
     value = total_windows / dt
@@ -523,9 +523,10 @@ def main():
     if rank == 0 and os.environ.get("CW_PROFILE"):
         ctr, prof = eng.profile()
         names = ["idx.count", "idx.exact", "idx.export", "idx.support", "idx.cand+P", "idx.chain", "idx.segments", "idx.tplhash"]
-        for tname in ("S", "M1", "M2", "L", "G"):
+        for tname in ("S", "M1", "M2", "L", "Q"):
             names += [f"{tname}.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
-        print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier", ctr[6:11].tolist(), "outgrew into tier", ctr[16:21].tolist(), file=sys.stderr)
+        names += ["-"] * (64 - len(names)) + [f"H.{x}" for x in ("meta", "fill", "trace", "merge", "cons")]
+        print("tasks", int(ctr[0]), "members", int(ctr[1]), "routed per tier (Q, M1, M2, L, G, H)", ctr[6:12].tolist(), "outgrew into tier (S, M1, M2, L, G, H)", ctr[18:24].tolist(), file=sys.stderr)
         print("phase Mcycles", {n: round(float(v) / 1e6, 2) for n, v in zip(names, prof) if n != "-"}, file=sys.stderr)
         print("chain kernel: windows", int(prof[44]), "mean anchors", float(prof[42]) / max(1, int(prof[44])), "mean dirty sequences", float(prof[43]) / max(1, int(prof[44])),
               "Mcycles: stage-in", round(float(prof[48]) / 1e6, 1), "(part of idx.chain) segment flush", round(float(prof[49]) / 1e6, 1), "(part of idx.segments)", file=sys.stderr)

@@ -21,6 +21,7 @@
 #include "cw_index.h"
 #include "cw_poa.h" /* tier capacities for the routing rule */
 #include "cw_poa_q.h"
+#include "cw_poa_h.h"
 
 #define CW_CH_WAVES 4
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
@@ -360,18 +361,22 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                        (a task that outgrows tier S is redone in tier L, the scarcest one) */
                     const uint32_t est_s = (e_mx * (15u + e_n / 5u) + 9u) / 10u;
                     /* tier Q (four tasks per wave, cw_poa_q.h): members of at most 31 bases and a graph that should stay small */
+                    /* tier H (two tasks per wave, cw_poa_h.h): members of 32 .. 63 bases, graph expected to stay inside 128 nodes */
+                    const bool fits_h = sc.use_h != 0u && e_mx <= (uint32_t)CW_POAH_LC && e_mx >= sc.h_min_len && est <= (uint32_t)CW_POAH_ROUTE_NODES;
+                    const bool fits_s = (est_s + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est_s <= (uint32_t)CW_POA_NC;
                     const uint32_t tier = !poa ? 0xFFu
                                           : (sc.use_q && e_mx <= (uint32_t)CW_POAQ_LC && est_s <= (uint32_t)CW_POAQ_ROUTE_NODES) ? 4u
-                                          : ((est_s + 1) * (e_mx + 1) <= (uint32_t)CW_POA_HC && est_s <= (uint32_t)CW_POA_NC) ? 0u
+                                          : (fits_h && (sc.use_h > 1u || !fits_s)) ? 5u
+                                          : fits_s ? 0u
                                           : (est <= (uint32_t)CW_POAM1_ROUTE && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
                                           : (est <= (uint32_t)CW_POAM2_ROUTE && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long pm = __ballot(poa);
-                    const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u), tmq = __ballot(tier == 4u);
+                    const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u), tmq = __ballot(tier == 4u), tmh = __ballot(tier == 5u);
                     const int minc = cw_wave_scan_add(poa ? (int)e_n : 0);
                     const uint32_t m_total = (uint32_t)cw_lane_value(minc, 63);
-                    uint32_t tb = 0, mb = 0, b1 = 0, b2 = 0, b3 = 0, bq = 0;
+                    uint32_t tb = 0, mb = 0, b1 = 0, b2 = 0, b3 = 0, bq = 0, bh = 0;
                     if (lane == 0 && pm) {
                         tb = atomicAdd(&sc.ctr->n_tasks, (uint32_t)__popcll(pm));
                         mb = atomicAdd(&sc.ctr->n_members, m_total);
@@ -379,13 +384,15 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         if (tm2) b2 = atomicAdd(&sc.ctr->n_tier[2], (uint32_t)__popcll(tm2));
                         if (tm3) b3 = atomicAdd(&sc.ctr->n_tier[3], (uint32_t)__popcll(tm3));
                         if (tmq) bq = atomicAdd(&sc.ctr->n_tier[0], (uint32_t)__popcll(tmq));
+                        if (tmh) bh = atomicAdd(&sc.ctr->n_tier[5], (uint32_t)__popcll(tmh));
                     }
                     tb = (uint32_t)cw_lane_value((int)tb, 0); mb = (uint32_t)cw_lane_value((int)mb, 0);
                     b1 = (uint32_t)cw_lane_value((int)b1, 0); b2 = (uint32_t)cw_lane_value((int)b2, 0); b3 = (uint32_t)cw_lane_value((int)b3, 0);
-                    bq = (uint32_t)cw_lane_value((int)bq, 0);
+                    bq = (uint32_t)cw_lane_value((int)bq, 0); bh = (uint32_t)cw_lane_value((int)bh, 0);
                     const bool cap_ok = (uint64_t)tb + (uint32_t)__popcll(pm) <= sc.task_cap && (uint64_t)mb + m_total <= sc.member_cap &&
                                         b1 + (uint32_t)__popcll(tm1) <= sc.list_cap && b2 + (uint32_t)__popcll(tm2) <= sc.list_cap &&
-                                        b3 + (uint32_t)__popcll(tm3) <= sc.list_cap && bq + (uint32_t)__popcll(tmq) <= sc.list_cap;
+                                        b3 + (uint32_t)__popcll(tm3) <= sc.list_cap && bq + (uint32_t)__popcll(tmq) <= sc.list_cap &&
+                                        bh + (uint32_t)__popcll(tmh) <= sc.list_cap;
                     if (!cap_ok) {
                         /* The counters have advanced and are never rolled back; consumers clamp them to the capacities and walk every slot
                            below.  Whatever this flush reserved inside a capacity is therefore given a neutral content -- a finished task
@@ -395,12 +402,13 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         const uint32_t n_t = (uint32_t)__popcll(pm);
                         for (uint32_t x = lane; x < n_t; x += 64)
                             if ((uint64_t)tb + x < sc.task_cap) { PoaTask t; t.window = w; t.seg_slot = seg_base; t.member_off = 0; t.n_members = 0; t.max_len = 0; t.out_off = 0; t.out_cap = 0; t.state = 1u; sc.tasks[tb + x] = t; }
-                        const uint32_t lb[4] = {bq, b1, b2, b3};
-                        const unsigned long long lm[4] = {tmq, tm1, tm2, tm3};
-                        for (int li = 0; li < 4; ++li) {
+                        const uint32_t lb[5] = {bq, b1, b2, b3, bh};
+                        const unsigned long long lm[5] = {tmq, tm1, tm2, tm3, tmh};
+                        const int lt[5] = {0, 1, 2, 3, 5};
+                        for (int li = 0; li < 5; ++li) {
                             const uint32_t n_l = (uint32_t)__popcll(lm[li]);
                             for (uint32_t x = lane; x < n_l; x += 64)
-                                if ((uint64_t)lb[li] + x < sc.list_cap) sc.tier_list[li][lb[li] + x] = sc.task_cap;
+                                if ((uint64_t)lb[li] + x < sc.list_cap) sc.tier_list[lt[li]][lb[li] + x] = sc.task_cap;
                         }
                     }
                     else {
@@ -417,6 +425,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             else if (tier == 2u) sc.tier_list[2][b2 + (uint32_t)__popcll(tm2 & below)] = t_idx;
                             else if (tier == 3u) sc.tier_list[3][b3 + (uint32_t)__popcll(tm3 & below)] = t_idx;
                             else if (tier == 4u) sc.tier_list[0][bq + (uint32_t)__popcll(tmq & below)] = t_idx;
+                            else if (tier == 5u) sc.tier_list[5][bh + (uint32_t)__popcll(tmh & below)] = t_idx;
                             sc.seg_off[t.seg_slot] = t.out_off; sc.seg_len[t.seg_slot] = 0;
                         }
                         /* the wave-wide part, entry by entry: member lists (coalesced matrix rows) and long single pieces */

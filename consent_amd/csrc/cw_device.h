@@ -73,7 +73,9 @@ struct PoaMember {
     uint16_t len;
 };
 
-#define CW_TIERS 5 /* POA memory tiers: 0 = S (LDS), 1 = M1, 2 = M2, 3 = L (graph in LDS, matrix in a slab), 4 = G (all global) */
+#define CW_TIERS 6 /* POA memory tiers: 0 = S (LDS), 1 = M1, 2 = M2, 3 = L (graph in LDS, matrix in a slab), 4 = G (all global), 5 = H (two tasks per wave,
+                      cw_poa_h.h); list 0 is tier Q's (four tasks per wave, cw_poa_q.h) */
+#define CW_PROF_SLOTS 72
 
 /* Batch-wide counters (one struct in scratch, zeroed before every run). */
 struct BatchCounters {
@@ -89,7 +91,7 @@ struct BatchCounters {
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
-    unsigned long long prof[64];  /* cycle totals per phase (0-32), longest single task per POA tier (36-40), see cw_debug_profile */
+    unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile */
 };
 
 struct DevBatch {
@@ -131,6 +133,8 @@ struct DevScratch {
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
+    uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1; 2 = also what tier S would take (CW_TIER_H) */
+    uint32_t h_min_len;            /* shortest "longest member" tier H takes (CW_H_MIN_LEN, default CW_POAH_MIN_LEN) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */
 };

@@ -9,6 +9,7 @@
 #include "cw_chain.h"
 #include "cw_poa.h"
 #include "cw_poa_q.h"
+#include "cw_poa_h.h"
 #include "cw_finish.h"
 #include "cw_extract.h"
 #include "cw_stitch.h"
@@ -63,6 +64,7 @@ void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
     t[2] = {(uint32_t)cus * 5 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
     t[3] = {(uint32_t)cus * 5 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
     t[4] = {big_slots, big_slab_bytes()};
+    t[5] = {(uint32_t)cus * 6 * 2 * CW_POAH_WAVES, CW_POAH_SLAB_BYTES}; /* tier H: a slab per 32-lane half, at most five work-groups of four halves per CU */
 }
 
 struct ScratchPlan {
@@ -145,6 +147,7 @@ int set_kernel_attributes() {
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_poa_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -321,7 +324,17 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.persist_wgs[4] = 0;
     const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
                    wgs_l = yield_wgs[3] + sc.persist_wgs[3];
-    sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2;
+    /* Tier H (two tasks per wave, cw_poa_h.h) is built, bit-identical to the oracle (tests/test_gpu_parity.py::test_tier_h_two_tasks_per_wave)
+       and OFF unless CW_TIER_H=1 (takes what would go to tier M1) or 2 (also what tier S would take): measured at depth 150 it costs 2.4 M
+       wave-cycles per task where tier M1 spends 3.1 M on the same tasks, but with its 8 waves per CU beside the other tiers the step is
+       slower (111 ms against 93 with one engine) -- DESIGN.md "Round 3".  Persistent work-groups of four halves, 29 KB of LDS each. */
+    sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
+    if (const char* env = getenv("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
+    if (const char* env = getenv("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
+    uint32_t wgs_h = 0;
+    if (sc.use_h) { uint32_t per_cu = 4; if (const char* env = getenv("CW_WGS_H")) { const int v = atoi(env); if (v >= 1 && v <= 5) per_cu = (uint32_t)v; } wgs_h = (uint32_t)cus * per_cu; }
+    sc.persist_wgs[5] = wgs_h;
+    sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2 + wgs_h;
     if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
     sc.use_q = getenv("CW_NO_TIER_Q") ? 0u : 1u;
@@ -346,7 +359,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
-    CW_HIP(hipMemsetAsync(base + p.sbusy[1], 0, p.sbusy[4] + (size_t)p.tier[4].slots * 4 - p.sbusy[1], st)); /* every slab free */
+    CW_HIP(hipMemsetAsync(base + p.sbusy[1], 0, p.sbusy[CW_TIERS - 1] + (size_t)p.tier[CW_TIERS - 1].slots * 4 - p.sbusy[1], st)); /* every slab free */
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(db, sc, e->prm);
@@ -380,7 +393,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64, 1, (uint32_t)cus * 2);
     const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
     const uint32_t big_wgs = knob_u("CW_BIG_WGS", big_cap < 16 ? big_cap : 16, 1, big_cap);
-    cw_sort_tier_kernel<<<4, sort_thr, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tier Q: like with like */
+    cw_sort_tier_kernel<<<5, sort_thr, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tiers Q and H: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
     const char* ph_env = getenv("CW_PHASES");
@@ -396,6 +409,11 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         sid = stage_begin(e, e->side[1], "poa_m2");
         cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
         stage_end(e, e->side[1], sid);
+        if (wgs_h) {
+            sid = stage_begin(e, e->side[0], "poa_h");
+            cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
+            stage_end(e, e->side[0], sid);
+        }
         sid = stage_begin(e, e->side[0], "poa_m1");
         cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
         stage_end(e, e->side[0], sid);
@@ -417,6 +435,11 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, e->side[1], "poa_m2");
     cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
     stage_end(e, e->side[1], sid);
+    if (wgs_h) { /* tier H shares tier M1's stream (a stream of its own would be a fifth hardware queue per engine): H first, then what is left for M1 */
+        sid = stage_begin(e, e->side[0], "poa_h");
+        cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
+        stage_end(e, e->side[0], sid);
+    }
     sid = stage_begin(e, e->side[0], "poa_m1");
     cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
@@ -535,9 +558,9 @@ int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* pro
     CW_HIP(hipDeviceSynchronize());
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(counters26, &c, 26 * 4);
+    memcpy(counters26, &c, (6 + 4 * CW_TIERS) * 4); /* n_tasks .. any_overflow, then n_tier, next_tier, n_over, next_over [CW_TIERS] each: 30 words */
     if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] done_wgs %u any_overflow %u n_over[0] %u next_over[0] %u n_over[3] %u next_over[3] %u\n", c.done_wgs, c.any_overflow, c.n_over[0], c.next_over[0], c.n_over[3], c.next_over[3]);
-    memcpy(prof32, c.prof, sizeof(c.prof)); /* 64 entries */
+    memcpy(prof32, c.prof, sizeof(c.prof)); /* CW_PROF_SLOTS = 72 entries */
     return CW_OK;
 }
 

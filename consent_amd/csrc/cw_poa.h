@@ -892,9 +892,9 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 if (c1 > tc) { top = 1; tc = c1; }
                 if (c2 > tc) { top = 2; tc = c2; }
                 if (c3 > tc) { top = 3; tc = c3; }
-                if (!(gaps > tc)) {
+                if (!CW_CONS_DROPS(gaps, tc)) { /* cw_policy.h "switches" */
                     const int tplc = tpl_code == 0 ? c0 : tpl_code == 1 ? c1 : tpl_code == 2 ? c2 : tpl_code == 3 ? c3 : -1;
-                    if (tplc == tc) top = tpl_code;
+                    if (CW_CONS_TEMPLATE_WINS_TIES && tplc == tc) top = tpl_code;
                     emit = top;
                 }
             }
@@ -1123,7 +1123,7 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t l
         const uint32_t nm = n_members >> 3;
         return (CW_SORT_CLASSES - 1) - ((max_len < 32u ? max_len : 31u) * 4u + (nm < 3u ? nm : 3u));
     }
-    if (tier == 1) {
+    if (tier == 1 || tier == 5) { /* tier H: the two tasks of a wave advance in lock step, so neighbours in the list should be alike as well */
         c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;
     } else {
         /* fitted on the task timeline of a depth-150 batch (tools/task_trace.py, CW_FIT): tier L time ~ members^1.76 x mean length^0.84 x
@@ -1140,7 +1140,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
     __shared__ uint32_t cnt[16][CW_SORT_CLASSES];
     __shared__ uint32_t tot_c[CW_SORT_CLASSES];
     extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* lds_cls bytes (<= CW_SORT_LDS_CLS) */
-    const int tier = blockIdx.x == 3 ? 0 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list */
+    const int tier = blockIdx.x == 3 ? 0 : blockIdx.x == 4 ? 5 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list, 5 = tier H's */
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
     const uint32_t nthr = blockDim.x, nwv = nthr >> 6; /* 4 .. 16 waves: a small work-group finds room beside another batch's persistent kernels */

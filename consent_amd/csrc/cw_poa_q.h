@@ -381,9 +381,9 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                 if (c1 > tc) { top = 1; tc = c1; }
                 if (c2 > tc) { top = 2; tc = c2; }
                 if (c3 > tc) { top = 3; tc = c3; }
-                if (!(gaps > tc)) {
+                if (!CW_CONS_DROPS(gaps, tc)) { /* cw_policy.h "switches" */
                     const int tplc = tpl_code == 0 ? c0 : tpl_code == 1 ? c1 : tpl_code == 2 ? c2 : tpl_code == 3 ? c3 : -1;
-                    if (tplc == tc) top = tpl_code;
+                    if (CW_CONS_TEMPLATE_WINS_TIES && tplc == tc) top = tpl_code;
                     emit = top;
                 }
             }

@@ -74,7 +74,8 @@ class SynthSpec(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libconsent_amd.so")
+    """The in-tree library; CONSENT_AMD_LIB names another build of the same sources (tests/test_gpu_policy.py: a non-default policy)."""
+    return os.environ.get("CONSENT_AMD_LIB") or os.path.join(_HERE, "libconsent_amd.so")
 
 
 _LIB = None
@@ -512,8 +513,8 @@ class Engine:
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
     def profile(self):
-        c = np.zeros(26, np.uint32)
-        p = np.zeros(64, np.uint64)
+        c = np.zeros(30, np.uint32)  # n_tasks, n_members, 3 cursors, any_overflow, then n_tier / next_tier / n_over / next_over for the six tiers
+        p = np.zeros(72, np.uint64)  # phase cycle totals (cw_device.h BatchCounters::prof)
         _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
         return c, p
 

@@ -47,6 +47,50 @@
 /* Otherwise the most frequent base; ties -> the template's base if tied for the top, else the       */
 /* smallest code (A<C<G<T).                                                                          */
 
+/* --- switches ------------------------------------------------------------------------------- */
+/* Policies with more than one defensible reading are build-time switches that BOTH sides honour     */
+/* (-DNAME=value for oracle/ and for consent_amd/csrc/; tests/test_gpu_policy.py builds both with a   */
+/* non-default consensus and checks that they still agree with each other and differ from the        */
+/* default).  A value that is named here but not implemented stops the build on both sides.          */
+#define CW_POA_MODE_NW 0 /* global alignment of the segment against the graph (implemented)          */
+#define CW_POA_MODE_SW 1 /* local                                                                     */
+#define CW_POA_MODE_OV 2 /* semi-global / overlap                                                     */
+#ifndef CW_POA_MODE
+#define CW_POA_MODE CW_POA_MODE_NW
+#endif
+#define CW_POA_CONSENSUS_MAJORITY 0        /* column-majority vote over the MSA (implemented)        */
+#define CW_POA_CONSENSUS_HEAVIEST_BUNDLE 1 /* spoa's heaviest bundle                                  */
+#ifndef CW_POA_CONSENSUS
+#define CW_POA_CONSENSUS CW_POA_CONSENSUS_MAJORITY
+#endif
+#define CW_CONS_TIE_TEMPLATE 0 /* equally frequent bases in a column -> the template's if among them, else the smallest code */
+#define CW_CONS_TIE_SMALLEST 1 /* -> the smallest code (A<C<G<T)                                      */
+#ifndef CW_POA_CONS_TIE
+#define CW_POA_CONS_TIE CW_CONS_TIE_TEMPLATE
+#endif
+#define CW_CONS_GAP_STRICT 0   /* a column is dropped iff gaps > every base count                     */
+#define CW_CONS_GAP_TIE_DROPS 1 /* ... iff gaps >= the largest base count                             */
+#ifndef CW_POA_CONS_GAP
+#define CW_POA_CONS_GAP CW_CONS_GAP_STRICT
+#endif
+#define CW_CHAIN_TIE_SMALLEST_SUCCESSOR 0 /* equal length and score -> the smallest successor index (implemented) */
+#define CW_CHAIN_TIE_LARGEST_SUCCESSOR 1
+#ifndef CW_CHAIN_TIE
+#define CW_CHAIN_TIE CW_CHAIN_TIE_SMALLEST_SUCCESSOR
+#endif
+#define CW_SEG_MISSING_ANCHOR_DROP 0 /* a sequence lacking an anchor of a segment is left out of that segment (implemented) */
+#define CW_SEG_MISSING_ANCHOR_EXTRAPOLATE 1
+#ifndef CW_SEG_MISSING_ANCHOR
+#define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
+#endif
+#if CW_POA_MODE != CW_POA_MODE_NW || CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY || CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || \
+    CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
+#error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
+#endif
+/* the column vote, one place for both sides: drop the column? / take the template's base on a tie? */
+#define CW_CONS_DROPS(gaps, top_count) (CW_POA_CONS_GAP == CW_CONS_GAP_STRICT ? (gaps) > (top_count) : (gaps) >= (top_count))
+#define CW_CONS_TEMPLATE_WINS_TIES (CW_POA_CONS_TIE == CW_CONS_TIE_TEMPLATE)
+
 /* --- anchor index (A4a) --------------------------------------------------------------------- */
 /* A k-mer occurring twice inside ANY single sequence of the pile is never an anchor.            */
 /* A k-mer must occur in at least `anchor_support` distinct sequences (compared as                */

@@ -277,8 +277,8 @@ struct PoaGraph {
             const int gaps = n_sequences - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
             int top = 0;
             for (int c = 1; c < 4; ++c) if (cnt[c] > cnt[top]) top = c;
-            if (!(gaps > cnt[top])) {
-                if (tpl_code != -1 && cnt[tpl_code] == cnt[top]) top = tpl_code;
+            if (!CW_CONS_DROPS(gaps, cnt[top])) { /* cw_policy.h "switches" */
+                if (CW_CONS_TEMPLATE_WINS_TIES && tpl_code != -1 && cnt[tpl_code] == cnt[top]) top = tpl_code;
                 out.push_back("ACGT"[top]);
             }
             r += width;

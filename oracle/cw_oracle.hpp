@@ -54,7 +54,7 @@ std::string revcomp(const std::string& s);            /* reverseComplement.cpp:6
 bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anchor_support, unsigned min_anchors,
                    unsigned max_msa, std::string& consensus, KmerCounts& counts, Stats* st);
 
-/* A4d alone (one segment): POA + heaviest bundle over `seqs` in order. */
+/* A4d alone (one segment): POA over `seqs` in order + the column-majority consensus of cw_policy.h (CW_POA_CONSENSUS). */
 std::string poa_consensus(const std::vector<std::string>& seqs, Stats* st);
 
 /* A5 */ std::string weight_consensus(std::string cons, const KmerCounts& counts, unsigned k, unsigned solid);

@@ -238,6 +238,44 @@ def test_long_and_outlier_segments_exercise_all_tiers(engines):
     assert_same(got, exp, len(piles), "tiers")
 
 
+def test_tier_h_two_tasks_per_wave(engines, monkeypatch):
+    """Tier H (cw_poa_h.h): segments whose longest member has 32..63 bases, two tasks per wave on 32-lane halves, traceback over
+    direction words.  Windows with few anchors give such segments; deep piles make nodes with many predecessors (the ordinal of the
+    direction bytes covers four, the rest is decided from the cell values); CW_TIER_H=1 sends it what tier M1 would take, 2 also the
+    tasks of tier S, 0 (the default) nothing -- the consensus never depends on the tier."""
+    rng = random.Random(29)
+    piles = []
+    for depth, rate, k_gap in ((24, 0.14, 40), (60, 0.16, 55), (150, 0.12, 48), (12, 0.2, 60)):
+        truth = rand_seq(rng, 520)
+        tpl = list(mutate(rng, truth[:500], 0.05))
+        # anchors only every k_gap bases: in between, the template is scrambled so that no 9-mer of it is shared
+        for a in range(0, 500, k_gap):
+            for x in range(a + 14, min(a + k_gap - 2, len(tpl)), 3):
+                tpl[x] = rng.choice("ACGT")
+        piles.append(["".join(tpl)] + [mutate(rng, truth[:500], rate) for _ in range(depth)])
+    prm = (9, 4, 8, 2, 150)
+    hb = ca.pack_piles(piles)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
+    e = engines(*prm)
+    monkeypatch.setenv("CW_TIER_H", "1")  # the tier is off by default (DESIGN.md "Round 3": correct, not faster)
+    got = e.run(hb)
+    ctr, _ = e.profile()
+    assert int(ctr[11]) > 0, ctr[6:12]  # tasks routed to tier H
+    assert_same(got, exp, len(piles), "tier H")
+    for mode in ("2", "0"):
+        monkeypatch.setenv("CW_TIER_H", mode)
+        got = e.run(hb)
+        ctr2, _ = e.profile()
+        assert (int(ctr2[11]) >= int(ctr[11])) if mode == "2" else int(ctr2[11]) == 0
+        assert_same(got, exp, len(piles), f"CW_TIER_H={mode}")
+    monkeypatch.delenv("CW_TIER_H")
+    hb2 = synth_host(ca.SynthSpec.pacbio(96, 150, first_window=7000))
+    exp2, _ = oracle_lib.oracle_run(ca.Params(*prm), hb2, threads=os.cpu_count() or 1)
+    monkeypatch.setenv("CW_TIER_H", "2")
+    monkeypatch.setenv("CW_H_MIN_LEN", "8")  # nearly everything that is not tier Q's
+    assert_same(e.run(hb2), exp2, 96, "depth 150, tier H for every task it can hold")
+
+
 def test_empty_batch_and_capacity_overflow(engines):
     e = engines(9, 4, 8, 2, 20)
     lib = e.lib

@@ -1,0 +1,59 @@
+"""GPU: the switches of include/cw_policy.h are live on BOTH sides.  The engine and the oracle are built once more with a non-default
+column vote (-DCW_POA_CONS_TIE=1 -DCW_POA_CONS_GAP=1: ties go to the smallest code instead of the template's base, a column whose gap
+count equals its best base count is dropped), into a scratch directory; under that policy the HIP engine and the oracle still agree
+window by window, and their consensus differs from the default policy's on the same piles -- so neither side ignores the switch."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POLICY = ["-DCW_POA_CONS_TIE=1", "-DCW_POA_CONS_GAP=1"]
+
+CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import consent_amd as ca
+from consent_amd.engine import synth_host
+import oracle_lib
+prm = ca.Params(9, 4, 8, 2, 150)
+h = hashlib.sha256()
+same = True
+for depth, n in ((150, 24), (30, 64), (12, 48)):
+    hb = synth_host(ca.SynthSpec.pacbio(n, depth, first_window=900))
+    eng = ca.Engine(prm)
+    got = eng.run(hb)
+    eng.close()
+    exp, _ = oracle_lib.oracle_run(prm, hb, threads=os.cpu_count() or 1)
+    for w in range(n):
+        same = same and got.consensus(w) == exp.consensus(w) and int(got.status[w]) == int(exp.status[w])
+        h.update(got.consensus(w).encode())
+print("RESULT", int(same), h.hexdigest())
+"""
+
+
+def run_child(env):
+    out = subprocess.run([sys.executable, "-c", CHILD, ROOT], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _, same, digest = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    return same == "1", digest
+
+
+@pytest.mark.timeout(1200)
+def test_non_default_consensus_policy_is_honoured_by_engine_and_oracle(tmp_path):
+    from consent_amd import _build
+
+    alt_lib = str(tmp_path / "libconsent_amd_policy.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *POLICY, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(POLICY)])
+    same_default, digest_default = run_child({})
+    same_alt, digest_alt = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_alt            # engine == oracle under either policy
+    assert digest_default != digest_alt         # and the policy changes the consensus
+    # mixing the two sides must disagree somewhere: the switch is live on each side separately
+    mixed1, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    mixed2, _ = run_child({"CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert not mixed1 and not mixed2
