@@ -161,7 +161,10 @@ int set_kernel_attributes() {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess)
+        hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_STN_QMAX, CW_STN_RMAX, 5, CW_STN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX)) != hipSuccess)
         return CW_E_NO_DEVICE;
     return CW_OK;
 }
@@ -749,17 +752,32 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     a.solid = res->solid; a.solid_off = res->solid_off; a.solid_len = res->solid_len;
     a.window_size = window_size; a.window_overlap = window_overlap; a.mer_size = e->prm.k; a.do_trim = do_trim;
     a.out = out; a.out_off = out_off; a.out_len = out_len; a.read_status = read_status; a.cursor = (uint32_t*)e->xscratch;
-    const size_t lds = (size_t)CW_ST_WAVES * CW_ST_SLAB;
+    const size_t lds = (size_t)CW_ST_WAVES * CW_ST_SLAB, lds_n = (size_t)CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX);
     uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
     if (wgs > CW_ST_MAX_WGS) wgs = CW_ST_MAX_WGS;
+    /* the narrow kernel holds four work-groups of four waves per CU (29 KB of LDS each, <= 128 VGPRs) */
+    const int cus_st = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    uint32_t wgs_n = (n_reads + CW_STN_WAVES - 1) / CW_STN_WAVES;
+    if (wgs_n > (uint32_t)cus_st * 4u) wgs_n = (uint32_t)cus_st * 4u;
+    /* Opt-in (CW_STITCH_NARROW=1).  Measured on the E. coli-scale ONT-profile set (10 jobs of 32768 windows, rocprofv3): the narrow kernel takes
+       63 ms per job where the wide one takes ~75 -- a launch lasts as long as its longest read's serial chain of windows (a 30 kbp read: 66
+       windows), which twice the resident waves do not shorten -- and the reads it hands on (a consensus above 640 in any of their windows)
+       cost a second such tail, 51 ms: 114 ms per job against 75.  DESIGN.md "Round 3". */
+    const bool narrow = getenv("CW_STITCH_NARROW") && (uint64_t)window_size + 2ull * window_overlap <= CW_STN_RMAX;
+    const uint32_t wgs_max = narrow && wgs_n > wgs ? wgs_n : wgs;
     /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
     a.dir_bytes = getenv("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(getenv("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
     if (a.dir_bytes < 64) a.dir_bytes = 64;
-    rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs * CW_ST_WAVES * a.dir_bytes);
+    rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs_max * CW_ST_WAVES * a.dir_bytes);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
-    cw_stitch_kernel<<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
+    if (narrow) {
+        cw_stitch_kernel<CW_STN_QMAX, CW_STN_RMAX, 5, CW_STN_WAVES, false><<<wgs_n, 64 * CW_STN_WAVES, lds_n, st>>>(a);
+        cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a); /* the reads it marked (normally none) */
+    } else {
+        cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
+    }
     CW_HIP(hipGetLastError());
     return CW_OK;
 }

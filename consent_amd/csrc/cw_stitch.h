@@ -216,7 +216,10 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     return best;
 }
 
+template <int NCHK>
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
+    /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
+    if constexpr (NCHK <= 8) return st_sweep_pk<NCHK>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
     /* Two instantiations: eight chunks for consensuses up to 1024 positions (every 500-base window), sixteen beyond; chunks beyond the
        query are skipped by a scalar branch.  Round 1 had 4-, 8- and 16-chunk variants side by side and the 8-chunk one returned garbage
        rows on gfx950 (ROCm 7.2 hipcc), each of them alone being correct; this pair is clean (tests/test_gpu_stitch.py::
@@ -325,18 +328,19 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
 struct StAlign { int score, ref_begin, ref_end, query_begin, query_end; };
 
 /* full alignment: forward sweep, reverse sweep.  qfw = query codes; qrv = scratch for the reversed prefix. */
+template <int NCHK>
 __device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane) {
     StAlign a{0, 0, -1, 0, -1};
     m = st_uni(m); n = st_uni(n);
     if (m <= 0 || n <= 0) return a;
-    const StSweep fw = st_sweep_any(qfw, m, ref, 0, n, 1, -1, lane);
+    const StSweep fw = st_sweep_any<NCHK>(qfw, m, ref, 0, n, 1, -1, lane);
     a.score = fw.score;
     if (fw.score <= 0) return a;
     a.ref_end = fw.col; a.query_end = fw.row;
     const int pm = fw.row + 1;
     for (int x = lane; x < pm; x += 64) qrv[x] = qfw[fw.row - x];
     st_mem_sync();
-    const StSweep bw = st_sweep_any(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
+    const StSweep bw = st_sweep_any<NCHK>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
 }
@@ -372,23 +376,35 @@ __global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
     for (uint32_t i = threadIdx.x; i < a.n_reads; i += 1024) a.order[atomicAdd(&hist[min(a.jobs[i].win_count, 1023u)], 1u)] = i;
 }
 
-__global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs a) {
+/* Two instantiations: the NARROW one (consensus and read slice of at most 640 positions -- every window of the wrappers' defaults, 500 + 2 x 50 --
+   five packed chunks, 7.3 KB of LDS per wave, half the registers: twice the reads in flight per CU, and a read is a serial chain) runs over all
+   reads; a read that does not fit it (a longer consensus, a wider window) is marked CW_READ_REDO and taken by the WIDE one (2048 positions) in a
+   second launch.  REDO = this is that second launch: only marked reads. */
+#define CW_READ_REDO 0xFEu
+#define CW_ST_SLAB_OF(QMAX, RMAX) ((RMAX) + 2 * (QMAX) + CW_ST_ROWS_BYTES + 2 * (QMAX))
+#define CW_STN_QMAX 640
+#define CW_STN_RMAX 640
+#define CW_STN_WAVES 4
+template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO>
+__global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB;
-    uint8_t* refc = slab;                              /* CW_ST_RMAX codes of the aligned slice              */
-    uint8_t* cur = refc + CW_ST_RMAX;                  /* current consensus (chars), CW_ST_QMAX              */
-    uint8_t* old = cur + CW_ST_QMAX;                   /* previous window's consensus as written, CW_ST_QMAX */
-    uint8_t* rows = old + CW_ST_QMAX;                  /* CW_ST_ROWS_BYTES: the three int32 rows of the banded traceback */
-    uint8_t* qfw = rows + CW_ST_ROWS_BYTES;            /* CW_ST_QMAX query codes                              */
-    uint8_t* qrv = qfw + CW_ST_QMAX;                   /* CW_ST_QMAX reversed prefix / build area             */
-    int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * CW_ST_WAVES + wave) * a.dir_bytes;
+    const uint32_t too_big = REDO ? 2u : (uint32_t)CW_READ_REDO; /* the narrow kernel hands on what the wide one reports as a capacity */
+    uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB_OF(QMAX, RMAX);
+    uint8_t* refc = slab;                              /* RMAX codes of the aligned slice              */
+    uint8_t* cur = refc + RMAX;                        /* current consensus (chars), QMAX              */
+    uint8_t* old = cur + QMAX;                         /* previous window's consensus as written, QMAX */
+    uint8_t* rows = old + QMAX;                        /* CW_ST_ROWS_BYTES: the three int32 rows of the banded traceback */
+    uint8_t* qfw = rows + CW_ST_ROWS_BYTES;            /* QMAX query codes                              */
+    uint8_t* qrv = qfw + QMAX;                         /* QMAX reversed prefix / build area             */
+    int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * WAVES + wave) * a.dir_bytes;
     for (;;) {
         uint32_t ri = 0;
-        if (lane == 0) ri = atomicAdd(a.cursor, 1u);
+        if (lane == 0) ri = atomicAdd(a.cursor + (REDO ? 1 : 0), 1u);
         ri = (uint32_t)cw_lane_value((int)ri, 0);
         if (ri >= a.n_reads) break;
         ri = st_uni(a.order[ri]);
+        if (REDO && st_uni((uint32_t)a.read_status[ri]) != (uint32_t)CW_READ_REDO) continue;
         cw_stitch_read jb = a.jobs[ri];
         jb.read = st_uni(jb.read); jb.win_first = st_uni(jb.win_first); jb.win_count = st_uni(jb.win_count);
         const uint32_t rlen = st_uni(a.reads.read_len[jb.read]);
@@ -415,13 +431,13 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
             uint32_t clen = st_uni(a.cons_len[w]);
             const bool long_enough = clen >= a.mer_size;                      /* :75 / :98 / :125 */
             if (long_enough) {
-                if (clen > CW_ST_QMAX) { status = 2; break; }
+                if (clen > QMAX) { status = too_big; break; }
                 const char* src = a.cons + a.cons_off[w];
                 for (uint32_t x = lane; x < clen; x += 64) cur[x] = (uint8_t)src[x];
             } else {                                                          /* :76 the window's template */
                 const uint32_t ts = a.batch.win_first_seq[w];
                 clen = st_uni((a.batch.win_first_seq[w + 1] > ts) ? a.batch.seq_len[ts] : 0u);
-                if (clen > CW_ST_QMAX) { status = 2; break; }
+                if (clen > QMAX) { status = too_big; break; }
                 const uint32_t* tw = a.batch.bases + a.batch.seq_word_off[ts];
                 for (uint32_t x = lane; x < clen; x += 64) cur[x] = "ACGT"[cw_base_at(tw, x)];
             }
@@ -432,11 +448,11 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
             if ((uint64_t)al_pos + a.window_size + 2ull * a.window_overlap >= tot) size_al = (int)tot - al_pos;   /* :84-88 */
             else size_al = (int)(a.window_size + 2 * a.window_overlap);
             if (size_al <= 0 || clen == 0) continue;
-            if (size_al > CW_ST_RMAX) { status = 2; break; }
+            if (size_al > RMAX) { status = too_big; break; }
             for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
             st_mem_sync();
-            const StAlign al = st_align(qfw, (int)clen, qrv, refc, size_al, lane);                   /* :90 */
+            const StAlign al = st_align<NCHK>(qfw, (int)clen, qrv, refc, size_al, lane);                   /* :90 */
             if (a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
                 t[0] = (uint32_t)al_pos; t[1] = (uint32_t)size_al; t[2] = (uint32_t)al.score; t[3] = (uint32_t)al.ref_begin; t[4] = (uint32_t)al.ref_end;
@@ -477,7 +493,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
                             st_mem_sync();
-                            const StAlign sub = st_align(qfw, (int)overlap, qrv, refc, (int)overlap, lane);
+                            const StAlign sub = st_align<NCHK>(qfw, (int)overlap, qrv, refc, (int)overlap, lane);
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
@@ -486,7 +502,7 @@ __global__ void __launch_bounds__(64 * CW_ST_WAVES) cw_stitch_kernel(StitchArgs 
                             const uint32_t cut = overlap - ins + del;
                             if (cut < cl) {                                                                 /* :114-115 curCons = seq1 + curCons.substr(cut) */
                                 const uint32_t tail = cl - cut, nl = overlap + tail;
-                                if (nl > CW_ST_QMAX) { status = 2; break; }
+                                if (nl > QMAX) { status = too_big; break; }
                                 /* build in qrv (free now), then copy back */
                                 for (uint32_t x = lane; x < nl; x += 64) qrv[x] = x < overlap ? seq1[x] : cur[cut + (x - overlap)];
                                 st_mem_sync();

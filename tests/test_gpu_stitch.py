@@ -196,3 +196,12 @@ def test_stitch_capacity_path_reports_status_and_does_not_disturb_other_reads(mo
     assert any(st == 2 for _, st in small)
     for (g, st), (f, _) in zip(small, full):
         assert (st == 2 and g == "") or (st == 0 and g == f)
+
+
+def test_stitch_narrow_kernel_hands_long_consensuses_to_the_wide_one(monkeypatch):
+    """CW_STITCH_NARROW=1: the five-chunk kernel (consensus and slice <= 640) takes every read first; a read with a longer consensus in any window is
+    marked and redone by the wide kernel in a second launch -- same strings either way (the oracle's restatement decides)."""
+    monkeypatch.setenv("CW_STITCH_NARROW", "1")
+    test_stitch_long_consensuses_use_the_wide_sweeps()
+    got, n_up = run_case(make_reads(118, 40, 10, lo=600, hi=1800))
+    assert len(got) == 40 and n_up > 0
