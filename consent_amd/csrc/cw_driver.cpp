@@ -185,20 +185,49 @@ struct Worker {
         DRV_HIP(hipMemcpyAsync(pos.p, j.win_pos.data(), (size_t)n_win * 8, hipMemcpyHostToDevice, st), j, "H2D positions");
         DRV_HIP(hipMemcpyAsync(sr.p, j.sr.data(), (size_t)n_piles * sizeof(cw_stitch_read), hipMemcpyHostToDevice, st), j, "H2D reads");
 
-        /* ---- piles, cut on the device ---- */
-        uint32_t n_seqs = 0;
-        uint64_t n_words = 0;
-        int rc = cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>(), j.wj.data(), n_win, a.mer_size, nullptr, nullptr, nullptr,
-                                 nullptr, 0, 0, &n_seqs, &n_words, st);
-        if (rc != CW_OK && rc != CW_E_CAPACITY) { j.rc = rc; j.err = "cw_extract_piles_device (sizing)"; (void)hipStreamSynchronize(st); return; }
+        /* ---- piles, cut on the device ----
+           A job's windows are extracted in slices (the extraction keeps one descriptor per window and overlap of its pile: a slice stays
+           under 2^26 of them) into ONE batch in device memory -- every slice writes window -> sequence and sequence -> word offsets that
+           start at zero, which cw_add_offsets_device then moves to the slice's place -- and corrected in runs of at most CW_MAX_BATCH_WINDOWS
+           windows over that batch (a run names its windows by pointer; sequence indices and word offsets are the batch's), results into
+           one set of arrays planned for the whole job.  The re-assembly then walks each read's windows over the whole job, so a read --
+           or a contig of any length -- may span slices and runs.  (Usually: one slice, one run.) */
+        uint64_t desc_budget = 1ull << 26;
+        uint32_t run_windows = CW_MAX_BATCH_WINDOWS;
+        if (const char* env = getenv("CW_DRIVER_SLICE_DESC")) { const long long v = atoll(env); if (v >= 1) desc_budget = (uint64_t)v; }           /* test aids */
+        if (const char* env = getenv("CW_DRIVER_RUN_WINDOWS")) { const long v = atol(env); if (v >= 1 && v < (long)run_windows) run_windows = (uint32_t)v; }
+        struct Slice { uint32_t w0, w1, n_seqs; uint64_t n_words, seq_base, word_base; };
+        std::vector<Slice> slices;
+        uint64_t tot_seqs = 0, tot_words = 0;
+        for (uint32_t w0 = 0; w0 < n_win;) {
+            uint64_t d = 0;
+            uint32_t w1 = w0;
+            while (w1 < n_win && w1 - w0 < run_windows && (w1 == w0 || d + j.wj[w1].ovl_count + 1 <= desc_budget)) { d += j.wj[w1].ovl_count + 1; ++w1; }
+            Slice sl{w0, w1, 0, 0, tot_seqs, tot_words};
+            const int rc = cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>() + w0, j.wj.data() + w0, w1 - w0, a.mer_size, nullptr, nullptr,
+                                           nullptr, nullptr, 0, 0, &sl.n_seqs, &sl.n_words, st);
+            if (rc != CW_OK && rc != CW_E_CAPACITY) { j.rc = rc; j.err = "cw_extract_piles_device (sizing)"; (void)hipStreamSynchronize(st); return; }
+            tot_seqs += sl.n_seqs; tot_words += sl.n_words;
+            slices.push_back(sl);
+            w0 = w1;
+        }
+        if (tot_seqs > 0xFFFFFFF0ull) { j.rc = CW_E_CAPACITY; j.err = "more than 2^32 pile sequences in one job"; (void)hipStreamSynchronize(st); return; }
         DRV_RC(b_wfs.ensure((size_t)(n_win + 1) * 4), j, "device memory (batch)");
-        DRV_RC(b_len.ensure((size_t)n_seqs * 4 + 4), j, "device memory (batch)");
-        DRV_RC(b_off.ensure((size_t)n_seqs * 8 + 8), j, "device memory (batch)");
-        DRV_RC(b_bases.ensure((size_t)n_words * 4 + 8), j, "device memory (batch)");
-        DRV_HIP(hipMemsetAsync((uint8_t*)b_bases.p + (size_t)n_words * 4, 0, 8, st), j, "memset");
-        DRV_RC(cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>(), j.wj.data(), n_win, a.mer_size, b_wfs.as<uint32_t>(),
-                               b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>(), n_seqs, n_words, &n_seqs, &n_words, st),
-               j, "cw_extract_piles_device");
+        DRV_RC(b_len.ensure((size_t)tot_seqs * 4 + 4), j, "device memory (batch)");
+        DRV_RC(b_off.ensure((size_t)tot_seqs * 8 + 8), j, "device memory (batch)");
+        DRV_RC(b_bases.ensure((size_t)tot_words * 4 + 8), j, "device memory (batch)");
+        DRV_HIP(hipMemsetAsync((uint8_t*)b_bases.p + (size_t)tot_words * 4, 0, 8, st), j, "memset");
+        for (const Slice& sl : slices) {
+            uint32_t ns = 0; uint64_t nw = 0;
+            DRV_RC(cw_extract_impl(eng, &dev_reads, ovl.as<cw_overlap>(), j.ovl.size(), wj.as<cw_window_job>() + sl.w0, j.wj.data() + sl.w0, sl.w1 - sl.w0, a.mer_size,
+                                   b_wfs.as<uint32_t>() + sl.w0, b_len.as<uint32_t>() + sl.seq_base, b_off.as<uint64_t>() + sl.seq_base, b_bases.as<uint32_t>() + sl.word_base,
+                                   sl.n_seqs, sl.n_words, &ns, &nw, st),
+                   j, "cw_extract_piles_device");
+            DRV_RC(cw_add_offsets_device(b_wfs.as<uint32_t>() + sl.w0, (uint64_t)(sl.w1 - sl.w0) + 1, (uint32_t)sl.seq_base, b_off.as<uint64_t>() + sl.seq_base, sl.n_seqs, sl.word_base, st),
+                   j, "cw_add_offsets_device");
+        }
+        const uint32_t n_seqs = (uint32_t)tot_seqs;
+        const uint64_t n_words = tot_words;
         cw_batch batch{n_win, n_seqs, n_words, b_wfs.as<uint32_t>(), b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>()};
         const double t1 = now_ms();
 
@@ -214,7 +243,18 @@ struct Worker {
         DRV_RC(r_stat.ensure(n_win), j, "device memory (results)");
         DRV_HIP(hipMemsetAsync(r_stat.p, 0xFF, n_win, st), j, "memset");
         cw_result res{r_cons.as<char>(), r_coff.as<uint64_t>(), r_clen.as<uint32_t>(), r_stat.as<uint8_t>(), r_solid.as<uint32_t>(), r_soff.as<uint64_t>(), r_slen.as<uint32_t>()};
-        DRV_RC(cw_run_device(eng, &batch, &res, st), j, "cw_run_device");
+        for (size_t s0 = 0; s0 < slices.size();) { /* runs = whole slices, at most run_windows windows */
+            size_t s1 = s0 + 1;
+            while (s1 < slices.size() && slices[s1].w1 - slices[s0].w0 <= run_windows) ++s1;
+            const uint32_t w0 = slices[s0].w0, w1 = slices[s1 - 1].w1;
+            uint64_t rs = 0, rw = 0;
+            for (size_t x = s0; x < s1; ++x) { rs += slices[x].n_seqs; rw += slices[x].n_words; }
+            cw_batch run{w1 - w0, (uint32_t)rs, rw, b_wfs.as<uint32_t>() + w0, b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>()};
+            cw_result rres{r_cons.as<char>(), r_coff.as<uint64_t>() + w0, r_clen.as<uint32_t>() + w0, r_stat.as<uint8_t>() + w0, r_solid.as<uint32_t>(), r_soff.as<uint64_t>() + w0,
+                           r_slen.as<uint32_t>() + w0};
+            DRV_RC(cw_run_device(eng, &run, &rres, st), j, "cw_run_device");
+            s0 = s1;
+        }
 
         /* ---- re-assembly per read ---- */
         std::vector<uint64_t> out_off((size_t)n_piles + 1, 0);
@@ -578,7 +618,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
                 ++n_piles;
                 const uint32_t np = p.np, n = p.n;
                 if (np == 0) continue; /* processRead returns (readId, "") before anything else (CONSENT-correction.cpp:22-25) */
-                if (np > CW_MAX_BATCH_WINDOWS) { fprintf(stderr, "[consent_amd] %s has %u windows; one job holds at most %u\n", cw_read_index_name(index, p.tpl), np, CW_MAX_BATCH_WINDOWS); return CW_E_CAPACITY; }
+                /* (a read or contig with more windows than one engine call takes -- CW_MAX_BATCH_WINDOWS -- becomes a job of its own: the worker
+                   corrects it in several runs and re-assembles it once, Worker::process) */
                 /* a job's extraction scratch is one descriptor per (window, overlap of its pile): polishing with -S 20000 looks at every
                    overlap of the contig for every window (alignmentWindows.cpp:105), so jobs are also cut by that product -- 2^26
                    descriptors = 1 GiB; only a single pile larger than that still makes a larger job (a read's windows are never split) */

@@ -700,6 +700,22 @@ int cw_extract_impl(cw_engine* e, const cw_read_set* reads, const cw_overlap* ov
     return CW_OK;
 }
 
+__global__ void __launch_bounds__(256) cw_add_offsets_kernel(uint32_t* a32, uint64_t n32, uint32_t add32, uint64_t* a64, uint64_t n64, uint64_t add64) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n32) a32[i] += add32;
+    if (i < n64) a64[i] += add64;
+}
+
+int cw_add_offsets_device(uint32_t* a32, uint64_t n32, uint32_t add32, uint64_t* a64, uint64_t n64, uint64_t add64, void* hip_stream) {
+    if ((n32 && !a32) || (n64 && !a64)) return CW_E_INVALID;
+    const uint64_t n = n32 > n64 ? n32 : n64;
+    if (n == 0 || (add32 == 0 && add64 == 0)) return CW_OK;
+    if ((n + 255) / 256 > 0x7FFFFFFFull) return CW_E_INVALID;
+    cw_add_offsets_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(a32, n32, add32, a64, n64, add64);
+    CW_HIP(hipGetLastError());
+    return CW_OK;
+}
+
 int cw_plan_results_device(cw_engine* e, const cw_batch* batch, uint64_t* cons_off, uint64_t* solid_off, uint64_t* cons_total, uint64_t* solid_total,
                            void* hip_stream) {
     if (!e || !batch || !cons_off || !solid_off || !cons_total || !solid_total) return CW_E_INVALID;

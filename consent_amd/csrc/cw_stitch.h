@@ -389,7 +389,7 @@ template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO>
 __global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t too_big = REDO ? 2u : (uint32_t)CW_READ_REDO; /* the narrow kernel hands on what the wide one reports as a capacity */
+    const uint32_t too_big = NCHK <= 8 ? (uint32_t)CW_READ_REDO : (uint32_t)CW_READ_CAPACITY; /* the narrow kernel hands on what the wide one reports as a capacity */
     uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB_OF(QMAX, RMAX);
     uint8_t* refc = slab;                              /* RMAX codes of the aligned slice              */
     uint8_t* cur = refc + RMAX;                        /* current consensus (chars), QMAX              */

@@ -244,3 +244,21 @@ def test_config5_ten_contig_polishing_with_an_oracle_sample(tmp_path):
     assert [n for n, _ in want] == ["ctg3", "ctg8"]
     for n, s in want:
         assert recs[n] == s, n
+
+
+def test_a_read_or_contig_may_span_extraction_slices_and_engine_runs(tmp_path):
+    """One engine call takes at most CW_MAX_BATCH_WINDOWS windows and one extraction call a bounded number of (window, overlap) descriptors, but
+    a job -- and a single contig inside it -- may be larger: the worker extracts in slices into one batch, corrects in runs over it and
+    re-assembles once.  With the two limits shrunk (test aids) reads and contigs span many slices and runs; the FASTA must not change."""
+    fa, paf = make_dataset(tmp_path, 48, n_reads=40)
+    argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 1, "-r", fa, "-M", 150, "-p", "x"]
+    whole, _ = run_bin("CONSENT-correction", argv)
+    assert whole.count(">") > 15
+    for env in ({"CW_DRIVER_RUN_WINDOWS": "5"}, {"CW_DRIVER_SLICE_DESC": "60"}, {"CW_DRIVER_RUN_WINDOWS": "3", "CW_DRIVER_SLICE_DESC": "25"}):
+        got, _ = run_bin("CONSENT-correction", argv, env=env)
+        assert got == whole, env
+    ctg, fa2, paf2 = make_polishing_dataset(tmp_path, 49)
+    argv = ["-a", paf2, "-s", 1, "-S", 20000, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 1, "-r", ctg, "-R", fa2, "-M", 150, "-p", "x"]
+    whole, _ = run_bin("CONSENT-polishing", argv)
+    got, _ = run_bin("CONSENT-polishing", argv, env={"CW_DRIVER_RUN_WINDOWS": "2", "CW_DRIVER_SLICE_DESC": "100"})
+    assert got == whole and whole.count(">") == 2
