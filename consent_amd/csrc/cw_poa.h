@@ -75,12 +75,18 @@
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
 #define CW_POA_SLAB2_TOTAL(NC, EC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD2_BYTES(NC, EC, LC))
 
+#define CW_RM_NP(m) (int)(((m) >> 2) & 0x1FFFu)
+#define CW_RM_LIN(m) (((m) & 0x8000u) != 0u)
+#define CW_RM_X(m) (int)((m) >> 16)
+#define CW_RM_MAX_PRED 8191u
 template <typename HT>
 struct PoaMem {
     HT* H;
     unsigned long long* dirs; /* traceback codes, 2 bits per cell as two ballots per (row, chunk): 0 diagonal and
                                  1 vertical through the first predecessor, 2 horizontal, 3 = compare cell values */
-    uint32_t* rmeta;    /* rank -> base | n_pred << 2 | csr offset << 16 (n_pred counts the virtual start as 1) */
+    uint32_t* rmeta;    /* rank -> base | n_pred << 2 (13 bits; the virtual start counts as 1) | linear << 15 | x << 16, where linear = the only
+                           predecessor is the rank before, and x = that predecessor's DP row when n_pred is 1, else the offset of the node's list in
+                           plist: the fill reads this ONE word per row and branches on one bit (CW_RM_*) */
     uint16_t* rpred0;   /* rank -> DP row of its first predecessor (0 = virtual start)                           */
     uint16_t* p2;       /* rank -> DP row two / four steps up the first-predecessor chain, CW_NONE16 beyond the start */
     uint16_t* p4;       /* (only where the traceback walks matrix tiles: tier M1; else NULL)                      */
@@ -148,8 +154,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
  * fetched for all chunks at once (one round trip per row).  The next row's metadata is requested while the
  * current row computes.
  */
-template <typename HT, int NCH>
-__device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs) {
+template <typename HT, int NCH, bool DIRS>
+__device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs_) {
+    const bool use_dirs = DIRS && use_dirs_; /* direction words exist in tier L only: everywhere else the branch is compiled out of the row loop */
     const int nch = (cols + 63) >> 6;
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     /* the last RC rows stay in registers (rc_[0] = the previous row): a predecessor a few ranks back -- the other arm of a bubble --
@@ -166,18 +173,15 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         for (int k = 0; k < RC; ++k) rc_[k][c] = j * G; /* row 0 */
     }
     uint32_t meta_n = M.rmeta[0];
-    uint32_t pr0_n = M.rpred0[0];
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
-        const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
-        if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
-        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+        if (r + 1 < n) meta_n = M.rmeta[r + 1];
+        const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta), pr0 = off; /* pr0 is meaningful when np == 1 */
         int v[NCH], dgv[NCH], upv[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
-        const bool linear_row = np == 1 && pr0 == r; /* see poa_fill_pk */
-        if (linear_row) {
+        if (CW_RM_LIN(meta)) { /* see poa_fill_pk */
             int carry_in = CW_NEG;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -285,9 +289,10 @@ __device__ __forceinline__ int poa_dir_code(const unsigned long long* dirs, int 
  * its wave_shr:1 copy; the horizontal recurrence is an in-lane step plus a packed DPP prefix max.  Row stride hs is even
  * so that a lane's pair is one aligned 32-bit access.  |values| stay far from the int16 range (CW_NEG16 headroom).
  */
-template <int NCH2>
+template <int NCH2, bool DIRS>
 __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int n, const int cols, const int hs, const int lane,
-                                            const bool use_dirs) {
+                                            const bool use_dirs_) {
+    const bool use_dirs = DIRS && use_dirs_;
     const int G = CW_POA_GAP;
     const int GPK = pk_make(G, G);
     const int nch = (cols + 127) >> 7;
@@ -305,13 +310,11 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         qpk[c] = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* see pk_score */
     }
     uint32_t meta_n = M.rmeta[0];
-    uint32_t pr0_n = M.rpred0[0];
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
-        const int pr0 = __builtin_amdgcn_readfirstlane((int)pr0_n);
-        if (r + 1 < n) { meta_n = M.rmeta[r + 1]; pr0_n = M.rpred0[r + 1]; }
-        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+        if (r + 1 < n) meta_n = M.rmeta[r + 1];
+        const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta), pr0 = off; /* pr0 is meaningful when np == 1 */
         int v[NCH2], dgv[NCH2], upv[NCH2], srow[NCH2];
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
@@ -321,8 +324,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         /* the usual row -- one predecessor, the row just computed (a linear stretch of the graph): straight-line code, no predecessor
            loop, no choice of the source row.  Read in the ISA: the general loop below costs ~12 taken branches and ~130 instructions per
            row (814 cycles per row measured in tier L); this path is the ~45 vector instructions the recurrence needs */
-        const bool linear_row = np == 1 && pr0 == r;
-        if (linear_row) {
+        if (CW_RM_LIN(meta)) {
             int carry_in = CW_NEGPK;
 #pragma unroll
             for (int c = 0; c < NCH2; ++c) {
@@ -419,7 +421,7 @@ __device__ __forceinline__ bool poa_slow_step(const PoaMem<HT>& M, const int i, 
                                               int* pi_out, int* pj_out) {
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
     const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.rmeta[i - 1]);
-    const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
+    const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta); /* off: only read when np > 1 */
     int pi = i, pj = j;
     bool found = false;
     if (np <= 64) {
@@ -515,8 +517,10 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                         M.plist[q++] = (uint16_t)pr;
                     }
                     M.rpred0[r] = (uint16_t)first;
-                    M.rmeta[r] = (uint32_t)M.nbase[node] | ((uint32_t)(d ? d : 1) << 2) | ((uint32_t)off << 16);
+                    const uint32_t np_ = (uint32_t)(d ? d : 1);
+                    M.rmeta[r] = (uint32_t)M.nbase[node] | (np_ << 2) | ((np_ == 1u && first == r) ? 0x8000u : 0u) | ((uint32_t)(np_ == 1u ? first : off) << 16);
                 }
+                if (__ballot(r < n && (uint32_t)d > CW_RM_MAX_PRED) != 0ull) return 2; /* more in-edges than the row word counts (cannot happen below 8192 members) */
                 run += cw_lane_value(inc, 63);
             }
             meta_ok = true;
@@ -544,24 +548,24 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
         if constexpr (PK != 0) {
             if (!packed) {
-                if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
+                if (cols <= 64) poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs);
                 else if constexpr (PK == 2) { /* a very large graph in tier L: one column per lane */
-                    if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
-                    else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
-                    else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
-                    else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
+                    if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
+                    else if (cols <= 256) poa_fill<HT, 4, PK == 2>(M, n, cols, lane, use_dirs);
+                    else if (cols <= 512) poa_fill<HT, 8, PK == 2>(M, n, cols, lane, use_dirs);
+                    else poa_fill<HT, 16, PK == 2>(M, n, cols, lane, use_dirs);
                 }
             }
-            else if (cols <= 128) poa_fill_pk<1>(M, n, cols, hs, lane, use_dirs);
-            else if (cols <= 256) poa_fill_pk<2>(M, n, cols, hs, lane, use_dirs);
-            else if (cols <= 512) poa_fill_pk<4>(M, n, cols, hs, lane, use_dirs);
-            else if constexpr (PK == 2) poa_fill_pk<8>(M, n, cols, hs, lane, use_dirs);
+            else if (cols <= 128) poa_fill_pk<1, PK == 2>(M, n, cols, hs, lane, use_dirs);
+            else if (cols <= 256) poa_fill_pk<2, PK == 2>(M, n, cols, hs, lane, use_dirs);
+            else if (cols <= 512) poa_fill_pk<4, PK == 2>(M, n, cols, hs, lane, use_dirs);
+            else if constexpr (PK == 2) poa_fill_pk<8, PK == 2>(M, n, cols, hs, lane, use_dirs);
         } else {
-            if (cols <= 64) poa_fill<HT, 1>(M, n, cols, lane, use_dirs);
-            else if (cols <= 128) poa_fill<HT, 2>(M, n, cols, lane, use_dirs);
-            else if (cols <= 256) poa_fill<HT, 4>(M, n, cols, lane, use_dirs);
-            else if (cols <= 512) poa_fill<HT, 8>(M, n, cols, lane, use_dirs);
-            else poa_fill<HT, 16>(M, n, cols, lane, use_dirs);
+            if (cols <= 64) poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs);
+            else if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
+            else if (cols <= 256) poa_fill<HT, 4, PK == 2>(M, n, cols, lane, use_dirs);
+            else if (cols <= 512) poa_fill<HT, 8, PK == 2>(M, n, cols, lane, use_dirs);
+            else poa_fill<HT, 16, PK == 2>(M, n, cols, lane, use_dirs);
         }
         POA_PROF(1);
         if (PK == 2 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
@@ -682,7 +686,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     if (row <= 0) code = 6;
                     else if (tr == 7 || (tc == 7 && col > 0)) code = 5;
                     else if (col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS)) code = 0;
-                    else if (((meta_r >> 2) & 0x3FFF) != 1) code = 3;
+                    else if (CW_RM_NP((uint32_t)meta_r) != 1) code = 3;
                     else if (hv == bv + G) code = 1;
                     else if (col > 0 && hv == lv + G) code = 2;
                     else code = 4;
