@@ -110,6 +110,8 @@ struct PoaMem {
     uint8_t* sq;        /* current member, base codes                                                            */
     uint32_t n_cap, e_cap, l_cap, h_cap, d_cap;
     bool runs;          /* consume runs of equal moves per round trip (pays when paths have long straight stretches) */
+    bool pad64;         /* the matrix is in a slab with room to spare: rows of <= 64 columns get a stride of 64, every lane stores its cell (no
+                           execution mask round the store of a row, no mask round a far row's load) */
 };
 
 template <typename HT>
@@ -144,7 +146,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
     M.sq = p; p += lc + 1;
-    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false;
+    M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false; M.pad64 = false;
     return M;
 }
 
@@ -154,8 +156,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
  * fetched for all chunks at once (one round trip per row).  The next row's metadata is requested while the
  * current row computes.
  */
-template <typename HT, int NCH, bool DIRS>
+template <typename HT, int NCH, bool DIRS, bool PAD = false>
 __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs_) {
+    const int hs = PAD ? 64 : cols; /* row stride of the matrix (PAD: NCH == 1, stride 64, lanes beyond the columns store and load harmless cells of the padding) */
     const bool use_dirs = DIRS && use_dirs_; /* direction words exist in tier L only: everywhere else the branch is compiled out of the row loop */
     const int nch = (cols + 63) >> 6;
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
@@ -207,11 +210,11 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             } else {
                 /* no fence: a lane reads back only the columns it wrote itself (program order of one work-item), and a fence here
                    would wait for the store of the row just finished before the load could even be issued */
-                const int pr = prow * cols;
+                const int pr = prow * hs;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int j = c * 64 + lane;
-                    up[c] = act[c] ? (int)M.H[pr + j] : CW_NEG;
+                    up[c] = (PAD || act[c]) ? (int)M.H[pr + j] : CW_NEG;
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(up[c])); /* see poa_fill_pk: keeps the wait for this load out of the common path */
@@ -238,7 +241,7 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
 #pragma unroll
             for (int k = RC - 1; k > 0; --k) rc_[k][c] = rc_[k - 1][c];
             rc_[0][c] = nv;
-            if (act[c]) M.H[i * cols + j] = (HT)nv;
+            if (PAD || act[c]) M.H[i * hs + j] = (HT)nv;
             if (use_dirs && c < nch) {
                 /* single-predecessor row: the code the traceback would derive (diagonal, then vertical, then horizontal) */
                 unsigned long long b0, b1;
@@ -497,7 +500,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         }
         const int cols = L + 1;
         const bool packed = PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN); /* two columns per lane (int16 tiers, wide rows) */
-        const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
+        const bool pad = PK != 0 && !packed && M.pad64 && cols <= 64;
+        const int hs = packed ? ((cols + 1) & ~1) : pad ? 64 : cols;    /* row stride of the DP matrix */
         if ((uint32_t)((n + 1) * hs) > M.h_cap) return 2;
 
         /* ---- per-rank metadata (parallel over ranks) ---- */
@@ -548,7 +552,7 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
         if constexpr (PK != 0) {
             if (!packed) {
-                if (cols <= 64) poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs);
+                if (cols <= 64) { if (pad) poa_fill<HT, 1, PK == 2, true>(M, n, cols, lane, use_dirs); else poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs); }
                 else if constexpr (PK == 2) { /* a very large graph in tier L: one column per lane */
                     if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
                     else if (cols <= 256) poa_fill<HT, 4, PK == 2>(M, n, cols, lane, use_dirs);
@@ -1026,6 +1030,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
                                            true, TIER <= 2);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     M.runs = TIER >= 3; /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
+    M.pad64 = LC >= 63; /* (NC + 1) x 64 cells fit every slab tier's matrix */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
