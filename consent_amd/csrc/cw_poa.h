@@ -233,7 +233,9 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int j = c * 64 + lane;
-            int w = act[c] ? v[c] - j * G : CW_NEG;
+            /* (no mask for the lanes beyond the member's columns: a prefix max runs left to right, and everything to the right of the last
+               column -- in this chunk and in the chunks after it -- is beyond the columns too: what they hold reaches no cell that is read) */
+            int w = v[c] - j * G;
             w = cw_wave_scan_max(w);
             w = max(w, carry);
             carry = cw_lane_value(w, 63);
@@ -378,7 +380,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
             int w = pk_sub(v[c], jg[c]);
-            w = (w & amask[c]) | (CW_NEGPK & ~amask[c]);
+            /* (no mask for halves beyond the member's columns, see poa_fill: they only ever reach cells further right) */
             w = pk_max(w, (w << 16) | 0x8AD0);                                   /* odd column sees the even one of its lane */
             /* the lane's running max (its high half) as a biased unsigned number: the prefix max over the lanes is then six fused
                v_max_u32_dpp (VOP3P has no DPP form, and 0 is both the fill value of a shift and the identity of the max) */
@@ -686,22 +688,25 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                     const int av = __shfl_down(hv, 9), bv = __shfl_down(hv, 8), lv = __shfl_down(hv, 1); /* (tr+1,tc+1), (tr+1,tc), (tr,tc+1) */
                     /* 0 diagonal, 1 vertical, 2 horizontal; 3 several predecessors, 4 no move explains the cell, 5 neighbours outside
                        the tile, 6 the virtual start row */
-                    int code;
-                    if (row <= 0) code = 6;
-                    else if (tr == 7 || (tc == 7 && col > 0)) code = 5;
-                    else if (col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS)) code = 0;
-                    else if (CW_RM_NP((uint32_t)meta_r) != 1) code = 3;
-                    else if (hv == bv + G) code = 1;
-                    else if (col > 0 && hv == lv + G) code = 2;
-                    else code = 4;
+                    /* (selects, not branches: as an if-chain this was six nested execution-mask regions per tile) */
+                    const bool c_start = row <= 0, c_edge = tr == 7 || (tc == 7 && col > 0);
+                    const bool c_d = col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS);
+                    const bool c_m = CW_RM_NP((uint32_t)meta_r) != 1, c_v = hv == bv + G, c_h = col > 0 && hv == lv + G;
+                    const int code = c_start ? 6 : c_edge ? 5 : c_d ? 0 : c_m ? 3 : c_v ? 1 : c_h ? 2 : 4;
                     const unsigned long long m_d = __ballot(code == 0), m_v = __ballot(code == 1), m_h = __ballot(code == 2);
+                    /* the walk, a whole diagonal run per trip: the cells pos, pos + 9, ... are one 64-bit mask; the first of them that does not
+                       move diagonally ends the run (every diagonal of the tile ends in an edge cell, which never does), then one vertical or
+                       horizontal step.  A step at a time on the scalar unit was ~20 instructions for each of up to 14 steps. */
                     int pos = 0;
                     unsigned long long on_diag = 0ull;
                     for (;;) {
-                        const unsigned long long bit = 1ull << pos;
-                        if (m_d & bit) { on_diag |= bit; pos += 9; }
-                        else if (m_v & bit) pos += 8;
-                        else if (m_h & bit) pos += 1;
+                        const unsigned long long dm = 0x8040201008040201ull << pos;
+                        const unsigned long long stop = ~m_d & dm;
+                        const int first = stop ? __ffsll((long long)stop) - 1 : 63;
+                        on_diag |= dm & ((1ull << first) - 1ull);
+                        pos = first;
+                        if ((m_v >> pos) & 1ull) pos += 8;
+                        else if ((m_h >> pos) & 1ull) pos += 1;
                         else break;
                     }
                     if ((on_diag >> lane) & 1ull) M.seqrank[col - 1] = (uint16_t)(row - 1);
