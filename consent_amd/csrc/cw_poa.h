@@ -110,8 +110,8 @@ struct PoaMem {
     uint8_t* sq;        /* current member, base codes                                                            */
     uint32_t n_cap, e_cap, l_cap, h_cap, d_cap;
     bool runs;          /* consume runs of equal moves per round trip (pays when paths have long straight stretches) */
-    bool pad64;         /* the matrix is in a slab with room to spare: rows of <= 64 columns get a stride of 64, every lane stores its cell (no
-                           execution mask round the store of a row, no mask round a far row's load) */
+    bool pad64;         /* the matrix is in a slab with 64 cells of slack behind it: rows of <= 64 columns are stored and loaded by all 64 lanes
+                           (no execution mask round the store of a row, no mask round a far row's load; see poa_fill) */
 };
 
 template <typename HT>
@@ -158,7 +158,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
  */
 template <typename HT, int NCH, bool DIRS, bool PAD = false>
 __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const int cols, const int lane, const bool use_dirs_) {
-    const int hs = PAD ? 64 : cols; /* row stride of the matrix (PAD: NCH == 1, stride 64, lanes beyond the columns store and load harmless cells of the padding) */
+    const int hs = cols; /* row stride of the matrix.  PAD (slab tiers, NCH == 1): every lane stores and loads without an execution mask -- a lane beyond
+                            the member's columns then writes into the first cells of the NEXT row(s), which are computed and stored later (rows are
+                            written in rank order, read only when complete), and reads cells nobody uses; the slab has 64 cells of slack */
     const bool use_dirs = DIRS && use_dirs_; /* direction words exist in tier L only: everywhere else the branch is compiled out of the row loop */
     const int nch = (cols + 63) >> 6;
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
@@ -503,8 +505,8 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         const int cols = L + 1;
         const bool packed = PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN); /* two columns per lane (int16 tiers, wide rows) */
         const bool pad = PK != 0 && !packed && M.pad64 && cols <= 64;
-        const int hs = packed ? ((cols + 1) & ~1) : pad ? 64 : cols;    /* row stride of the DP matrix */
-        if ((uint32_t)((n + 1) * hs) > M.h_cap) return 2;
+        const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
+        if ((uint32_t)((n + 1) * hs + (pad ? 64 : 0)) > M.h_cap) return 2;
 
         /* ---- per-rank metadata (parallel over ranks) ---- */
         if (!meta_ok) {
@@ -1035,7 +1037,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
                                            true, TIER <= 2);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     M.runs = TIER >= 3; /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
-    M.pad64 = LC >= 63; /* (NC + 1) x 64 cells fit every slab tier's matrix */
+    M.pad64 = true; /* the slab's matrix area is (NC + 1) x (LC + 1) cells: a matrix of <= 64 columns leaves more than 64 cells free */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
