@@ -133,6 +133,9 @@ struct DevScratch {
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
+    uint32_t s_route_cells;        /* tier S takes a task whose expected matrix (nodes + 1) x (longest member + 1) stays below this many cells (its LDS holds
+                                      CW_POA_HC; a task that outgrows it is redone in tier L, late) */
+    uint32_t m1_route_depth;       /* tier M1 is chosen with the depth-aware graph estimate too (deep piles of ~100-base members outgrow its 256 nodes) */
     uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1; 2 = also what tier S would take (CW_TIER_H) */
     uint32_t h_min_len;            /* shortest "longest member" tier H takes (CW_H_MIN_LEN, default CW_POAH_MIN_LEN) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */

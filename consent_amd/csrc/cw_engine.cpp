@@ -331,6 +331,16 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        and OFF unless CW_TIER_H=1 (takes what would go to tier M1) or 2 (also what tier S would take): measured at depth 150 it costs 2.4 M
        wave-cycles per task where tier M1 spends 3.1 M on the same tasks, but with its 8 waves per CU beside the other tiers the step is
        slower (111 ms against 93 with one engine) -- DESIGN.md "Round 3".  Persistent work-groups of four halves, 29 KB of LDS each. */
+    /* Routing margins against late hand-overs.  A task that outgrows tier S or M1 is redone in tier L, whose work-groups only turn to the
+       hand-over queue once their own list is empty: measured on a depth-150 batch (tools/task_trace.py), the ~150 tasks of 24-45 members
+       x 27-31 bases that the depth-aware estimate put just inside tier S's 2048 cells, and the ~45 tasks of 52-64 members x 90-120 bases
+       that outgrew tier M1's 256 nodes, kept a handful of tier-L waves busy for 10-20 ms after every other tier had finished.  With tier S
+       taking only what is expected to stay below 1700 cells and tier M1 chosen by the depth-aware estimate as well, one task per batch is
+       handed over instead of ~195, and the step (two engines) goes from 73.1 to 68.8 ms on the same box.  CW_S_ROUTE_CELLS /
+       CW_M1_ROUTE_DEPTH=0 give the old routing (experiments; results do not depend on the tier). */
+    sc.s_route_cells = 1700;
+    if (const char* env = getenv("CW_S_ROUTE_CELLS")) { const int v = atoi(env); if (v >= 64 && v <= CW_POA_HC) sc.s_route_cells = (uint32_t)v; }
+    sc.m1_route_depth = getenv("CW_M1_ROUTE_DEPTH") ? (uint32_t)atoi(getenv("CW_M1_ROUTE_DEPTH")) : 1u;
     sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
     if (const char* env = getenv("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
     if (const char* env = getenv("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
@@ -392,7 +402,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t sort_lds = knob_u("CW_SORT_LDS", 16384, 0, CW_SORT_LDS_CLS);
     const uint32_t sort_thr = knob_u("CW_SORT_THREADS", 256, 128, 1024) / 64 * 64;
     const uint32_t q_waves = knob_u("CW_Q_WAVES", 2, 1, CW_POAQ_WAVES);          /* waves per tier-Q work-group (four tasks per wave) */
-    const uint32_t q_grid = (uint32_t)cus * CW_POAQ_WAVES / q_waves;
+    const uint32_t q_per_cu = knob_u("CW_Q_WGS_PER_CU", CW_POAQ_WAVES / q_waves, 1, CW_POAQ_WAVES / q_waves);
+    const uint32_t q_grid = (uint32_t)cus * q_per_cu;
     const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64, 1, (uint32_t)cus * 2);
     const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
     const uint32_t big_wgs = knob_u("CW_BIG_WGS", big_cap < 16 ? big_cap : 16, 1, big_cap);
