@@ -147,14 +147,26 @@ __device__ __forceinline__ uint32_t cw_block_exscan(uint32_t v, uint32_t* scratc
 
 __device__ __forceinline__ uint32_t cw_hash32(uint32_t x) { return x * 2654435761u; }
 
+/* the template's k-mer table: 512 buckets of four entries, entry = (template position + 1) | the key's low 21 bits << 11 (the whole key
+   when k <= 10).  A bucket is one 16-byte LDS read and its four entries are compared in registers; entries fill a bucket front to back
+   and overflow into the next bucket, so a bucket with a free last entry ends the search.  (Linear probing over single entries took about
+   eight dependent round trips to LDS per wave and lookup round at depth 150 -- half of the support pass.) */
+#define CW_TH_POS(e) ((e) & 2047u)
+#define CW_TH_FP(key) (((key) & 0x1FFFFFu) << 11)
+#define CW_TH_BUCKETS (CW_TH_SLOTS / 4)
+#define CW_TH_HOME(key) (cw_hash32(key) >> (32 - 9))
+static_assert(CW_TH_BUCKETS == 512, "CW_TH_HOME takes nine bits of the hash");
 /* lookup of a template k-mer: returns its representative template position or -1 */
 __device__ __forceinline__ int cw_tpl_lookup(const uint32_t* th, const uint32_t* tkey, uint32_t key) {
-    uint32_t slot = cw_hash32(key) >> (32 - 11);
+    uint32_t bkt = CW_TH_HOME(key);
+    const uint32_t fp = CW_TH_FP(key);
     for (;;) {
-        uint32_t e = th[slot];
-        if (e == 0) return -1;
-        if (tkey[e - 1] == key) return (int)e - 1;
-        slot = (slot + 1) & (CW_TH_SLOTS - 1);
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t e = th[bkt * 4u + j];
+            if (e == 0) return -1;
+            if ((e & ~2047u) == fp && tkey[CW_TH_POS(e) - 1] == key) return (int)CW_TH_POS(e) - 1;
+        }
+        bkt = (bkt + 1) & (CW_TH_BUCKETS - 1);
     }
 }
 
@@ -278,6 +290,34 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 if (stw) { const uint32_t len = s_len[s]; const cw_l32 words = (cw_l32)(s_words + s_off[s]); CW_IDX_KMERS4(__VA_ARGS__) } \
                 else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
                        const cw_g32 words = (cw_g32)(b.bases + b.seq_word_off[s0 + s]); CW_IDX_KMERS4(__VA_ARGS__) }           \
+            }                                                                                                           \
+        }
+
+/* eight sequences at a time and four consecutive k-mers per thread like CW_IDX_PASS_BLOCK, but the eight thread groups start 64 positions
+   apart (rotating inside each block of 512 positions): the sequences of a pile are copies of one stretch of the genome, so groups that
+   walk them in step update the same counters at the same moment; 64 positions apart they are in different k-mers */
+#define CW_IDX_KMERS4R(...)                                                                                             \
+                const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;                                \
+                for (uint32_t pb = 0; pb < nk; pb += 512u) {                                                            \
+                    const uint32_t p0 = pb + ((((uint32_t)tid & 127u) * 4u + ((uint32_t)tid >> 7) * 64u) & 511u);      \
+                    if (p0 >= nk) continue;                                                                             \
+                    const uint32_t wi_ = p0 >> 4;                                                                       \
+                    uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);               \
+                    x_ <<= 2u * (p0 & 15u);                                                                             \
+                    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4u; ++q_, x_ <<= 2) {                                  \
+                        const uint32_t p = p0 + q_;                                                                     \
+                        if (p >= nk) break;                                                                             \
+                        const uint32_t key = (uint32_t)(x_ >> (64u - 2u * k));                                          \
+                        __VA_ARGS__                                                                                     \
+                    }                                                                                                   \
+                }
+#define CW_IDX_PASS_BLOCKR(...)                                                                                         \
+        for (uint32_t sp = 0; sp < N; sp += 8) {                                                                        \
+            const uint32_t s = sp + ((uint32_t)tid >> 7);                                                               \
+            if (s < N) {                                                                                                \
+                if (stw) { const uint32_t len = s_len[s]; const cw_l32 words = (cw_l32)(s_words + s_off[s]); CW_IDX_KMERS4R(__VA_ARGS__) } \
+                else { const uint32_t len = stm ? s_len[s] : b.seq_len[s0 + s];                                         \
+                       const cw_g32 words = (cw_g32)(b.bases + b.seq_word_off[s0 + s]); CW_IDX_KMERS4R(__VA_ARGS__) }          \
             }                                                                                                           \
         }
 
@@ -425,7 +465,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         if (tid < 8) flags[tid] = 0;
         __syncthreads();
         CW_PROF(sc.ctr, 55, tid == 0);
-        CW_IDX_PASS_BLOCK2({
+        CW_IDX_PASS_BLOCKR({
             const uint32_t wd = key >> 3, sh = (key & 7) * 4;
             uint32_t old = tab[wd];
             bool sat = false;
@@ -694,49 +734,87 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         __syncthreads();
         if ((uint32_t)tid < nk0) {
             const uint32_t key = tkey[tid];
-            uint32_t slot = cw_hash32(key) >> (32 - 11);
-            for (;;) {
-                uint32_t prev = atomicCAS(&th[slot], 0u, (uint32_t)tid + 1);
-                if (prev == 0) break;
-                if (tkey[prev - 1] == key) { trep[prev - 1] = 1; break; } /* repeated inside the template */
-                slot = (slot + 1) & (CW_TH_SLOTS - 1);
+            uint32_t bkt = CW_TH_HOME(key);
+            for (bool placed = false; !placed; bkt = (bkt + 1) & (CW_TH_BUCKETS - 1)) {
+                for (uint32_t j = 0; j < 4u && !placed; ++j) {
+                    const uint32_t prev = atomicCAS(&th[bkt * 4u + j], 0u, ((uint32_t)tid + 1) | CW_TH_FP(key));
+                    if (prev == 0) placed = true;
+                    else if ((prev & ~2047u) == CW_TH_FP(key) && tkey[CW_TH_POS(prev) - 1] == key) { trep[CW_TH_POS(prev) - 1] = 1; placed = true; } /* repeated inside the template */
+                }
             }
         }
         __syncthreads();
         CW_PROF(sc.ctr, 7, tid == 0);
         /* support + repeat detection: one wave per sequence, four consecutive k-mers per lane out of one 64-bit window of the packed bases.  The
-           first probes of the four template-table lookups are requested together (nine in ten end there: not a template k-mer), then the hits
-           are settled one by one. */
+           four template-table lookups of a lane are requested together, one bucket each (nine in ten end there: not a template k-mer), and so
+           are the hits' updates: the four "seen in this sequence" bits go out together, and the wave takes its places in the hit list with
+           one add per round. */
+        const bool fp_exact = k <= 10u; /* the entry holds the whole key */
         auto support_seq = [&](auto words, const uint32_t len, const uint32_t s, uint32_t* my_seen) {
             const uint32_t nk = len >= k ? len - k + 1 : 0, nwd = (len + 15u) >> 4;
             for (uint32_t p0 = (uint32_t)lane * 4u; p0 < nk; p0 += 256u) {
                 const uint32_t wi_ = p0 >> 4;
                 uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);
                 x_ <<= 2u * (p0 & 15u);
-                uint32_t key4[4], slot4[4], e1[4];
+                uint32_t key4[4], bkt4[4], e1[4]; /* e1[q]: the key's entry, 0 = not a template k-mer */
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) { key4[q] = (uint32_t)(x_ >> (64u - 2u * k)); slot4[q] = cw_hash32(key4[q]) >> (32 - 11); }
+                for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) { key4[q] = (uint32_t)(x_ >> (64u - 2u * k)); bkt4[q] = CW_TH_HOME(key4[q]); }
+                if (fp_exact) {
+                    auto match = [&](const uint4 v, const uint32_t fp) -> uint32_t {
+                        return (v.x & ~2047u) == fp ? v.x : (v.y & ~2047u) == fp ? v.y : (v.z & ~2047u) == fp ? v.z : (v.w & ~2047u) == fp ? v.w : 0u;
+                    };
+                    uint4 v4[4];
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q) e1[q] = p0 + q < nk ? th[slot4[q]] : 0u;
+                    for (uint32_t q = 0; q < 4u; ++q) v4[q] = p0 + q < nk ? *(const uint4*)&th[bkt4[q] * 4u] : make_uint4(0u, 0u, 0u, 0u);
+                    uint32_t pend = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) { e1[q] = match(v4[q], CW_TH_FP(key4[q])); if (e1[q] == 0u && v4[q].w != 0u) pend |= 1u << q; }
+                    while (__ballot(pend != 0u) != 0ull) { /* a full bucket without the key: the next one (rare) */
+#pragma unroll
+                        for (uint32_t q = 0; q < 4u; ++q) {
+                            if ((pend >> q) & 1u) {
+                                bkt4[q] = (bkt4[q] + 1u) & (CW_TH_BUCKETS - 1);
+                                const uint4 v = *(const uint4*)&th[bkt4[q] * 4u];
+                                e1[q] = match(v, CW_TH_FP(key4[q]));
+                                if (e1[q] != 0u || v.w == 0u) pend &= ~(1u << q);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) e1[q] = p0 + q < nk ? (uint32_t)(cw_tpl_lookup(th, tkey, key4[q]) + 1) : 0u;
+                }
+                uint32_t old4[4];
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; ++q) {
-                    uint32_t ee = e1[q], slot = slot4[q];
-                    int e = -1;
-                    while (ee != 0u) { /* cw_tpl_lookup from its second step on */
-                        if (tkey[ee - 1] == key4[q]) { e = (int)ee - 1; break; }
-                        slot = (slot + 1) & (CW_TH_SLOTS - 1);
-                        ee = th[slot];
+                    const uint32_t e = CW_TH_POS(e1[q]) - 1u;
+                    old4[q] = e1[q] != 0u ? atomicOr(&my_seen[e >> 5], 1u << (e & 31u)) : 0u;
+                }
+                uint32_t n_list = 0, my_list = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    const bool hit = e1[q] != 0u;
+                    const uint32_t e = CW_TH_POS(e1[q]) - 1u, p = p0 + q;
+                    if (hit) {
+                        if (old4[q] & (1u << (e & 31u))) trep[e] = 1;
+                        else atomicAdd(&tsup[e], 1u);
+                        if (tfit) P_lds[e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
+                        else if (hl && p >= 1024u) misc[5] = 1;
                     }
-                    if (e < 0) continue;
-                    const uint32_t p = p0 + q;
-                    const uint32_t bit = 1u << (e & 31);
-                    const uint32_t old = atomicOr(&my_seen[e >> 5], bit);
-                    if (old & bit) trep[e] = 1;
-                    else atomicAdd(&tsup[e], 1u);
-                    if (tfit) P_lds[(uint32_t)e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
-                    else if (hl) {
-                        if (p < 1024u) { const uint32_t hi_ = atomicAdd(&misc[4], 1u); if (hi_ < hit_cap) hitlist[hi_] = ((uint32_t)e << 22) | (s << 10) | p; }
-                        else misc[5] = 1;
+                    if (!tfit && hl) {
+                        const unsigned long long hm = __ballot(hit && p < 1024u);
+                        if (hit && p < 1024u) my_list |= (n_list + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))) << (8u * q); /* at most 256 hits per round */
+                        n_list += (uint32_t)__popcll(hm);
+                    }
+                }
+                if (!tfit && hl && n_list) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&misc[4], n_list);
+                    base = (uint32_t)cw_lane_value((int)base, 0);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        const uint32_t p = p0 + q, hi_ = base + ((my_list >> (8u * q)) & 255u);
+                        if (e1[q] != 0u && p < 1024u && hi_ < hit_cap) hitlist[hi_] = ((CW_TH_POS(e1[q]) - 1u) << 22) | (s << 10) | p;
                     }
                 }
             }
