@@ -791,7 +791,13 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
        windows), which twice the resident waves do not shorten -- and the reads it hands on (a consensus above 640 in any of their windows)
        cost a second such tail, 51 ms: 114 ms per job against 75.  DESIGN.md "Round 3". */
     const bool narrow = getenv("CW_STITCH_NARROW") && (uint64_t)window_size + 2ull * window_overlap <= CW_STN_RMAX;
-    const uint32_t wgs_max = narrow && wgs_n > wgs ? wgs_n : wgs;
+    /* several waves per read (cw_stitch.h, st_sweep_sys): one read per work-group of five waves */
+    const bool sys = !narrow && getenv("CW_STITCH_SYS") && (uint64_t)window_size + 2ull * window_overlap <= CW_STS_RMAX;
+    const size_t lds_s = (((size_t)CW_ST_SLAB_OF(CW_STS_QMAX, CW_STS_RMAX) + 15u) & ~(size_t)15u) + sizeof(StSys);
+    uint32_t wgs_s = n_reads;
+    if (wgs_s > (uint32_t)cus_st * 6u) wgs_s = (uint32_t)cus_st * 6u;
+    uint32_t wgs_max = narrow && wgs_n > wgs ? wgs_n : wgs;
+    if (sys && (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES > wgs_max) wgs_max = (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES;
     /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
     a.dir_bytes = getenv("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(getenv("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
     if (a.dir_bytes < 64) a.dir_bytes = 64;
@@ -799,7 +805,10 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
-    if (narrow) {
+    if (sys) {
+        cw_stitch_kernel<CW_STS_QMAX, CW_STS_RMAX, 5, 1, false, true><<<wgs_s, 64 * CW_STS_WAVES, lds_s, st>>>(a);
+        cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a); /* the reads it marked (a consensus above 1280: normally none) */
+    } else if (narrow) {
         cw_stitch_kernel<CW_STN_QMAX, CW_STN_RMAX, 5, CW_STN_WAVES, false><<<wgs_n, 64 * CW_STN_WAVES, lds_n, st>>>(a);
         cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a); /* the reads it marked (normally none) */
     } else {

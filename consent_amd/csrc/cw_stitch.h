@@ -216,6 +216,207 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     return best;
 }
 
+/* ---- the same sweep on several waves of one work-group (a read is a serial chain of windows, and a window is two sweeps of ~600
+ * columns: with one wave per read a launch lasts as long as its longest read, ~0.4 ms per window).  The query's chunks of 128 positions
+ * are dealt to the waves in order -- one chunk per wave up to 128 x waves positions, two beyond -- and a column moves down the waves as
+ * a pipeline: within a column, chunk c needs from chunk c - 1 only the running maximum of the in-column gap (16 bits) and, for the
+ * next column, the H pair of its last lane (32 bits).  Both travel in ONE 64-bit LDS word per column, tagged with the column (ring of
+ * eight per wave, the consumer publishes how far it has read).  Everything of a column that does not depend on the word is issued
+ * before the wave polls for it.  A reverse sweep ends at the first column that holds the forward score: the wave that finds it lowers
+ * `stop`; waves ahead of it have walked a few columns further, which cannot change the result (no cell of the reverse rectangle
+ * exceeds the forward score, and a position's first column is only recorded when its best improves).  Results are reduced over the
+ * waves through LDS; three work-group barriers per sweep. ---- */
+#define CW_STS_WAVES 5
+#define CW_STS_CPW 2 /* chunks per wave at most: consensuses up to 1280 positions */
+#define CW_STS_QMAX (CW_STS_WAVES * CW_STS_CPW * 128)
+#define CW_STS_RMAX 640
+#define CW_STS_RING 8
+struct StSys {
+    unsigned long long mail[CW_STS_WAVES][CW_STS_RING]; /* [producer][column & 7]: F maximum (biased u16) | H pair << 16 | (column + 1) << 48 */
+    uint32_t progress[8];                                /* [consumer]: columns read so far */
+    int stop;                                            /* first column index (in sweep order) holding the terminate score; INT_MAX: none */
+    int red[3][8];
+    uint32_t q_off, r_off;                               /* the request: LDS byte offsets of the query and the slice */
+    int m, r_first, r_last_excl, step, terminate, quit;
+    int fail;                                            /* a bounded wait ran out (cannot happen): the read is reported as CW_READ_CAPACITY */
+};
+
+__device__ __forceinline__ StSweep st_sweep_sys(StSys* sm, const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate,
+                                                const int lane, const int wv) {
+    const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), FADJ = pk_make(GE - GO, GE - GO);
+    m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate); step = st_uni(step);
+    const int TERMPK = pk_make(terminate, terminate);
+    const int cpw = m <= CW_STS_WAVES * 128 ? 1 : 2;
+    const int chunk0 = wv * cpw;
+    const bool active = chunk0 * 128 < m;
+    const bool has_prev = wv > 0, has_next = wv + 1 < CW_STS_WAVES && (wv + 1) * cpw * 128 < m;
+    int hprev[CW_STS_CPW], ee[CW_STS_CPW], jg[CW_STS_CPW], amask[CW_STS_CPW], qpk[CW_STS_CPW], qok[CW_STS_CPW], bestv[CW_STS_CPW], bce[CW_STS_CPW], bco[CW_STS_CPW];
+#pragma unroll
+    for (int c = 0; c < CW_STS_CPW; ++c) {
+        const int j0 = (chunk0 + c) * 128 + 2 * lane, j1 = j0 + 1;
+        jg[c] = pk_make(j0 * GE, j1 * GE);
+        amask[c] = (j0 < m ? 0xFFFF : 0) | (j1 < m ? (int)0xFFFF0000 : 0);
+        const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
+        qpk[c] = pk_make(q0, q1);
+        qok[c] = (q0 < 4 ? 0xFFFF : 0) | (q1 < 4 ? (int)0xFFFF0000 : 0);
+        hprev[c] = 0; ee[c] = 0; bestv[c] = 0; bce[c] = -1; bco[c] = -1;
+    }
+    const int ncols = (r_last_excl - r_first) * step; /* step is +1 or -1 */
+    typedef __attribute__((address_space(3))) volatile unsigned long long* st_l64;
+    typedef __attribute__((address_space(3))) volatile uint32_t* st_l32;
+    typedef __attribute__((address_space(3))) volatile int* st_li32;
+    int carry_pair = 0;  /* H of the previous column at the last rows of the wave before */
+    uint32_t seen = 0;   /* columns the next wave has read, as last looked up */
+    if (active) {
+        for (int k = 0; k < ncols; ++k) {
+            if (k > st_uni(*(st_li32)&sm->stop)) break;
+            const int i = r_first + k * step;
+            const int rc = st_uni((int)r[i]);
+            const int rcpk = rc * 0x00010001, rc_ok = rc <= 3 ? -1 : 0;
+            /* what does not depend on the wave before */
+            int e_[CW_STS_CPW], hp[CW_STS_CPW], w[CW_STS_CPW];
+            unsigned inc[CW_STS_CPW];
+            int cp = carry_pair;
+#pragma unroll
+            for (int c = 0; c < CW_STS_CPW; ++c) {
+                if (c < cpw && (chunk0 + c) * 128 < m) {
+                    const int hp_ = hprev[c];
+                    int e = pk_max(pk_sub(ee[c], GEPK), pk_sub(hp_, GOPK));
+                    e = pk_max(e, 0);
+                    const int sh = CW_DPP(cp, hp_, 0x138, 0xF);
+                    cp = cw_lane_value(hp_, 63);
+                    const int dg = __builtin_amdgcn_alignbit(hp_, sh, 16);
+                    const int sv = st_score(qpk[c] ^ rcpk) & qok[c] & rc_ok;
+                    hp[c] = pk_max(pk_max(pk_add(dg, sv), e), 0);
+                    e_[c] = e;
+                    w[c] = pk_add(hp[c], jg[c]);
+                    const int tot = pk_max(w[c], __builtin_amdgcn_perm(w[c], w[c], 0x01000302));
+                    inc[c] = cw_wave_scan_max_u32(((unsigned)tot & 0xFFFFu) ^ 0x8000u);
+                }
+            }
+            /* the word of the wave before */
+            unsigned carry_f = (unsigned)(CW_NEG16 + 32768);
+            int pair_next = 0;
+            bool gone = false;
+            if (has_prev) {
+                const st_l64 slot = (st_l64)&sm->mail[wv - 1][k & (CW_STS_RING - 1)];
+                for (uint32_t spin = 0;; ++spin) {
+                    const unsigned long long msg = *slot;
+                    const uint32_t lo = st_uni((uint32_t)msg), hi = st_uni((uint32_t)(msg >> 32));
+                    if ((hi >> 16) == (uint32_t)(k + 1)) { carry_f = lo & 0xFFFFu; pair_next = (int)((lo >> 16) | (hi << 16)); break; }
+                    if (k > st_uni(*(st_li32)&sm->stop)) { gone = true; break; }
+                    if (spin > (1u << 22)) { if (lane == 0) { sm->fail = 1; atomicMin(&sm->stop, -1); } gone = true; break; } /* cannot happen: every wait is bounded all the same */
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (gone) break;
+                if (lane == 0) *(st_l32)&sm->progress[wv] = (uint32_t)(k + 1);
+            }
+            unsigned long long hit = 0ull;
+            int h_last = 0;
+#pragma unroll
+            for (int c = 0; c < CW_STS_CPW; ++c) {
+                if (c < cpw && (chunk0 + c) * 128 < m) {
+                    const unsigned ex = max((unsigned)CW_DPP(0, (int)inc[c], 0x138, 0xF), carry_f);
+                    carry_f = max(carry_f, (unsigned)cw_lane_value((int)inc[c], 63));
+                    const int pre = pk_max(pk_splat_lo((int)(ex ^ 0x8000u)), (w[c] << 16) | (CW_NEGPK & 0xFFFF));
+                    const int f = pk_max(pk_add(pk_sub(pre, jg[c]), FADJ), 0);
+                    const int h = pk_max(hp[c], f);
+                    hprev[c] = h; ee[c] = e_[c];
+                    h_last = h;
+                    const int hm = h & amask[c];
+                    const int nb = pk_max(bestv[c], hm);
+                    const int ch = nb ^ bestv[c];
+                    bestv[c] = nb;
+                    bce[c] = (ch & 0xFFFF) ? i : bce[c];
+                    bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
+                    if (terminate >= 0) {
+                        const int d = hm ^ TERMPK;
+                        hit |= __ballot((d & 0xFFFF) == 0 || ((unsigned)d >> 16) == 0u);
+                    }
+                }
+            }
+            if (has_next) { /* hand the column on: not before the next wave has read the word this one replaces */
+                for (uint32_t spin = 0; (uint32_t)k >= seen + CW_STS_RING; ++spin) {
+                    seen = st_uni(*(st_l32)&sm->progress[wv + 1]);
+                    if (k > st_uni(*(st_li32)&sm->stop)) { gone = true; break; }
+                    if (spin > (1u << 22)) { if (lane == 0) { sm->fail = 1; atomicMin(&sm->stop, -1); } gone = true; break; }
+                    if ((uint32_t)k >= seen + CW_STS_RING) __builtin_amdgcn_s_sleep(1);
+                }
+                if (gone) break;
+                const uint32_t pair = (uint32_t)cw_lane_value(h_last, 63);
+                const unsigned long long msg = (unsigned long long)(carry_f & 0xFFFFu) | ((unsigned long long)pair << 16) | ((unsigned long long)(k + 1) << 48);
+                if (lane == 0) *(st_l64)&sm->mail[wv][k & (CW_STS_RING - 1)] = msg;
+            }
+            carry_pair = pair_next;
+            if (hit) { if (lane == 0) atomicMin(&sm->stop, k); break; }
+        }
+    }
+    /* over the waves: the best score, the first column that reached it, the smallest position holding it there */
+    int lm = 0;
+#pragma unroll
+    for (int c = 0; c < CW_STS_CPW; ++c) lm = max(lm, max((int)(short)(bestv[c] & 0xFFFF), (int)(short)((unsigned)bestv[c] >> 16)));
+    lm = st_uni(cw_wave_max(lm));
+    if (lane == 0) sm->red[0][wv] = lm;
+    __syncthreads();
+    const bool was_hit = st_uni(*(st_li32)&sm->stop) != 0x7FFFFFFF;
+    int M = 0;
+    for (int x = 0; x < CW_STS_WAVES; ++x) M = max(M, sm->red[0][x]);
+    M = was_hit ? terminate : st_uni(M);
+    /* the rings are free again: every wave is out of its loop */
+    if (lane < CW_STS_RING) sm->mail[wv][lane] = 0ull;
+    if (lane == 0) sm->progress[wv] = 0u;
+    StSweep best{0, -1, 0};
+    if (M <= 0) { __syncthreads(); return best; } /* (the master may post its next request only when every wave has read this one's results) */
+    int kc = 0x7FFFFFFF;
+#pragma unroll
+    for (int c = 0; c < CW_STS_CPW; ++c) {
+        if ((int)(short)(bestv[c] & 0xFFFF) == M) kc = min(kc, bce[c] * step);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M) kc = min(kc, bco[c] * step);
+    }
+    kc = st_uni(-cw_wave_max(-kc));
+    if (lane == 0) sm->red[1][wv] = kc;
+    __syncthreads();
+    for (int x = 0; x < CW_STS_WAVES; ++x) kc = min(kc, sm->red[1][x]);
+    kc = st_uni(kc);
+    const int col = kc * step;
+    int jr = 0x7FFFFFFF;
+#pragma unroll
+    for (int c = 0; c < CW_STS_CPW; ++c) {
+        const int j0 = (chunk0 + c) * 128 + 2 * lane;
+        if ((int)(short)(bestv[c] & 0xFFFF) == M && bce[c] == col) jr = min(jr, j0);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M && bco[c] == col) jr = min(jr, j0 + 1);
+    }
+    jr = st_uni(-cw_wave_max(-jr));
+    if (lane == 0) sm->red[2][wv] = jr;
+    __syncthreads();
+    for (int x = 0; x < CW_STS_WAVES; ++x) jr = min(jr, sm->red[2][x]);
+    best.score = M; best.col = col; best.row = st_uni(jr);
+    return best;
+}
+
+/* the master wave (wave 0, which runs the read) posts a sweep and takes part in it; the other waves wait for requests in st_sys_helper */
+__device__ __forceinline__ StSweep st_sweep_post(StSys* sm, const uint8_t* lds_base, const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step,
+                                                 int terminate, const int lane) {
+    if (lane == 0) {
+        sm->q_off = (uint32_t)(q - lds_base); sm->r_off = (uint32_t)(r - lds_base);
+        sm->m = m; sm->r_first = r_first; sm->r_last_excl = r_last_excl; sm->step = step; sm->terminate = terminate; sm->quit = 0;
+        sm->stop = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    const StSweep sw = st_sweep_sys(sm, q, m, r, r_first, r_last_excl, step, terminate, lane, 0);
+    if (st_uni(sm->fail)) return StSweep{0, -1, 0}; /* no coordinates from a sweep that was given up */
+    return sw;
+}
+__device__ __forceinline__ void st_sys_helper(StSys* sm, const uint8_t* lds_base, const int lane, const int wv) {
+    for (;;) {
+        __syncthreads();
+        if (st_uni(sm->quit)) break;
+        (void)st_sweep_sys(sm, lds_base + st_uni(sm->q_off), st_uni(sm->m), lds_base + st_uni(sm->r_off), st_uni(sm->r_first), st_uni(sm->r_last_excl), st_uni(sm->step),
+                           st_uni(sm->terminate), lane, wv);
+    }
+}
+
 template <int NCHK>
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
@@ -328,19 +529,23 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
 struct StAlign { int score, ref_begin, ref_end, query_begin, query_end; };
 
 /* full alignment: forward sweep, reverse sweep.  qfw = query codes; qrv = scratch for the reversed prefix. */
-template <int NCHK>
-__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane) {
+template <int NCHK, bool SYS = false>
+__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane, StSys* sm = nullptr, const uint8_t* lds_base = nullptr) {
     StAlign a{0, 0, -1, 0, -1};
     m = st_uni(m); n = st_uni(n);
     if (m <= 0 || n <= 0) return a;
-    const StSweep fw = st_sweep_any<NCHK>(qfw, m, ref, 0, n, 1, -1, lane);
+    StSweep fw;
+    if constexpr (SYS) fw = st_sweep_post(sm, lds_base, qfw, m, ref, 0, n, 1, -1, lane);
+    else fw = st_sweep_any<NCHK>(qfw, m, ref, 0, n, 1, -1, lane);
     a.score = fw.score;
     if (fw.score <= 0) return a;
     a.ref_end = fw.col; a.query_end = fw.row;
     const int pm = fw.row + 1;
     for (int x = lane; x < pm; x += 64) qrv[x] = qfw[fw.row - x];
     st_mem_sync();
-    const StSweep bw = st_sweep_any<NCHK>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
+    StSweep bw;
+    if constexpr (SYS) bw = st_sweep_post(sm, lds_base, qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
+    else bw = st_sweep_any<NCHK>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
 }
@@ -385,11 +590,21 @@ __global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
 #define CW_STN_QMAX 640
 #define CW_STN_RMAX 640
 #define CW_STN_WAVES 4
-template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO>
-__global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
+/* SYS: one read per work-group of CW_STS_WAVES waves; wave 0 runs the read exactly as the one-wave kernels do, and every sweep is shared
+   with the other waves (st_sweep_sys).  WAVES = 1 then (slabs and scratch are per read). */
+template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO, bool SYS = false>
+__global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = SYS ? 0 : threadIdx.x >> 6;
     const uint32_t too_big = NCHK <= 8 ? (uint32_t)CW_READ_REDO : (uint32_t)CW_READ_CAPACITY; /* the narrow kernel hands on what the wide one reports as a capacity */
+    StSys* const sm = (StSys*)(lds + (((size_t)CW_ST_SLAB_OF(QMAX, RMAX) + 15u) & ~(size_t)15u));
+    if constexpr (SYS) {
+        static_assert(WAVES == 1 && QMAX <= CW_STS_QMAX && RMAX <= CW_STS_RMAX, "one read per work-group");
+        const int wv = threadIdx.x >> 6;
+        if (lane < CW_STS_RING) sm->mail[wv][lane] = 0ull;
+        if (lane == 0) { sm->progress[wv] = 0u; if (wv == 0) sm->fail = 0; }
+        if (wv != 0) { st_sys_helper(sm, lds, lane, wv); return; }
+    }
     uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB_OF(QMAX, RMAX);
     uint8_t* refc = slab;                              /* RMAX codes of the aligned slice              */
     uint8_t* cur = refc + RMAX;                        /* current consensus (chars), QMAX              */
@@ -452,7 +667,7 @@ __global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
             for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
             st_mem_sync();
-            const StAlign al = st_align<NCHK>(qfw, (int)clen, qrv, refc, size_al, lane);                   /* :90 */
+            const StAlign al = st_align<NCHK, SYS>(qfw, (int)clen, qrv, refc, size_al, lane, sm, lds);     /* :90 */
             if (a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
                 t[0] = (uint32_t)al_pos; t[1] = (uint32_t)size_al; t[2] = (uint32_t)al.score; t[3] = (uint32_t)al.ref_begin; t[4] = (uint32_t)al.ref_end;
@@ -493,7 +708,7 @@ __global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
                             st_mem_sync();
-                            const StAlign sub = st_align<NCHK>(qfw, (int)overlap, qrv, refc, (int)overlap, lane);
+                            const StAlign sub = st_align<NCHK, SYS>(qfw, (int)overlap, qrv, refc, (int)overlap, lane, sm, lds);
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
@@ -561,8 +776,13 @@ __global__ void __launch_bounds__(64 * WAVES) cw_stitch_kernel(StitchArgs a) {
             }
         }
         flen = st_uni(flen); status = st_uni(status);
+        if constexpr (SYS) { if (st_uni(sm->fail)) { flen = 0; status = (uint32_t)CW_READ_CAPACITY; if (lane == 0) sm->fail = 0; } }
         if (lane == 0) { a.out_len[ri] = flen; a.read_status[ri] = (uint8_t)status; }
         st_mem_sync();
+    }
+    if constexpr (SYS) { /* the other waves wait for the next request: none */
+        if (lane == 0) sm->quit = 1;
+        __syncthreads();
     }
 }
 

@@ -205,3 +205,19 @@ def test_stitch_narrow_kernel_hands_long_consensuses_to_the_wide_one(monkeypatch
     test_stitch_long_consensuses_use_the_wide_sweeps()
     got, n_up = run_case(make_reads(118, 40, 10, lo=600, hi=1800))
     assert len(got) == 40 and n_up > 0
+
+
+def test_stitch_several_waves_per_read(monkeypatch):
+    """CW_STITCH_SYS=1: one read per work-group of five waves, every sweep shared between them as a pipeline over the query's chunks (one chunk
+    per wave up to 640 positions, two up to 1280; longer consensuses are handed to the wide kernel) -- same strings as the oracle's restatement in
+    every case the one-wave kernels are tested on."""
+    monkeypatch.setenv("CW_STITCH_SYS", "1")
+    test_stitch_matches_oracle_pacbio_like()
+    test_stitch_without_trimming_keeps_the_uncorrected_ends()
+    test_stitch_with_sparse_coverage_and_dropped_reads()
+    test_stitch_overlap_reconciliation_paths()
+    test_stitch_short_consensus_falls_back_to_the_template_without_writing()
+    test_stitch_long_consensuses_use_the_wide_sweeps()
+    test_stitch_many_reads_in_one_launch()
+    got, n_up = run_case(make_reads(118, 40, 10, lo=600, hi=1800))
+    assert len(got) == 40 and n_up > 0
