@@ -122,13 +122,19 @@ struct StSweep { int score, col, row; };
  */
 /* x = (query letters of two positions) ^ (the reference letter in both halves): +MATCH where a half is zero, -MISMATCH elsewhere */
 __device__ __forceinline__ int st_score(int x) {
-    typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
-    const st_u2 m = __builtin_elementwise_min(__builtin_bit_cast(st_u2, x), (st_u2)(1));
-    const cw_s2 r = __builtin_bit_cast(cw_s2, m) * (cw_s2)(-CW_SSW_MISMATCH - CW_SSW_MATCH) + (cw_s2)(CW_SSW_MATCH);
-    return __builtin_bit_cast(int, r);
+    /* min(x, 1) * -(MISMATCH + MATCH) + MATCH in both halves: two packed instructions (written out: the generic vector min was lowered to
+       two compares, two selects, a permute and a shift per call -- nine instructions per chunk and column of the sweep) */
+    int t, r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(x));
+    const int mul = pk_make(-CW_SSW_MISMATCH - CW_SSW_MATCH, -CW_SSW_MISMATCH - CW_SSW_MATCH), add = pk_make(CW_SSW_MATCH, CW_SSW_MATCH);
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(mul), "v"(add));
+    return r;
 }
 
-template <int NCH2>
+/* EXACT: the caller picked NCH2 for this query (m > 128 * (NCH2 - 1) or the next smaller variant does not exist): every chunk is walked
+   without a branch -- a chunk beyond the query is all masks and feeds nothing below it -- so the column is one basic block and the
+   chunks' prefix-max ladders fill each other's wait states. */
+template <int NCH2, bool EXACT = false, bool TERM = true> /* TERM: a reverse sweep (terminate > 0); forward sweeps are compiled without the test */
 __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate,
                                                int lane) {
     const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
@@ -153,9 +159,58 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
         unsigned carry_f = (unsigned)(CW_NEG16 + 32768); /* running max of h'[t] + t*GE over the rows of this column so far (biased by 32768) */
         const int rcpk = rc * 0x00010001, rc_ok = rc <= 3 ? -1 : 0;
         unsigned long long hit = 0ull;
+        int zacc = -1;
+        if constexpr (EXACT) {
+            /* the same column written chunk-interleaved: everything that only needs the previous column for all chunks, then the six
+               steps of the prefix-max ladders side by side, then the short chain through the chunks (the running maximum of the gap).
+               The compiler finds this order itself for the forward sweeps and not for the reverse ones (whose columns it left chunk
+               after chunk, a wait state behind every packed instruction: 346 against 246 instructions for five chunks) */
+            int e_[NCH2], hp[NCH2], w[NCH2];
+            unsigned key[NCH2];
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) {
+                const int hp_ = hprev[c];
+                e_[c] = pk_max(pk_max(pk_sub(ee[c], GEPK), pk_sub(hp_, GOPK)), 0);
+                const int sh = CW_DPP(carry_pair, hp_, 0x138, 0xF);
+                carry_pair = cw_lane_value(hp_, 63);
+                const int dg = __builtin_amdgcn_alignbit(hp_, sh, 16);
+                const int sv = st_score(qpk[c] ^ rcpk) & qok[c] & rc_ok;
+                hp[c] = pk_max(pk_max(pk_add(dg, sv), e_[c]), 0);
+                w[c] = pk_add(hp[c], jg[c]);
+                const int tot = pk_max(w[c], __builtin_amdgcn_perm(w[c], w[c], 0x01000302));
+                key[c] = ((unsigned)tot & 0xFFFFu) ^ 0x8000u;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x111, 0xF));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x112, 0xF));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x114, 0xF));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x118, 0xF));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x142, 0xA));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) key[c] = max(key[c], (unsigned)CW_DPP(0, (int)key[c], 0x143, 0xC));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) {
+                const unsigned ex = max((unsigned)CW_DPP(0, (int)key[c], 0x138, 0xF), carry_f);
+                carry_f = max(carry_f, (unsigned)cw_lane_value((int)key[c], 63));
+                const int pre = pk_max(pk_splat_lo((int)(ex ^ 0x8000u)), (w[c] << 16) | (CW_NEGPK & 0xFFFF));
+                const int f = pk_max(pk_add(pk_sub(pre, jg[c]), FADJ), 0);
+                const int h = pk_max(hp[c], f);
+                hprev[c] = h; ee[c] = e_[c];
+                const int hm = h & amask[c];
+                const int nb = pk_max(bestv[c], hm);
+                const int ch = nb ^ bestv[c];
+                bestv[c] = nb;
+                bce[c] = (ch & 0xFFFF) ? i : bce[c];
+                bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
-            if (c * 128 < m) {
+            if (EXACT || c * 128 < m) {
                 const int hp_ = hprev[c];
                 int e = pk_max(pk_sub(ee[c], GEPK), pk_sub(hp_, GOPK));
                 e = pk_max(e, 0);
@@ -181,11 +236,15 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
                 bestv[c] = nb;
                 bce[c] = (ch & 0xFFFF) ? i : bce[c];
                 bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
-                if (terminate >= 0) {
-                    const int d = hm ^ TERMPK;
-                    hit |= __ballot((d & 0xFFFF) == 0 || ((unsigned)d >> 16) == 0u);
-                }
             }
+        }
+        if (TERM) { /* a half of zacc is zero iff some position of this column holds the score: one test per column, from the column as stored */
+            typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c)
+                if (EXACT || c * 128 < m)
+                    zacc = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(st_u2, zacc), __builtin_bit_cast(st_u2, (hprev[c] & amask[c]) ^ TERMPK)));
+            hit = __ballot((zacc & 0xFFFF) == 0 || ((unsigned)zacc >> 16) == 0u);
         }
         if (hit) { hit_col = i; break; }
     }
@@ -422,18 +481,26 @@ __device__ __forceinline__ void st_sys_helper(StSys* sm, const uint8_t* lds_base
     }
 }
 
-template <int NCHK>
+template <int NCHK, bool TERM>
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
-    if constexpr (NCHK <= 8) return st_sweep_pk<NCHK>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
-    /* Two instantiations: eight chunks for consensuses up to 1024 positions (every 500-base window), sixteen beyond; chunks beyond the
-       query are skipped by a scalar branch.  Round 1 had 4-, 8- and 16-chunk variants side by side and the 8-chunk one returned garbage
-       rows on gfx950 (ROCm 7.2 hipcc), each of them alone being correct; this pair is clean (tests/test_gpu_stitch.py::
-       test_stitch_long_consensuses_use_the_wide_sweeps, tools/fuzz_pipeline.py) and brings the kernel from 260 to 256 VGPRs, i.e. from
-       one to two waves per SIMD */
+    if constexpr (NCHK <= 8) return st_sweep_pk<NCHK, false, TERM>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
+    /* A variant per chunk count for the common lengths (a 500-base window's consensus is 500-600 positions: five chunks), each a
+       branch-free column written chunk-interleaved (st_sweep_pk, EXACT); the rare long ones keep the sixteen-chunk loop that skips the
+       chunks beyond the query with a scalar branch.  Round 2 walked everything up to 1024 positions through an eight-chunk loop with those
+       skips: a basic block per chunk, nothing to fill the wait states of the prefix-max ladders with, the per-position best copied
+       between register sets at every branch -- ~110 issued instructions per chunk and column against 49 now (read in the ISA; a
+       column of five chunks: 550 -> 241 instructions forward, 269 reverse).  Round 1 had 4-, 8- and 16-chunk variants side by side and
+       the 8-chunk one returned garbage rows on gfx950 (ROCm 7.2 hipcc), each of them alone being correct; the present set is checked by
+       tests/test_gpu_stitch.py (lengths on both sides of every boundary), tests/test_gpu_pipeline.py and tools/fuzz_pipeline.py. */
     m = st_uni(m);
-    if (m <= 1024) return st_sweep_pk<8>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    return st_sweep_pk<CW_ST_QMAX / 128>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 128) return st_sweep_pk<1, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 256) return st_sweep_pk<2, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 512) return st_sweep_pk<4, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 640) return st_sweep_pk<5, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 768) return st_sweep_pk<6, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1024) return st_sweep_pk<8, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    return st_sweep_pk<CW_ST_QMAX / 128, false, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 }
 
 /* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
@@ -541,7 +608,7 @@ __device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* 
     if (m <= 0 || n <= 0) return a;
     StSweep fw;
     if constexpr (SYS) fw = st_sweep_post(sm, lds_base, qfw, m, ref, 0, n, 1, -1, lane);
-    else fw = st_sweep_any<NCHK>(qfw, m, ref, 0, n, 1, -1, lane);
+    else fw = st_sweep_any<NCHK, false>(qfw, m, ref, 0, n, 1, -1, lane);
     a.score = fw.score;
     if (fw.score <= 0) return a;
     a.ref_end = fw.col; a.query_end = fw.row;
@@ -550,7 +617,7 @@ __device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* 
     st_mem_sync();
     StSweep bw;
     if constexpr (SYS) bw = st_sweep_post(sm, lds_base, qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
-    else bw = st_sweep_any<NCHK>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
+    else bw = st_sweep_any<NCHK, true>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
 }
@@ -598,6 +665,8 @@ __global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
 /* SYS: one read per work-group of CW_STS_WAVES waves; wave 0 runs the read exactly as the one-wave kernels do, and every sweep is shared
    with the other waves (st_sweep_sys).  WAVES = 1 then (slabs and scratch are per read). */
 template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO, bool SYS = false>
+/* (the wide kernel needs 243 + 16 registers: one wave per SIMD, 1024 reads in flight.  Capped at 256 for two waves per SIMD the launch
+   is SLOWER, 60.5 against 55.3 ms per job of 32768 windows: it lasts as long as its longest read, and that read's wave then shares its SIMD) */
 __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = SYS ? 0 : threadIdx.x >> 6;
