@@ -141,7 +141,7 @@ int check_params(const cw_params* p) {
 }
 
 int set_kernel_attributes() {
-    const int lds_st = CW_ST_WAVES * CW_ST_SLAB;
+    const int lds_st = CW_ST_WAVES * CW_ST_SLAB > 84 * 1024 ? CW_ST_WAVES * CW_ST_SLAB : 84 * 1024; /* see cw_stitch_device: one work-group per CU */
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
@@ -779,7 +779,12 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     a.solid = res->solid; a.solid_off = res->solid_off; a.solid_len = res->solid_len;
     a.window_size = window_size; a.window_overlap = window_overlap; a.mer_size = e->prm.k; a.do_trim = do_trim;
     a.out = out; a.out_off = out_off; a.out_len = out_len; a.read_status = read_status; a.cursor = (uint32_t*)e->xscratch;
-    const size_t lds = (size_t)CW_ST_WAVES * CW_ST_SLAB, lds_n = (size_t)CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX);
+    /* one work-group of the wide kernel per CU, i.e. one wave per SIMD: the launch lasts as long as its longest read, and that read's wave is
+       faster alone on its SIMD (measured with the register count deciding it: 55.3 ms per job at one wave per SIMD, 60.5 at two).  The kernel
+       fits two per CU by registers and LDS; asking for more than half of the LDS keeps the second one off (CW_STITCH_TWO_PER_CU=1: don't). */
+    const size_t lds_one = getenv("CW_STITCH_TWO_PER_CU") ? 0 : (size_t)84 * 1024;
+    const size_t lds_need = (size_t)CW_ST_WAVES * CW_ST_SLAB;
+    const size_t lds = lds_need > lds_one ? lds_need : lds_one, lds_n = (size_t)CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX);
     uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
     if (wgs > CW_ST_MAX_WGS) wgs = CW_ST_MAX_WGS;
     /* the narrow kernel holds four work-groups of four waves per CU (29 KB of LDS each, <= 128 VGPRs) */

@@ -131,6 +131,15 @@ __device__ __forceinline__ int st_score(int x) {
     return r;
 }
 
+/* the column of a position's best: where the best changed (a half of ch is not zero) the half takes the column -- a packed min, a packed
+   negate and one bit-field insert instead of two compares and two selects */
+__device__ __forceinline__ int st_keep_col(const int ch, const int ipk, const int bcol) {
+    int t;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(ch));
+    const int mask = pk_sub(0, t); /* 0xFFFF where the half changed */
+    return (ipk & mask) | (bcol & ~mask);
+}
+
 /* EXACT: the caller picked NCH2 for this query (m > 128 * (NCH2 - 1) or the next smaller variant does not exist): every chunk is walked
    without a branch -- a chunk beyond the query is all masks and feeds nothing below it -- so the column is one basic block and the
    chunks' prefix-max ladders fill each other's wait states. */
@@ -141,7 +150,7 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), FADJ = pk_make(GE - GO, GE - GO);
     m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
     const int TERMPK = pk_make(terminate, terminate);
-    int hprev[NCH2], ee[NCH2], jg[NCH2], amask[NCH2], qpk[NCH2], qok[NCH2], bestv[NCH2], bce[NCH2], bco[NCH2];
+    int hprev[NCH2], ee[NCH2], jg[NCH2], amask[NCH2], qpk[NCH2], qok[NCH2], bestv[NCH2], bcol[NCH2]; /* bcol: the first column reaching bestv, two 16-bit halves (-1: none) */
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
         const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
@@ -150,7 +159,7 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
         const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
         qpk[c] = pk_make(q0, q1);
         qok[c] = (q0 < 4 ? 0xFFFF : 0) | (q1 < 4 ? (int)0xFFFF0000 : 0);
-        hprev[c] = 0; ee[c] = 0; bestv[c] = 0; bce[c] = -1; bco[c] = -1;
+        hprev[c] = 0; ee[c] = 0; bestv[c] = 0; bcol[c] = -1;
     }
     int hit_col = -1;
     for (int i = r_first; i != r_last_excl; i += step) {
@@ -158,6 +167,7 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
         int carry_pair = 0;      /* H of the previous column at rows (.., 128c - 1) */
         unsigned carry_f = (unsigned)(CW_NEG16 + 32768); /* running max of h'[t] + t*GE over the rows of this column so far (biased by 32768) */
         const int rcpk = rc * 0x00010001, rc_ok = rc <= 3 ? -1 : 0;
+        const int ipk = i * 0x00010001; /* the column in both halves (columns stay below 2048) */
         unsigned long long hit = 0ull;
         int zacc = -1;
         if constexpr (EXACT) {
@@ -204,8 +214,7 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
                 const int nb = pk_max(bestv[c], hm);
                 const int ch = nb ^ bestv[c];
                 bestv[c] = nb;
-                bce[c] = (ch & 0xFFFF) ? i : bce[c];
-                bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
+                bcol[c] = st_keep_col(ch, ipk, bcol[c]);
             }
         } else
 #pragma unroll
@@ -234,8 +243,7 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
                 const int nb = pk_max(bestv[c], hm);
                 const int ch = nb ^ bestv[c];
                 bestv[c] = nb;
-                bce[c] = (ch & 0xFFFF) ? i : bce[c];
-                bco[c] = ((unsigned)ch >> 16) ? i : bco[c];
+                bcol[c] = st_keep_col(ch, ipk, bcol[c]);
             }
         }
         if (TERM) { /* a half of zacc is zero iff some position of this column holds the score: one test per column, from the column as stored */
@@ -259,8 +267,8 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     int kc = 0x7FFFFFFF;
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
-        if ((int)(short)(bestv[c] & 0xFFFF) == M) kc = min(kc, bce[c] * step);
-        if ((int)(short)((unsigned)bestv[c] >> 16) == M) kc = min(kc, bco[c] * step);
+        if ((int)(short)(bestv[c] & 0xFFFF) == M) kc = min(kc, (int)(short)(bcol[c] & 0xFFFF) * step);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M) kc = min(kc, (int)(short)((unsigned)bcol[c] >> 16) * step);
     }
     kc = st_uni(-cw_wave_max(-kc));
     const int col = kc * step;
@@ -268,8 +276,8 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
 #pragma unroll
     for (int c = 0; c < NCH2; ++c) {
         const int j0 = c * 128 + 2 * lane;
-        if ((int)(short)(bestv[c] & 0xFFFF) == M && bce[c] == col) jr = min(jr, j0);
-        if ((int)(short)((unsigned)bestv[c] >> 16) == M && bco[c] == col) jr = min(jr, j0 + 1);
+        if ((int)(short)(bestv[c] & 0xFFFF) == M && (int)(short)(bcol[c] & 0xFFFF) == col) jr = min(jr, j0);
+        if ((int)(short)((unsigned)bestv[c] >> 16) == M && (int)(short)((unsigned)bcol[c] >> 16) == col) jr = min(jr, j0 + 1);
     }
     jr = st_uni(-cw_wave_max(-jr));
     best.score = M; best.col = col; best.row = jr;
