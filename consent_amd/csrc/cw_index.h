@@ -718,7 +718,13 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            positions as it goes and the anchors' rows are simply picked out of it afterwards: the second pass over the pile (one more
            table lookup per k-mer) is not needed.  Otherwise the matrix has one row per anchor and is filled by that second pass. */
         const bool tfit = (uint64_t)nk0 * Np * 2 + (uint64_t)nk0 * Nw * 8 + (uint64_t)N * 2 + 16 <= (uint64_t)p_cap * 2;
-        if (tfit) for (uint32_t i = tid; i < nk0 * Np; i += CW_IDX_THREADS) P_lds[i] = (uint16_t)CW_NONE16;
+        /* (the matrix in LDS is cleared sixteen bytes per lane and instruction: Np is even, P_lds 16-byte aligned) */
+        auto p_clear_lds = [&](const uint32_t n16) { /* n16 u16 entries, even */
+            const uint32_t nv = n16 >> 3, pat = (uint32_t)CW_NONE16 * 0x00010001u;
+            for (uint32_t i = tid; i < nv; i += CW_IDX_THREADS) ((uint4*)P_lds)[i] = make_uint4(pat, pat, pat, pat);
+            for (uint32_t i = (nv << 3) + tid; i < n16; i += CW_IDX_THREADS) P_lds[i] = (uint16_t)CW_NONE16;
+        };
+        if (tfit) p_clear_lds(nk0 * Np);
         /* When the matrix per template k-mer does not fit (depth > ~100), the support pass also writes every hit (template k-mer, sequence,
            position: 10 + 12 + 10 bits) to a list in this work-group's global scratch, and the anchors' rows are filled from the list: the
            second pass over the pile's k-mers (extraction and a table lookup each, nine in ten for nothing) is only taken when a hit does not
@@ -854,7 +860,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const uint32_t n_hits = misc[4];
         const bool from_list = hl && n_hits <= hit_cap && misc[5] == 0u;
         if (!tfit) {
-            for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
+            if (!pg) p_clear_lds(A * Np);
+            else for (uint32_t i = tid; i < A * Np; i += CW_IDX_THREADS) PWR(i, CW_NONE16);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the list was written by the other waves of this work-group (same CU, same L1) */
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -955,15 +962,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 __syncthreads();
             }
             CW_PROF(sc.ctr, 61, tid == 0);
-            for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
-                for (uint32_t w = 0; w < Nw; ++w) {
-                    const uint32_t s = w * 64 + lane;
-                    const uint32_t c = s < N ? (uint32_t)clean[s] : 0u;
-                    bool good = c == 1u;
-                    if (has_bm && (c & 0x80u)) { /* a dirty sequence counts where it is in order */
-                        const uint32_t d = N <= 1024u ? (uint32_t)didx[s] : (c & 63u);
-                        good = !((badm[(size_t)a * W + (d >> 6)] >> (d & 63u)) & 1ull);
-                    }
+            for (uint32_t w = 0; w < Nw; ++w) { /* what a lane knows about its sequence is read once, not once per anchor */
+                const uint32_t s = w * 64 + lane;
+                const uint32_t c = s < N ? (uint32_t)clean[s] : 0u;
+                const bool plain = c == 1u, part = has_bm && (c & 0x80u) != 0u; /* part: a dirty sequence counts where it is in order */
+                const uint32_t d = part ? (N <= 1024u ? (uint32_t)didx[s] : (c & 63u)) : 0u;
+                for (uint32_t a = wave; a < A; a += CW_IDX_WAVES) {
+                    bool good = plain;
+                    if (part) good = !((badm[(size_t)a * W + (d >> 6)] >> (d & 63u)) & 1ull);
                     const bool on = s < N && PRD(PROW(a) * Np + s) != CW_NONE16 && good;
                     const unsigned long long bal = __ballot(on);
                     if (lane == 0) pres[(size_t)a * Nw + w] = bal;
@@ -1038,6 +1044,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                         for (uint32_t j = lane; j < half; j += 64) dst[a * half + j] = src[(uint32_t)cand_tp[a] * half + j];
                 } else {
                     const uint32_t n2 = A * half;
+                    if (!pg) { /* out of LDS, both ends 16-byte aligned: four words per lane and instruction */
+                        const uint32_t n4 = n2 >> 2;
+                        for (uint32_t i = tid; i < n4; i += CW_IDX_THREADS) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+                        for (uint32_t i = (n4 << 2) + tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
+                    } else
                     for (uint32_t i = tid; i < n2; i += CW_IDX_THREADS) dst[i] = src[i];
                 }
             }
