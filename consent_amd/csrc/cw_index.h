@@ -866,10 +866,16 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (from_list) {
-                for (uint32_t i = tid; i < n_hits; i += CW_IDX_THREADS) {
-                    const uint32_t h = hitlist[i];
-                    const int a = tcand[h >> 22];
-                    if (a >= 0) PWR((uint32_t)a * Np + ((h >> 10) & 4095u), h & 1023u);
+                for (uint32_t i0 = tid; i0 < n_hits; i0 += 4u * CW_IDX_THREADS) { /* four list entries per thread in flight (L2 round trips) */
+                    uint32_t h4[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) { const uint32_t i = i0 + u * CW_IDX_THREADS; h4[u] = i < n_hits ? hitlist[i] : 0xFFFFFFFFu; }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t h = h4[u];
+                        const int a = i0 + u * CW_IDX_THREADS < n_hits ? tcand[h >> 22] : -1;
+                        if (a >= 0) PWR((uint32_t)a * Np + ((h >> 10) & 4095u), h & 1023u);
+                    }
                 }
             } else
             for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
