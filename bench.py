@@ -539,6 +539,10 @@ def main():
             print(f"per-step {_k} ms (HIP events):", [round(v, 2) for v in _v], file=sys.stderr)
         print("stage ms", {k: round(v, 2) for k, v in eng.timings().items()}, file=sys.stderr)
         print("longest single task, Mcycles", {t: round(float(prof[36 + i]) / 1e6, 3) for i, t in enumerate(("S", "M1", "M2", "L", "G"))}, file=sys.stderr)
+        if prof[72:120].any():  # a -DCW_DIAG build of the library (tools/diag_rows.sh): what the fills and tracebacks of the last batch did
+            dn = ("rows<=64", "linear", "far>RC", "preds(nonlinear)", "rows_packed", "linear_pk", "far_pk", "tb_trips", "tb_slow", "tb_members", "far>16", "far_pk>16")
+            for i, t in enumerate(("S", "M1", "M2", "L")):
+                print(f"diag tier {t}:", {n: int(prof[72 + 12 * i + k]) for k, n in enumerate(dn)}, file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

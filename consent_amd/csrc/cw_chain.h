@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     /* tier Q (four tasks per wave, cw_poa_q.h): members of at most 31 bases and a graph that should stay small */
                     /* tier H (two tasks per wave, cw_poa_h.h): members of 32 .. 63 bases, graph expected to stay inside 128 nodes */
                     const bool fits_h = sc.use_h != 0u && e_mx <= (uint32_t)CW_POAH_LC && e_mx >= sc.h_min_len && est <= (uint32_t)CW_POAH_ROUTE_NODES;
-                    const bool fits_s = (est_s + 1) * (e_mx + 1) <= sc.s_route_cells && est_s <= (uint32_t)CW_POA_NC;
+                    const bool fits_s = est_s <= sc.s_route_cells && e_mx <= (uint32_t)CW_POA_LC; /* s_route_cells: a node count since round 4 */
                     const uint32_t tier = !poa ? 0xFFu
                                           : (sc.use_q && e_mx <= (uint32_t)CW_POAQ_LC && est_s <= (uint32_t)CW_POAQ_ROUTE_NODES) ? 4u
                                           : (fits_h && (sc.use_h > 1u || !fits_s)) ? 5u

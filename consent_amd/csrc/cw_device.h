@@ -75,7 +75,7 @@ struct PoaMember {
 
 #define CW_TIERS 6 /* POA memory tiers: 0 = S (LDS), 1 = M1, 2 = M2, 3 = L (graph in LDS, matrix in a slab), 4 = G (all global), 5 = H (two tasks per wave,
                       cw_poa_h.h); list 0 is tier Q's (four tasks per wave, cw_poa_q.h) */
-#define CW_PROF_SLOTS 72
+#define CW_PROF_SLOTS 128
 
 /* Batch-wide counters (one struct in scratch, zeroed before every run). */
 struct BatchCounters {
@@ -91,7 +91,8 @@ struct BatchCounters {
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
-    unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile */
+    unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile; 72 + 10 t ..: row / trip
+                                               counts of tier t in a -DCW_DIAG build (cw_poa.h PoaMem::diag) */
 };
 
 struct DevBatch {
@@ -133,8 +134,8 @@ struct DevScratch {
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
-    uint32_t s_route_cells;        /* tier S takes a task whose expected matrix (nodes + 1) x (longest member + 1) stays below this many cells (its LDS holds
-                                      CW_POA_HC; a task that outgrows it is redone in tier L, late) */
+    uint32_t s_route_cells;        /* tier S takes a task whose graph is expected to stay below this many nodes (its capacity is CW_POA_NC; a task that outgrows
+                                      it is redone in tier L, late).  (Until round 3: a bound on the cells of its LDS matrix, hence the name.) */
     uint32_t m1_route_depth;       /* tier M1 is chosen with the depth-aware graph estimate too (deep piles of ~100-base members outgrow its 256 nodes) */
     uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1; 2 = also what tier S would take (CW_TIER_H) */
     uint32_t h_min_len;            /* shortest "longest member" tier H takes (CW_H_MIN_LEN, default CW_POAH_MIN_LEN) */

@@ -280,8 +280,8 @@ struct Worker {
         const double t3 = now_ms();
         if (t2 == 0) t2 = t3;
         if (getenv("CW_DRIVER_PROFILE")) { /* inspection: how the job's POA tasks spread over the tiers, and where tier L's time went */
-            uint32_t c[30]; unsigned long long pr[72]; /* cw_private.h: words 6.. = n_tier[6], 18.. = n_over[6] */
-            if (cw_debug_profile(eng, c, pr) == CW_OK)
+            uint32_t c[30] = {0}; unsigned long long pr[72] = {0}; /* cw_private.h: words 6.. = n_tier[6], 18.. = n_over[6] */
+            if (cw_debug_profile(eng, c, 30, pr, 72, nullptr, nullptr) == CW_OK)
                 fprintf(stderr, "[job %llu] windows %u tasks %u members %u | routed Q %u M1 %u M2 %u L %u, outgrew into S %u L %u G %u | L Mcycles meta %.0f fill %.0f trace %.0f merge %.0f, rows %llu chunk-rows %llu, longest task M1 %.1f M2 %.1f L %.1f Mcycles\n",
                         (unsigned long long)j.seq, n_win, c[0], c[1], c[6], c[7], c[8], c[9], c[18], c[21], c[22], pr[23] / 1e6, pr[24] / 1e6, pr[25] / 1e6, pr[26] / 1e6,
                         pr[47], pr[46], pr[37] / 1e6, pr[38] / 1e6, pr[39] / 1e6);

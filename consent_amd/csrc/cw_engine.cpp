@@ -24,8 +24,8 @@
 namespace {
 
 /* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
-static_assert(3 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: three work-groups per CU");
-static_assert(5 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: five work-groups per CU");
+static_assert(6 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: six work-groups per CU");
+static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
 static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
@@ -47,10 +47,10 @@ size_t big_slab_bytes() {
    CW_WGS_S / _M1 / _M2 / _L override (experiments). */
 struct TierMix { uint32_t s, m1, m2, l; };
 TierMix tier_mix(bool deep) {
-    TierMix m = deep ? TierMix{3, 5, 4, 2} : TierMix{3, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one */
+    TierMix m = deep ? TierMix{4, 5, 4, 2} : TierMix{4, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
     auto knob = [](const char* name, uint32_t dflt) { const char* v = getenv(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
-    if (m.s > 3) m.s = 3;
+    if (m.s > 6) m.s = 6;
     if (m.m1 > 5) m.m1 = 5;
     if (m.m2 > 4) m.m2 = 4;
     if (m.l > 4) m.l = 4;
@@ -58,7 +58,7 @@ TierMix tier_mix(bool deep) {
 }
 
 void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
-    t[0] = {0, 0};
+    t[0] = {(uint32_t)cus * 8 * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
     /* slabs: one per wave the hardware can hold at once (LDS-bound: 5, 4 and 4 work-groups per CU) plus a margin; waves claim them (slot_busy) */
     t[1] = {(uint32_t)cus * 6 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
     t[2] = {(uint32_t)cus * 5 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
@@ -101,7 +101,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.ctr, sizeof(BatchCounters));
     for (int t = 0; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4); /* list 0 = tier Q */
     for (int t = 0; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
-    for (int t = 1; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
+    for (int t = 0; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
@@ -109,7 +109,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
     put(p.pfall, (size_t)cus * p.pfall_elems * 2);
-    for (int t = 1; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
+    for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
     put(p.exg, (size_t)cus * CW_EXG_SLOTS * 8);
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
     put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
@@ -338,8 +338,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        taking only what is expected to stay below 1700 cells and tier M1 chosen by the depth-aware estimate as well, one task per batch is
        handed over instead of ~195, and the step (two engines) goes from 73.1 to 68.8 ms on the same box.  CW_S_ROUTE_CELLS /
        CW_M1_ROUTE_DEPTH=0 give the old routing (experiments; results do not depend on the tier). */
-    sc.s_route_cells = 1700;
-    if (const char* env = getenv("CW_S_ROUTE_CELLS")) { const int v = atoi(env); if (v >= 64 && v <= CW_POA_HC) sc.s_route_cells = (uint32_t)v; }
+    sc.s_route_cells = 112; /* round 4: tier S has no cell limit any more; it takes a task whose graph is expected to stay below this many NODES (its capacity: CW_POA_NC) */
+    if (const char* env = getenv("CW_S_ROUTE_NODES")) { const int v = atoi(env); if (v >= 8 && v <= CW_POA_NC) sc.s_route_cells = (uint32_t)v; }
     sc.m1_route_depth = getenv("CW_M1_ROUTE_DEPTH") ? (uint32_t)atoi(getenv("CW_M1_ROUTE_DEPTH")) : 1u;
     sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
     if (const char* env = getenv("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
@@ -351,9 +351,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
     sc.use_q = getenv("CW_NO_TIER_Q") ? 0u : 1u;
-    for (int t = 1; t < CW_TIERS; ++t) {
-        sc.tier_list[t] = (uint32_t*)(base + p.list[t]);
-        sc.over_list[t] = (uint32_t*)(base + p.over[t]);
+    for (int t = 0; t < CW_TIERS; ++t) {
+        if (t) { sc.tier_list[t] = (uint32_t*)(base + p.list[t]); sc.over_list[t] = (uint32_t*)(base + p.over[t]); }
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
         sc.slot_busy[t] = (uint32_t*)(base + p.sbusy[t]);
     }
@@ -372,7 +371,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
-    CW_HIP(hipMemsetAsync(base + p.sbusy[1], 0, p.sbusy[CW_TIERS - 1] + (size_t)p.tier[CW_TIERS - 1].slots * 4 - p.sbusy[1], st)); /* every slab free */
+    CW_HIP(hipMemsetAsync(base + p.sbusy[0], 0, p.sbusy[CW_TIERS - 1] + (size_t)p.tier[CW_TIERS - 1].slots * 4 - p.sbusy[0], st)); /* every slab free */
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(db, sc, e->prm);
@@ -564,17 +563,21 @@ int cw_debug_win_info(cw_engine* e, uint32_t n_windows, uint32_t* out16) {
     return CW_OK;
 }
 
-/* Debug/inspection (cw_private.h): 26 batch counters (u32) and 32 per-phase cycle totals (u64) of the last run. */
-int cw_debug_profile(cw_engine* e, uint32_t* counters26, unsigned long long* prof32) {
-    if (!e || !e->scratch || !counters26 || !prof32) return CW_E_INVALID;
+/* Debug/inspection (cw_private.h): the batch counters (u32) and the per-phase cycle totals (u64) of the last run; the caller says how many
+ * words each of its buffers holds and gets min(capacity, available) of them (returned through the two *_n when given). */
+int cw_debug_profile(cw_engine* e, uint32_t* counters, uint32_t counters_cap, unsigned long long* prof, uint32_t prof_cap, uint32_t* counters_n, uint32_t* prof_n) {
+    if (!e || !e->scratch || !counters || !prof) return CW_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
     CW_HIP(hipDeviceSynchronize());
     BatchCounters c;
     CW_HIP(hipMemcpy(&c, (uint8_t*)e->scratch + e->last_ctr_off, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(counters26, &c, (6 + 4 * CW_TIERS) * 4); /* n_tasks .. any_overflow, then n_tier, next_tier, n_over, next_over [CW_TIERS] each: 30 words */
-    if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] done_wgs %u any_overflow %u n_over[0] %u next_over[0] %u n_over[3] %u next_over[3] %u\n", c.done_wgs, c.any_overflow, c.n_over[0], c.next_over[0], c.n_over[3], c.next_over[3]);
-    memcpy(prof32, c.prof, sizeof(c.prof)); /* CW_PROF_SLOTS = 72 entries */
+    const uint32_t nc = counters_cap < 6u + 4u * CW_TIERS ? counters_cap : 6u + 4u * CW_TIERS; /* n_tasks .. any_overflow, then n_tier, next_tier, n_over, next_over [CW_TIERS] each */
+    const uint32_t np = prof_cap < (uint32_t)CW_PROF_SLOTS ? prof_cap : (uint32_t)CW_PROF_SLOTS;
+    memcpy(counters, &c, (size_t)nc * 4);
+    memcpy(prof, c.prof, (size_t)np * sizeof(unsigned long long));
+    if (counters_n) *counters_n = nc;
+    if (prof_n) *prof_n = np;
     return CW_OK;
 }
 

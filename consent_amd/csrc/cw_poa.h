@@ -60,7 +60,7 @@
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_SLAB_BYTES (CW_POA_HC * 2 + CW_POA_DC * 16 + 4 * CW_POA_NC + CW_POA_GRAPH_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC))
+
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
    predecessors, rank <-> node maps, in-edge heads and degrees, bases, sequence ranks); what only the rank bookkeeping before a fill
    and the merge touch -- aligned-node lists, in-edge lists (source, next) and tails, coverage counts, the scratch of the rank placement,
@@ -68,25 +68,28 @@
    That is what lets more waves share a CU's LDS where the time goes: M1 6.4 KB per wave (five work-groups per CU), M2 12.9 KB (three
    waves in 38 KB), L 37 KB (it fits the holes the other tiers leave). */
 #define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16) /* + the chain tables p2/p4 (tier M1) */
+#define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + 16 * 64 * 2 + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
 #define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
+#define CW_POA_SLAB_BYTES CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
 #define CW_POA_SLAB2_TOTAL(NC, EC, LC) (CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC) + CW_POA_COLD2_BYTES(NC, EC, LC))
 
-#define CW_RM_NP(m) (int)(((m) >> 2) & 0x1FFFu)
-#define CW_RM_LIN(m) (((m) & 0x8000u) != 0u)
-#define CW_RM_X(m) (int)((m) >> 16)
-#define CW_RM_MAX_PRED 8191u
+/* the row word (PoaMem::rmeta): base | linear << 2 | sink << 3 | slab << 4 | kind << 5 | n_pred << 8 (11 bits) | x << 19 (13 bits) */
+#define CW_RM_NP(m) (int)(((m) >> 8) & 0x7FFu)
+#define CW_RM_LIN(m) (((m) & 4u) != 0u)
+#define CW_RM_X(m) (int)((m) >> 19)
+#define CW_RM_MAX_PRED 2047u
+#define CW_RM_WORD(base, np, lin, sink, kind, x) ((uint32_t)(base) | ((lin) ? 4u : 0u) | ((sink) ? 8u : 0u) | ((uint32_t)(kind) << 5) | ((uint32_t)(np) << 8) | ((uint32_t)(x) << 19))
 template <typename HT>
 struct PoaMem {
     HT* H;
     unsigned long long* dirs; /* traceback codes, 2 bits per cell as two ballots per (row, chunk): 0 diagonal and
                                  1 vertical through the first predecessor, 2 horizontal, 3 = compare cell values */
-    uint32_t* rmeta;    /* rank -> base | n_pred << 2 (13 bits; the virtual start counts as 1) | linear << 15 | x << 16, where linear = the only
-                           predecessor is the rank before, and x = that predecessor's DP row when n_pred is 1, else the offset of the node's list in
-                           plist: the fill reads this ONE word per row and branches on one bit (CW_RM_*) */
+    uint32_t* rmeta;    /* rank -> the row word (CW_RM_*): base, n_pred (the virtual start counts as 1), sink = no out-edge, linear = the only predecessor is
+                           the rank before, x = that predecessor's DP row when n_pred is 1, else the offset of the node's list in plist; kind and slab
+                           bit: what cw_poa_c.h's fill does with the row.  The fills read this ONE word per row */
     uint16_t* rpred0;   /* rank -> DP row of its first predecessor (0 = virtual start)                           */
     uint16_t* p2;       /* rank -> DP row two / four steps up the first-predecessor chain, CW_NONE16 beyond the start */
     uint16_t* p4;       /* (only where the traceback walks matrix tiles: tier M1; else NULL)                      */
@@ -110,6 +113,15 @@ struct PoaMem {
     uint8_t* sq;        /* current member, base codes                                                            */
     uint32_t n_cap, e_cap, l_cap, h_cap, d_cap;
     bool runs;          /* consume runs of equal moves per round trip (pays when paths have long straight stretches) */
+    uint32_t* codes;    /* cw_poa_c.h: the traceback's decisions, four bits per cell (LDS in tier S, the wave's slab in tiers M1 / M2), c_cap words */
+    int16_t* ring;      /* cw_poa_c.h: the last CW_RING rows of the fill (LDS; tiers M1 / M2) */
+    uint32_t* gflag;    /* cw_poa_c.h: one bit per rank: the row is also written to the slab (a later row needs it from more than CW_RING ranks back,
+                           or it belongs to a node with more than three in-edges); NULL where every row is kept anyway */
+    uint32_t c_cap;
+#ifdef CW_DIAG
+    unsigned long long* diag; /* diagnostic build: ten counters of this tier in BatchCounters::prof (rows / linear rows / far loads / predecessor trips of the
+                                 unpacked fill, rows / linear / far loads of the packed fill, traceback trips, slow steps, members) */
+#endif
     bool pad64;         /* the matrix is in a slab with 64 cells of slack behind it: rows of <= 64 columns are stored and loaded by all 64 lanes
                            (no execution mask round the store of a row, no mask round a far row's load; see poa_fill) */
 };
@@ -147,6 +159,10 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.has_out = p; p += nc;
     M.sq = p; p += lc + 1;
     M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false; M.pad64 = false;
+    M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0;
+#ifdef CW_DIAG
+    M.diag = nullptr;
+#endif
     return M;
 }
 
@@ -178,11 +194,17 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         for (int k = 0; k < RC; ++k) rc_[k][c] = j * G; /* row 0 */
     }
     uint32_t meta_n = M.rmeta[0];
+#ifdef CW_DIAG
+    uint32_t dg_lin = 0, dg_far = 0, dg_pred = 0, dg_far16 = 0;
+#endif
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
         if (r + 1 < n) meta_n = M.rmeta[r + 1];
         const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta), pr0 = off; /* pr0 is meaningful when np == 1 */
+#ifdef CW_DIAG
+        if (CW_RM_LIN(meta)) dg_lin++; else { dg_pred += (uint32_t)np; for (int q = 0; q < np; ++q) { const int prow = (np == 1) ? pr0 : (int)M.plist[off + q]; if (i - prow > RC) dg_far++; if (i - prow > 16) dg_far16++; } }
+#endif
         int v[NCH], dgv[NCH], upv[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { v[c] = CW_NEG; dgv[c] = CW_NEG; upv[c] = CW_NEG; }
@@ -259,6 +281,9 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             }
         }
     }
+#ifdef CW_DIAG
+    if (lane == 0 && M.diag) { atomicAdd(&M.diag[0], (unsigned long long)n); atomicAdd(&M.diag[1], (unsigned long long)dg_lin); atomicAdd(&M.diag[2], (unsigned long long)dg_far); atomicAdd(&M.diag[3], (unsigned long long)dg_pred); atomicAdd(&M.diag[10], (unsigned long long)dg_far16); }
+#endif
     cw_wave_sync();
 }
 
@@ -317,11 +342,17 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         qpk[c] = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* see pk_score */
     }
     uint32_t meta_n = M.rmeta[0];
+#ifdef CW_DIAG
+    uint32_t dg_lin = 0, dg_far = 0, dg_far16 = 0;
+#endif
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
         if (r + 1 < n) meta_n = M.rmeta[r + 1];
         const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta), pr0 = off; /* pr0 is meaningful when np == 1 */
+#ifdef CW_DIAG
+        if (CW_RM_LIN(meta)) dg_lin++; else for (int q = 0; q < np; ++q) { const int prow = (np == 1) ? pr0 : (int)M.plist[off + q]; if (i - prow > RC) dg_far++; if (i - prow > 16) dg_far16++; }
+#endif
         int v[NCH2], dgv[NCH2], upv[NCH2], srow[NCH2];
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
@@ -416,8 +447,13 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
             }
         }
     }
+#ifdef CW_DIAG
+    if (lane == 0 && M.diag) { atomicAdd(&M.diag[4], (unsigned long long)n); atomicAdd(&M.diag[5], (unsigned long long)dg_lin); atomicAdd(&M.diag[6], (unsigned long long)dg_far); atomicAdd(&M.diag[11], (unsigned long long)dg_far16); }
+#endif
     cw_wave_sync();
 }
+
+#include "cw_poa_c.h"
 
 /* One traceback step at a node with several predecessors (or whose step the direction words left open), decided from the cell
  * values in the order of preference of cw_policy.h: diagonal through the in-edges in order, then vertical through them, then
@@ -468,8 +504,12 @@ __device__ __forceinline__ bool poa_slow_step(const PoaMem<HT>& M, const int i, 
    M2, whose capacities keep every score far inside int16); 2 = the same for tier L while nodes + columns <= CW_POA_PK_SPAN, i.e.
    while |score| <= 8 * span stays clear of the packed "minus infinity" even after the per-column gap offsets are taken out. */
 #define CW_POA_PK_SPAN 2600
-template <typename HT, int PK>
-__device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
+/* CM: 0 = the matrix path only; 2 = members of <= 63 bases take the recorded-decision path of cw_poa_c.h (tiers S / M1 / M2) */
+#ifndef CW_POA_CODES
+#define CW_POA_CODES 1
+#endif
+template <typename HT, int PK, int CM = 0, int LCAP = 1023> /* LCAP: the tier's longest member -- fills for wider rows are not compiled into its kernel */
+__device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
                        unsigned long long (&acc)[6]) {
     unsigned long long _pt = __builtin_readcyclecounter();
 #define POA_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
@@ -511,6 +551,10 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         /* ---- per-rank metadata (parallel over ranks) ---- */
         if (!meta_ok) {
             int run = 0;
+            if (CM == 2 && M.gflag) { /* cw_poa_c.h: which rows the fill also writes to the slab */
+                for (int w = lane; w < (int)(M.n_cap / 32 + 2); w += 64) M.gflag[w] = 0u;
+                cw_wave_sync();
+            }
             for (int r0 = 0; r0 < n; r0 += 64) {
                 const int r = r0 + lane;
                 const int node = r < n ? M.r2n[r] : 0;
@@ -519,20 +563,34 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 const int off = run + inc - d;
                 if (r < n) {
                     int q = off, first = 0;
+                    bool far_ = false; /* a predecessor more than CW_RING ranks back */
                     for (uint32_t e = M.in_head[node]; e != CW_NONE16; e = M.enext[e]) {
                         const int pr = M.n2r[M.efrom[e]] + 1;
                         if (q == off) first = pr;
                         M.plist[q++] = (uint16_t)pr;
+                        far_ = far_ || r + 1 - pr > CW_RING;
+                        if (CM == 2 && M.gflag && (r + 1 - pr > CW_RING || d > 3))
+                            __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
+                    if (CM == 2 && M.gflag && d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     M.rpred0[r] = (uint16_t)first;
                     const uint32_t np_ = (uint32_t)(d ? d : 1);
-                    M.rmeta[r] = (uint32_t)M.nbase[node] | (np_ << 2) | ((np_ == 1u && first == r) ? 0x8000u : 0u) | ((uint32_t)(np_ == 1u ? first : off) << 16);
+                    const bool lin_ = np_ == 1u && first == r;
+                    /* cw_poa_c.h row kinds: 0 the rank before (registers); 1 / 2 / 3 one, two, three predecessors that are all in the row
+                       store (any earlier row in tier S; at most CW_RING ranks back in tiers M1 / M2); 5 everything else */
+                    uint32_t kind_ = lin_ ? 0u : 5u;
+                    if (CM != 0 && !lin_ && np_ <= 3u && first != 0 && !far_) kind_ = np_;
+                    M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, lin_, !M.has_out[node], kind_, np_ == 1u ? first : off);
                 }
                 if (__ballot(r < n && (uint32_t)d > CW_RM_MAX_PRED) != 0ull) return 2; /* more in-edges than the row word counts (cannot happen below 8192 members) */
                 run += cw_lane_value(inc, 63);
             }
             meta_ok = true;
             cw_wave_sync();
+            if (CM == 2 && M.gflag) { /* the slab bit of the row word: set by the rows that will read the row back from the slab */
+                for (int r = lane; r < n; r += 64) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
+                cw_wave_sync();
+            }
             if (M.p2) { /* two and four steps up the first-predecessor chain: a traceback tile gets its eight rows in three reads, not seven */
                 for (int r = lane; r < n; r += 64) {
                     const int a = M.rpred0[r];
@@ -548,9 +606,22 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
         }
         POA_PROF(0);
 
-        /* ---- DP fill ---- */
-        for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
+        /* ---- DP fill, end cell, traceback ---- */
         for (int j = lane; j < L; j += 64) M.seqrank[j] = CW_NONE16;
+        bool coded = false; /* members of <= 63 bases in tiers S / M1 / M2: the fill records the traceback's decisions (cw_poa_c.h) */
+        if constexpr (CM != 0 && CW_POA_CODES != 0) {
+            if (cols <= 64 && M.codes != nullptr) {
+                if ((uint32_t)(((n + 7) >> 3) * 64) > M.c_cap || (uint32_t)((n + 1) * 64) > M.h_cap) return 2;
+                coded = true;
+            }
+        }
+#ifdef CW_POA_VERIFY
+        const bool run_matrix_path = true;
+#else
+        const bool run_matrix_path = !coded;
+#endif
+        if (run_matrix_path) {
+        for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         cw_wave_sync();
         const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
         const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
@@ -565,9 +636,13 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 }
             }
             else if (cols <= 128) poa_fill_pk<1, PK == 2>(M, n, cols, hs, lane, use_dirs);
-            else if (cols <= 256) poa_fill_pk<2, PK == 2>(M, n, cols, hs, lane, use_dirs);
-            else if (cols <= 512) poa_fill_pk<4, PK == 2>(M, n, cols, hs, lane, use_dirs);
-            else if constexpr (PK == 2) poa_fill_pk<8, PK == 2>(M, n, cols, hs, lane, use_dirs);
+            else if constexpr (LCAP > 127) {
+                if (cols <= 256) poa_fill_pk<2, PK == 2>(M, n, cols, hs, lane, use_dirs);
+                else if constexpr (LCAP > 255) {
+                    if (cols <= 512) poa_fill_pk<4, PK == 2>(M, n, cols, hs, lane, use_dirs);
+                    else if constexpr (PK == 2) poa_fill_pk<8, PK == 2>(M, n, cols, hs, lane, use_dirs);
+                }
+            }
         } else {
             if (cols <= 64) poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs);
             else if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
@@ -667,7 +742,13 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                    through the first predecessor, other predecessors, vertical, horizontal); the path is then three ballots
                    followed on the scalar unit. */
                 const int tr = lane >> 3, tc = lane & 7;
+#ifdef CW_DIAG
+                if (lane == 0 && M.diag) atomicAdd(&M.diag[9], 1ull);
+#endif
                 while (i > 0) {
+#ifdef CW_DIAG
+                    if (lane == 0 && M.diag) atomicAdd(&M.diag[7], 1ull);
+#endif
                     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
                     int row = i;
                     if (M.p2) { /* tr steps up the chain: 4 + 2 + 1 */
@@ -721,6 +802,9 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                         /* a node with several predecessors: one step decided from direct reads (same order of preference) */
                         const int pr0 = __builtin_amdgcn_readfirstlane((int)M.rpred0[i - 1]);
                         int pi, pj;
+#ifdef CW_DIAG
+                        if (lane == 0 && M.diag) atomicAdd(&M.diag[8], 1ull);
+#endif
                         if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
@@ -728,6 +812,43 @@ __device__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b,
                 }
             }
             /* i == 0: the remaining sequence positions are insertions, already CW_NONE16 */
+        }
+#ifdef CW_POA_VERIFY
+        if (coded) { /* keep the matrix path's answer, then let the recorded-decision path give its own */
+            cw_wave_sync();
+            for (int j = lane; j < L; j += 64) { M.pat[j] = M.seqrank[j]; M.seqrank[j] = CW_NONE16; }
+            if (lane == 0) M.pat[L] = (uint16_t)bi;
+            cw_wave_sync();
+        }
+#endif
+        }
+        if constexpr (CM != 0 && CW_POA_CODES != 0) {
+            if (coded) {
+                cw_wave_sync();
+                const int bi_c = poa_fill_c<CM>(M, n, cols, lane);
+                POA_PROF(1);
+                if (!poa_trace_c<CM>(M, n, bi_c, cols, lane)) return 3;
+#ifdef CW_POA_VERIFY
+                cw_wave_sync();
+                {
+                    bool bad = false;
+                    for (int j = lane; j < L; j += 64) bad = bad || M.pat[j] != M.seqrank[j];
+                    const unsigned long long bb = __ballot(bad);
+                    const bool bad_bi = (int)M.pat[L] != bi_c;
+                    if (lane == 0) {
+                        atomicAdd(&sc.ctr->prof[120], 1ull);
+                        if (bb != 0ull || bad_bi) {
+                            if (atomicAdd(&sc.ctr->prof[121], 1ull) == 0ull) { /* the first difference: task window, member, columns, rows, end rows */
+                                sc.ctr->prof[122] = ((unsigned long long)t.window << 32) | mi;
+                                sc.ctr->prof[123] = ((unsigned long long)cols << 32) | (unsigned)n;
+                                sc.ctr->prof[124] = ((unsigned long long)M.pat[L] << 32) | (unsigned)bi_c;
+                                sc.ctr->prof[125] = bb;
+                            }
+                        }
+                    }
+                }
+#endif
+            }
         }
         cw_wave_sync();
         POA_PROF(2);
@@ -956,14 +1077,44 @@ __device__ __forceinline__ void poa_producer_done(const DevScratch& sc) {
     }
 }
 
-/* ---- tier S: one task per wave, graph + DP matrix in LDS, work-stealing over the task list -------- */
-__global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, DevScratch sc) {
+/* ---- tier S: one task per wave, work-stealing over the task list ---------------------------------------------------
+ * Round 4: laid out like tiers M1 / M2 -- what the fill and the traceback read in LDS (5.9 KB per wave with the row ring of cw_poa_c.h,
+ * where graph, merge arrays, a 2048-cell matrix and the code words took 12.9), everything only the merge and the rank bookkeeping touch,
+ * the matrix of the rare member of more than 63 bases, flagged rows and the code words in a slab the wave claims (sc.slab[0]).
+ * Capacities: CW_POA_NC nodes, CW_POA_LC bases; the 2048-cell limit is gone. */
+__global__ void __launch_bounds__(64 * CW_POA_WAVES, 5) cw_poa_kernel(DevBatch b, DevScratch sc) { /* five waves per SIMD: 96 VGPRs */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, CW_POA_HC, CW_POA_DC, nullptr, nullptr, nullptr,
-                                                 false, true);
+    uint32_t gw = 0;
+    if (lane == 0) { /* claim a free slab, see cw_poa_slab_kernel */
+        const uint32_t n_slots = sc.slots[0];
+        uint32_t s = (uint32_t)(((unsigned long long)(blockIdx.x * CW_POA_WAVES + wave) * 2654435761ull) % n_slots);
+        for (;;) {
+            if (__hip_atomic_load(&sc.slot_busy[0][s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
+                atomicCAS(&sc.slot_busy[0][s], 0u, 1u) == 0u) break;
+            s = s + 1u == n_slots ? 0u : s + 1u;
+        }
+        gw = s;
+    }
+    gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gw);
+    typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
+    uint8_t* my_slab = (uint8_t*)(cw_gptr)(sc.slab[0] + (size_t)gw * sc.slab_bytes[0]);
+    int16_t* hslab = (int16_t*)my_slab;
+    unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC));
+    uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC) + CW_POA_DSLAB_BYTES(CW_POA_NC, CW_POA_LC);
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, (CW_POA_NC + 1) * (CW_POA_LC + 1), 0, hslab, dslab, cold, true, true);
+    M.H = hslab; M.dirs = dslab;
+    {
+        uint8_t* extra = lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(CW_POA_NC));
+        M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);
+        M.codes = (uint32_t*)dslab; M.c_cap = (uint32_t)(CW_POA_DSLAB_BYTES(CW_POA_NC, CW_POA_LC) / 4);
+    }
+    M.pad64 = true;
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#ifdef CW_DIAG
+    M.diag = &sc.ctr->prof[72];
+#endif
     /* see cw_poa_slab_kernel: all but the last persist_wgs work-groups take a chunk of tasks and end */
     const bool yields = blockIdx.x + sc.persist_wgs[0] < gridDim.x;
     uint32_t ran = 0;
@@ -976,7 +1127,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
             if (qi >= n_q) break;
             const uint32_t ti = sc.over_list[0][qi];
             const PoaTask t = sc.tasks[ti];
-            const int rc = poa_run<int16_t, true>(M, t, b, sc, lane, acc);
+            const int rc = poa_run<int16_t, 1, 2, CW_POA_LC>(M, t, b, sc, lane, acc);
             if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
             cw_wave_sync();
         }
@@ -989,13 +1140,14 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
         const PoaTask t = sc.tasks[ti];
         if (t.state != 0) continue; /* routed to a larger tier by the index kernel */
         const unsigned long long _t0 = __builtin_readcyclecounter();
-        const int rc = poa_run<int16_t, true>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int16_t, 1, 2, CW_POA_LC>(M, t, b, sc, lane, acc);
         { const unsigned long long d = __builtin_readcyclecounter() - _t0; acc[5] = d > acc[5] ? d : acc[5]; }
         if (lane == 0) poa_hand_over(sc, t, ti, rc, 3);
         cw_wave_sync();
         if (yields && ++ran >= CW_POA_CHUNK_S) break;
     }
     poa_flush_prof(sc, 8, acc, lane);
+    if (lane == 0) __hip_atomic_store(&sc.slot_busy[0][gw], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); /* the slab goes back */
     poa_producer_done(sc);
 }
 
@@ -1003,7 +1155,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_kernel(DevBatch b, D
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 5 : 1) /* M1: five waves per SIMD (96 VGPRs, a few spills in the merge): measured +7 % over four */
+__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 5 : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1036,7 +1188,15 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
                                            true, TIER <= 2);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
+    if (TIER <= 2) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
+        uint8_t* extra = lds + (size_t)wave * slab + (slab - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(NC));
+        M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);
+        M.codes = (uint32_t*)dslab; M.c_cap = (uint32_t)(CW_POA_DSLAB_BYTES(NC, LC) / 4);
+    }
     M.runs = TIER >= 3; /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
+#ifdef CW_DIAG
+    M.diag = &sc.ctr->prof[72 + 12 * TIER];
+#endif
     M.pad64 = true; /* the slab's matrix area is (NC + 1) x (LC + 1) cells: a matrix of <= 64 columns leaves more than 64 cells free */
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
@@ -1047,7 +1207,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         const PoaTask t = sc.tasks[ti];
         if (t.n_members == 0) return; /* a neutral entry: the chain kernel ran out of task or list slots (cw_chain.h "cap_ok") */
         const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
-        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2)>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2), (TIER < 3 ? 2 : 0), LC>(M, t, b, sc, lane, acc);
         const unsigned long long _t1 = __builtin_readcyclecounter();
         acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];
         if (lane == 0 && sc.task_dbg) { /* inspection aid (CW_TASK_TRACE): when each task of the slab tiers ran (10 ns units since the tier sort), where, and how it ended */
@@ -1232,7 +1392,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES) cw_poa_big_kernel(DevBatch 
         if (bi >= n_big) break;
         const uint32_t ti = sc.over_list[4][bi];
         const PoaTask t = sc.tasks[ti];
-        const int rc = poa_run<int32_t, false>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int32_t, 0, 0>(M, t, b, sc, lane, acc);
         if (lane == 0) poa_hand_over(sc, t, ti, rc, CW_TIERS);
         cw_wave_sync();
     }

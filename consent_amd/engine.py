@@ -114,7 +114,7 @@ def load_library():
     lib.cw_poll.restype = C.c_int
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.cw_extract_piles_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p]
     lib.cw_stitch_device.argtypes = [C.c_void_p, C.POINTER(ReadSet), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.c_uint32, C.c_uint32,
@@ -514,8 +514,8 @@ class Engine:
 
     def profile(self):
         c = np.zeros(30, np.uint32)  # n_tasks, n_members, 3 cursors, any_overflow, then n_tier / next_tier / n_over / next_over for the six tiers
-        p = np.zeros(72, np.uint64)  # phase cycle totals (cw_device.h BatchCounters::prof)
-        _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), _ptr(p)), "cw_debug_profile")
+        p = np.zeros(128, np.uint64)  # phase cycle totals (cw_device.h BatchCounters::prof)
+        _check(self.lib, self.lib.cw_debug_profile(self.handle, _ptr(c), len(c), _ptr(p), len(p), None, None), "cw_debug_profile")
         return c, p
 
     def win_info(self, n_windows):

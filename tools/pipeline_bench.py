@@ -4,7 +4,8 @@ reads) and a timed run of the native driver through bin/CONSENT-correction / bin
 
   config 1  --genome 460000  --cov 10 --profile pacbio                 (example/reads.fasta scale: 10x sim PacBio)
   config 4  --genome 4600000 --cov 30 --profile ont                    (E. coli 30x, CONSENT-correct --type ONT)
-  config 5  --genome 3350000 --cov 30 --profile pacbio --polish 86     (CONSENT-polish: 86 contigs of 3.35 Mbp + 30x reads)
+  config 5  --contigs tests/golden/rawAssembly.2bit.npz --cov 30       (CONSENT-polish on the reference's example assembly: 86 contigs, 3.35 Mbp,
+                                                                        + 30x reads simulated from it; --polish N --genome G = N synthetic contigs)
 GPU box only.  CW_BENCH_GPUS = number of GPUs handed to -j."""
 import argparse
 import json
@@ -116,6 +117,78 @@ def generate(d, glen, cov, profile, polish=0, rlen=8000, seed=7):
     return fa, paf, (ctg_fa if polish else None), n_reads, n_lines
 
 
+def generate_from_contigs(d, names, contigs, cov, profile, rlen=8000, seed=11, truth_err=0.03):
+    """Polishing data for GIVEN contigs (BASELINE configs[4]: example/rawAssembly.fasta, the fixture tests/golden/rawAssembly.2bit.npz):
+    every contig is taken as a draft of a truth sequence that differs from it by `truth_err` (truth = noisy copy of the contig, position
+    map kept), `cov`x reads of the profile are drawn from the truth, and the PAF is written from the ground-truth coordinates as
+    `minimap2 | sort -k6,6 | reformatPAF` leaves it (CONSENT-polish:189-193: the contig is the query, one run of lines per contig).
+    Writes contigs.fa, reads.fa, ovl.paf under d; returns (reads, paf, contigs, n_reads, n_overlaps)."""
+    mix = MIX[profile]
+    rng = np.random.default_rng(seed)
+    os.makedirs(d, exist_ok=True)
+    fa, paf, ctg_fa = os.path.join(d, "reads.fa"), os.path.join(d, "ovl.paf"), os.path.join(d, "contigs.fa")
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    n_reads = n_lines = 0
+    with open(ctg_fa, "w") as fc, open(fa, "w") as fr, open(paf, "w") as fp:
+        for name, ctg in zip(names, contigs):
+            fc.write(f">{name}\n{lut[ctg].tobytes().decode()}\n")
+            truth, pos_ct = noisy(rng, ctg, truth_err, (0.3, 0.3))  # contig position -> truth position
+            tl = len(truth)
+            inv = np.minimum(np.searchsorted(pos_ct, np.arange(tl + 1), side="left"), len(ctg))  # truth position -> contig position
+            q = (0, tl, inv, False, ctg)
+            fl = min(4000, tl // 4)  # the truth continues beyond the draft's ends: reads hang over them and overlap the contig partially
+            ext = np.concatenate([rng.integers(0, 4, fl).astype(truth.dtype), truth, rng.integers(0, 4, fl).astype(truth.dtype)])
+            lines = []
+            for _ in range(max(1, (tl + fl) * cov // rlen)):
+                ln = int(min(tl - 1, max(1000, rng.lognormal(np.log(rlen), 0.35))))
+                g0 = int(rng.integers(0, len(ext) - ln)) - fl  # truth coordinate of the read's first base (negative: in the left flank)
+                s_, pos = noisy(rng, ext[g0 + fl : g0 + fl + ln], 0.12, mix)
+                rev = bool(rng.random() < 0.5)
+                a_ = lut[s_]
+                if rev:
+                    a_ = COMP[a_[::-1]]
+                rid = f"r{n_reads}"
+                fr.write(f">{rid}\n{a_.tobytes().decode()}\n")
+                n_reads += 1
+                a, b = max(0, g0), min(tl, g0 + ln)
+                if b - a < 500:
+                    continue
+                t = (g0, g0 + ln, pos, rev, s_)
+                qs, qe = span(q, a, b)
+                ts, te = span(t, a, b)
+                lines.append((a, f"{name}\t{len(ctg)}\t{qs}\t{qe}\t{'-' if rev else '+'}\t{rid}\t{len(s_)}\t{ts}\t{te}\t{int((b - a) * 0.8)}\t{b - a}\t60\n"))
+            for _, l in lines:
+                fp.write(l)
+            n_lines += len(lines)
+    return fa, paf, ctg_fa, n_reads, n_lines
+
+
+def load_contigs(path):
+    """contigs from the 2-bit fixture (tests/golden/make_assembly_fixture.py) or from a FASTA file: (names, [code arrays])"""
+    if path.endswith(".npz"):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_assembly_fixture as maf
+
+        return maf.load(path)
+    lutc = np.full(256, 3, np.uint8)  # utils.cpp:21-32: everything but A, C, G is T
+    for i_, c_ in enumerate(b"ACG"):
+        lutc[c_] = i_
+        lutc[c_ + 32] = i_
+    names, seqs, cur = [], [], []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if names:
+                seqs.append("".join(cur))
+            names.append(line[1:].split(" ")[0])
+            cur = []
+        elif line:
+            cur.append(line)
+    if names:
+        seqs.append("".join(cur))
+    return names, [lutc[np.frombuffer(x.encode(), np.uint8)] for x in seqs]
+
+
 def replicate(fa, paf, copies):
     """`copies` independent copies of a read-correction data set (reads r<i> become c<k>r<i>, piles refer to their own copy): the same
     piles `copies` times over -- a larger job list for the scaling runs without minutes of simulation.  Returns the new (reads, paf)."""
@@ -138,12 +211,18 @@ def main():
     ap.add_argument("--cov", type=int, default=30)
     ap.add_argument("--profile", choices=sorted(MIX), default="pacbio")
     ap.add_argument("--polish", type=int, default=0, help="number of contigs: polish them with the reads instead of correcting the reads")
+    ap.add_argument("--contigs", default="", help="polish THESE contigs (FASTA, or the 2-bit fixture tests/golden/rawAssembly.2bit.npz = BASELINE configs[4]) with reads simulated from them")
     ap.add_argument("--read-len", type=int, default=8000)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--copies", type=int, default=1, help="read correction only: this many independent copies of the data set in one run")
     args = ap.parse_args()
     d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
-    fa, paf, ctg_fa, n_reads, n_lines = generate(d, args.genome, args.cov, args.profile, args.polish, args.read_len)
+    if args.contigs:
+        names_, ctgs_ = load_contigs(args.contigs)
+        fa, paf, ctg_fa, n_reads, n_lines = generate_from_contigs(d, names_, ctgs_, args.cov, args.profile, args.read_len)
+        args.polish, args.genome = len(names_), int(sum(len(c) for c in ctgs_))
+    else:
+        fa, paf, ctg_fa, n_reads, n_lines = generate(d, args.genome, args.cov, args.profile, args.polish, args.read_len)
     if not args.polish:
         fa, paf = replicate(fa, paf, args.copies)
     print(f"data set: genome {args.genome}, {n_reads} {args.profile} reads ({os.path.getsize(fa) / 1e6:.0f} MB), {n_lines} overlaps ({os.path.getsize(paf) / 1e6:.0f} MB)"
