@@ -1207,7 +1207,12 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         const PoaTask t = sc.tasks[ti];
         if (t.n_members == 0) return; /* a neutral entry: the chain kernel ran out of task or list slots (cw_chain.h "cap_ok") */
         const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
-        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2), (TIER < 3 ? 2 : 0), LC>(M, t, b, sc, lane, acc);
+        /* tier M2's rows are 85 % linear (long graphs, short members): there the matrix fill's 37-instruction row beats the recorded
+           decisions' 52, and its slower traceback does not make up for it (measured: 35.8 against 38.5 G wave-cycles per batch) */
+#ifndef CW_M2_CODES
+#define CW_M2_CODES 0
+#endif
+        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2), (TIER == 1 || (TIER == 2 && CW_M2_CODES) ? 2 : 0), LC>(M, t, b, sc, lane, acc);
         const unsigned long long _t1 = __builtin_readcyclecounter();
         acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];
         if (lane == 0 && sc.task_dbg) { /* inspection aid (CW_TASK_TRACE): when each task of the slab tiers ran (10 ns units since the tier sort), where, and how it ended */

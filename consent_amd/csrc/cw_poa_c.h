@@ -79,46 +79,51 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
     for (int r0 = 0; r0 < n; r0 += 64) {
         /* the row words of the next 64 rows, one per lane: a row costs a v_readlane, not an LDS round trip */
         const uint32_t meta_v = (r0 + lane < n) ? M.rmeta[r0 + lane] : 0u;
-        const int cnt = min(64, n - r0);
+        const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - r0));
         uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, 0);
+        int s_l = (sq == (int)(meta & 3u)) ? ms_l : xs_l;
         uint32_t acc = 0u; /* the codes of eight rows of this lane's column */
         for (int rl = 0; rl < cnt; ++rl) {
             const int i = r0 + rl + 1;
-            const int s_l = (sq == (int)(meta & 3u)) ? ms_l : xs_l;
-            const uint32_t kind = (meta >> 5) & 7u;
-            const int x = CW_RM_X(meta);
             int kD, kV;
-            if (kind == 0u) {
+            if (CW_RM_LIN(meta)) {
                 kD = cw_wave_shr1(rc0, 0) + s_l; kV = rc0 + G4;
-            } else if (kind == 1u) {
-                const int up = (int)rowst[(x & (CW_RING - 1)) * 64];
-                kD = cw_wave_shr1(up, 0) + s_l; kV = up + G4;
-            } else if (kind <= 3u) {
-                /* two or three in-edges, every predecessor in the row store: entry q of the list in lane q, its offset computed there too */
-                const int pl = (int)M.plist[x + lane];
-                const int po = (pl & (CW_RING - 1)) * 64;
-                const int up0 = (int)rowst[__builtin_amdgcn_readlane(po, 0)];
-                const int up1 = (int)rowst[__builtin_amdgcn_readlane(po, 1)] - 1;
-                int dm = max(cw_wave_shr1(up0, 0), cw_wave_shr1(up1, 0)), vm = max(up0, up1);
-                if (kind == 3u) {
-                    const int up2 = (int)rowst[__builtin_amdgcn_readlane(po, 2)] - 2;
-                    dm = max(dm, cw_wave_shr1(up2, 0)); vm = max(vm, up2);
+            } else {
+                const uint32_t kind = (meta >> 5) & 7u;
+                const int x = CW_RM_X(meta);
+                if (kind == 1u) {
+                    const int up = (int)rowst[(x & (CW_RING - 1)) * 64];
+                    kD = cw_wave_shr1(up, 0) + s_l; kV = up + G4;
+                } else if (kind <= 3u) {
+                    /* two or three in-edges, every predecessor in the ring: entry q of the list in lane q, its ring offset computed there too */
+                    const int po = ((int)M.plist[x + lane] & (CW_RING - 1)) * 64;
+                    const int up0 = (int)rowst[__builtin_amdgcn_readlane(po, 0)];
+                    const int up1 = (int)rowst[__builtin_amdgcn_readlane(po, 1)] - 1;
+                    int dm = max(cw_wave_shr1(up0, 0), cw_wave_shr1(up1, 0)), vm = max(up0, up1);
+                    if (kind == 3u) {
+                        const int up2 = (int)rowst[__builtin_amdgcn_readlane(po, 2)] - 2;
+                        dm = max(dm, cw_wave_shr1(up2, 0)); vm = max(vm, up2);
+                    }
+                    kD = dm + s_l; kV = vm + G4;
+                } else { /* the general row: any number of in-edges, rows from anywhere (the virtual start, the slab) */
+                    const int np = CW_RM_NP(meta);
+                    int dm = NEGD, vm = NEGD;
+                    for (int q = 0; q < np; ++q) {
+                        const int prow = np == 1 ? x : __builtin_amdgcn_readfirstlane((int)M.plist[x + q]);
+                        int up;
+                        if (prow == 0) up = 3;
+                        else if (i - prow <= CW_RING) up = (int)rowst[(prow & (CW_RING - 1)) * 64];
+                        else up = cwc_gload_i16_wait(Hg + prow * 64);
+                        up -= q < 3 ? q : 3;
+                        dm = max(dm, cw_wave_shr1(up, 0)); vm = max(vm, up);
+                    }
+                    kD = dm + s_l; kV = vm + G4;
                 }
-                kD = dm + s_l; kV = vm + G4;
-            } else { /* the general row: any number of in-edges, rows from anywhere (the virtual start, the slab) */
-                const int np = CW_RM_NP(meta);
-                int dm = NEGD, vm = NEGD;
-                for (int q = 0; q < np; ++q) {
-                    const int prow = np == 1 ? x : __builtin_amdgcn_readfirstlane((int)M.plist[x + q]);
-                    int up;
-                    if (prow == 0) up = 3;
-                    else if (i - prow <= CW_RING) up = (int)rowst[(prow & (CW_RING - 1)) * 64];
-                    else up = cwc_gload_i16_wait(Hg + prow * 64);
-                    up -= q < 3 ? q : 3;
-                    dm = max(dm, cw_wave_shr1(up, 0)); vm = max(vm, up);
-                }
-                kD = dm + s_l; kV = vm + G4;
             }
+            const int v = max(kD, kV);
+            /* the next row's word and match scores: independent of the scan, they fill the wait states between its DPP steps */
+            const uint32_t meta_n = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl + 1); /* (lane 64 = lane 0: not used) */
+            const int s_l_n = (sq == (int)(meta_n & 3u)) ? ms_l : xs_l;
 #if defined(CW_EXP_SALU) || defined(CW_EXP_VALU) /* experiment (tools/exp_issue.sh): what one more scalar / vector instruction per row costs */
             {
                 int xs_ = rl, xv_ = lane;
@@ -133,22 +138,20 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
                 asm volatile("" :: "s"(xs_), "v"(xv_));
             }
 #endif
-            const int nv = cw_wave_scan_max(max(kD, kV)) | 3;
+            const int nv = cw_wave_scan_max(v) | 3;
             const bool cd = (uint32_t)(kD ^ nv) < 4u, cv = (uint32_t)(kV ^ nv) < 4u;
             const uint32_t nib = ((uint32_t)(cd ? kD : kV) & 3u) | (cd ? 0u : cv ? 4u : 8u);
             acc |= nib << (4 * (rl & 7));
             rowst[(i & (CW_RING - 1)) * 64] = (int16_t)nv;
-            if (meta & 16u) cwc_gstore_b16(Hg + i * 64, nv);
-            if (CW_RM_SINK(meta)) {
-                const int h = __builtin_amdgcn_readlane(nv, L);
-                if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
+            if (meta & 24u) { /* rarely: a sink (the end cell is the best of them), a row some later row or the traceback reads from the slab */
+                if (meta & 16u) cwc_gstore_b16(Hg + i * 64, nv);
+                if (CW_RM_SINK(meta)) {
+                    const int h = __builtin_amdgcn_readlane(nv, L);
+                    if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
+                }
             }
-            rc0 = nv;
-            if ((rl & 7) == 7) {
-                cwc_gstore_b32(Cg + ((r0 + rl) >> 3) * 64, acc);
-                acc = 0u;
-            }
-            meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl + 1); /* (lane 64 = lane 0: not used) */
+            if ((rl & 7) == 7) { cwc_gstore_b32(Cg + ((r0 + rl) >> 3) * 64, acc); acc = 0u; }
+            rc0 = nv; meta = meta_n; s_l = s_l_n;
         }
         if (cnt & 7) cwc_gstore_b32(Cg + ((r0 + cnt - 1) >> 3) * 64, acc);
     }

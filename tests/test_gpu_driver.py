@@ -246,6 +246,72 @@ def test_config5_ten_contig_polishing_with_an_oracle_sample(tmp_path):
         assert recs[n] == s, n
 
 
+def _records(fasta_text):
+    lines = fasta_text.split("\n")
+    return dict(zip((l[1:] for l in lines[0::2] if l), lines[1::2]))
+
+
+@pytest.mark.timeout(1800)
+def test_config5_the_reference_example_assembly_polished_at_full_size(tmp_path):
+    """BASELINE configs[4] on the input it names: the reference's example/rawAssembly.fasta (86 contigs, 3 353 228 bp, 10-154 kbp; here as the
+    data fixture tests/golden/rawAssembly.2bit.npz, made by tests/golden/make_assembly_fixture.py) polished with 30x simulated reads through
+    bin/CONSENT-polishing with the argv of CONSENT-polish:197 (minSupport 1, maxSupport 20000: every window of a contig walks ALL its
+    overlaps, ~600 for the longest contig).  Oracle sample: the longest contig (contig12, 154 070 bp, ~340 windows) and two shorter ones,
+    polished by the oracle's own loop, must come out byte-identical; one engine and two engines write the same FASTA."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_bench as pb
+
+    names, contigs = pb.load_contigs(os.path.join(ROOT, "tests", "golden", "rawAssembly.2bit.npz"))
+    assert len(names) == 86 and sum(len(c) for c in contigs) == 3353228 and max(len(c) for c in contigs) == 154070
+    fa, paf, ctg, n_reads, n_ovl = pb.generate_from_contigs(str(tmp_path), names, contigs, 30, "pacbio")
+    assert n_reads > 12000 and n_ovl > 12000
+    argv = ["-a", paf, "-s", 1, "-S", 20000, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", ctg, "-R", fa, "-M", 150, "-p", "x"]
+    got, err = run_bin("CONSENT-polishing", argv, env={"CW_DEVICES": "0,0", "CW_DRIVER_STATS": "1"})
+    st = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])
+    assert st["piles"] == 86 and st["windows"] > 7000, st
+    recs = _records(got)
+    assert list(recs) == names  # every contig, in the order of the PAF (CONSENT-polishing.cpp:122-134)
+    assert all(abs(len(recs[n]) - len(c)) < 0.03 * len(c) for n, c in zip(names, contigs))
+    one, _ = run_bin("CONSENT-polishing", argv, env={"CW_DEVICES": "0"})
+    assert one == got
+    longest = names[max(range(86), key=lambda i: len(contigs[i]))]
+    sample = [longest, names[0], names[40]]
+    want = oracle_polish(ctg, fa, _sub_paf(paf, tmp_path / "sample.paf", sample), min_support=1, max_support=20000, window_size=500, mer_size=9, common_kmers=8,
+                         min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150)
+    assert sorted(n for n, _ in want) == sorted(sample)
+    for n, s_ in want:
+        assert recs[n] == s_, n
+    assert len(recs[longest]) > 150000
+
+
+@pytest.mark.timeout(2400)
+def test_config4_e_coli_scale_ont_correction_at_full_size_with_an_oracle_sample(tmp_path):
+    """BASELINE configs[3] as stated: a 4.6 Mbp genome under 30x ONT-profile reads (17 250 reads of ~8 kbp, ~1.1 M overlaps, ~3.2e5 windows)
+    through bin/CONSENT-correction with the wrapper's argv (CONSENT-correct:202); 20 reads spread over the set are corrected by the
+    oracle pipeline as well and must come out byte-identical."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_bench as pb
+
+    fa, paf, _, n_reads, n_ovl = pb.generate(str(tmp_path), 4600000, 30, "ont")
+    assert n_reads == 17250 and n_ovl > 900000
+    argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", fa, "-M", 150, "-p", "x"]
+    got, err = run_bin("CONSENT-correction", argv, env={"CW_DRIVER_STATS": "1", "CW_DEVICES": "0,0"})
+    st = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])
+    assert st["piles"] == n_reads and st["windows"] > 250000, st
+    recs = _records(got)
+    assert len(recs) > 0.97 * n_reads
+    names = [f"r{i}" for i in range(7, n_reads, n_reads // 20)][:20]
+    want = oracle_pipeline(fa, _sub_paf(paf, tmp_path / "sample.paf", names), min_support=3, max_support=150, window_size=500, mer_size=9, common_kmers=8, min_anchors=2,
+                           solid_thresh=4, window_overlap=50, max_msa=150)
+    assert len(want) >= 18
+    for n, s_ in want:
+        assert recs[n] == s_, n
+
+
 def test_a_read_or_contig_may_span_extraction_slices_and_engine_runs(tmp_path):
     """One engine call takes at most CW_MAX_BATCH_WINDOWS windows and one extraction call a bounded number of (window, overlap) descriptors, but
     a job -- and a single contig inside it -- may be larger: the worker extracts in slices into one batch, corrects in runs over it and
