@@ -8,6 +8,9 @@
 #include "../include/cw_policy.h"
 
 #include <algorithm>
+#if defined(CWO_SIMD) && defined(__AVX2__)
+#include <immintrin.h>
+#endif
 #include <cassert>
 #include <climits>
 #include <set>
@@ -140,9 +143,54 @@ struct PoaGraph {
         if (n == 0 || L == 0) return path;
         const int cols = L + 1;
         const int g = CW_POA_GAP;
-        std::vector<int32_t> H((size_t)(n + 1) * cols);
-        auto at = [&](int i, int j) -> int32_t& { return H[(size_t)i * cols + j]; };
         auto pred_row = [&](const PoaNode& nd, size_t p) { return node2rank[edges[nd.in_edges[p]].from] + 1; };
+#if defined(CWO_SIMD) && defined(__AVX2__)
+        /* Row-vectorised fill for the CPU BASELINE leg of bench.py only (the real reference's POA, spoa, is SIMD code, so a
+           scalar port flatters the GPU/CPU ratio).  Eight int32 columns per AVX2 register; rows are kept as W[i][j] = H[i][j] - j * gap,
+           in which a horizontal move costs nothing: the horizontal recurrence is a prefix max (three shift-and-max steps inside a
+           register, a carry between registers), the candidates of a row are plain vector loads of the predecessor rows at j and j - 1.
+           Exact integer arithmetic: every H value, hence the traceback and the consensus, is identical to the scalar code's
+           (tests/test_oracle_units.py builds both and compares). */
+        const int colsP = (cols + 7) & ~7, stride = colsP + 8; /* 8 cells of padding in front of column 0: the diagonal of column 0 reads "minus infinity" */
+        const int32_t NEGW = -(1 << 28);
+        static thread_local std::vector<int32_t> Wm, sc_tab; /* reused from alignment to alignment: most are a few dozen cells */
+        if (Wm.size() < (size_t)(n + 1) * stride + 8) Wm.resize((size_t)(n + 1) * stride + 8);
+        auto wrow = [&](int i) -> int32_t* { return Wm.data() + (size_t)i * stride + 8; };
+        for (int i = 0; i <= n; ++i) for (int j = -8; j < 0; ++j) wrow(i)[j] = NEGW;
+        for (int j = 0; j < colsP; ++j) wrow(0)[j] = 0;
+        if (sc_tab.size() < (size_t)4 * colsP) sc_tab.resize((size_t)4 * colsP); /* per base code: substitution score - gap for every column */
+        for (int b = 0; b < 4; ++b) for (int j = 0; j < colsP; ++j) sc_tab[(size_t)b * colsP + j] = (j >= 1 && j < cols && seq[j - 1] == "ACGT"[b]) ? CW_POA_MATCH - g : CW_POA_MISMATCH - g;
+        const __m256i vneg = _mm256_set1_epi32(NEGW), vg = _mm256_set1_epi32(g);
+        const __m256i sh1 = _mm256_setr_epi32(0, 0, 1, 2, 3, 4, 5, 6), sh2 = _mm256_setr_epi32(0, 0, 0, 1, 2, 3, 4, 5), sh4 = _mm256_setr_epi32(0, 0, 0, 0, 0, 1, 2, 3),
+                      last = _mm256_set1_epi32(7);
+        for (int i = 1; i <= n; ++i) {
+            const PoaNode& nd = nodes[rank2node[i - 1]];
+            const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+            const int32_t* srow = sc_tab.data() + (size_t)base_code(nd.base) * colsP;
+            int32_t* out = wrow(i);
+            __m256i carry = vneg;
+            for (int j = 0; j < colsP; j += 8) {
+                __m256i acc = vneg;
+                const __m256i s8 = _mm256_loadu_si256((const __m256i*)(srow + j));
+                for (size_t p = 0; p < np; ++p) {
+                    const int32_t* pr = wrow(nd.in_edges.empty() ? 0 : pred_row(nd, p));
+                    const __m256i up = _mm256_loadu_si256((const __m256i*)(pr + j)), dg = _mm256_loadu_si256((const __m256i*)(pr + j - 1));
+                    acc = _mm256_max_epi32(acc, _mm256_max_epi32(_mm256_add_epi32(dg, s8), _mm256_add_epi32(up, vg)));
+                }
+                __m256i t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh1), vneg, 0x01); acc = _mm256_max_epi32(acc, t);
+                t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh2), vneg, 0x03); acc = _mm256_max_epi32(acc, t);
+                t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh4), vneg, 0x0F); acc = _mm256_max_epi32(acc, t);
+                acc = _mm256_max_epi32(acc, carry);
+                carry = _mm256_permutevar8x32_epi32(acc, last);
+                _mm256_storeu_si256((__m256i*)(out + j), acc);
+            }
+        }
+        struct AtW { int32_t* base; int stride; int g; int32_t operator()(int i, int j) const { return base[(size_t)i * stride + 8 + j] + j * g; } };
+        const AtW at{Wm.data(), stride, g};
+#else
+        static thread_local std::vector<int32_t> H; /* reused from alignment to alignment; every cell is written before it is read */
+        if (H.size() < (size_t)(n + 1) * cols) H.resize((size_t)(n + 1) * cols);
+        auto at = [&](int i, int j) -> int32_t& { return H[(size_t)i * cols + j]; };
 
         for (int j = 0; j < cols; ++j) at(0, j) = j * g;
         for (int i = 1; i <= n; ++i) {
@@ -164,6 +212,7 @@ struct PoaGraph {
             }
             for (int j = 1; j < cols; ++j) at(i, j) = std::max(at(i, j - 1) + g, at(i, j));
         }
+#endif
         if (st) { st->dp_cells += (uint64_t)n * L; st->alignments++; }
 
         int bi = -1;
@@ -305,7 +354,56 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
     std::unordered_map<kmer_t, std::vector<Occ>> index;
     std::set<kmer_t> repeated;
     const kmer_t mask = (k >= 32) ? ~(kmer_t)0 : (((kmer_t)1 << (2 * k)) - 1);
-
+    std::vector<kmer_t> tpl;
+#ifdef CWO_FAST
+    /* CPU-baseline build (bench.py's cpu_baseline leg; never the checker): the same index with direct-addressed tables instead of three hash
+       maps per k-mer -- per-key count, "seen in this sequence" stamp and repeat flag in flat arrays over all 4^k keys (k <= 11), occurrence
+       lists only for the template's surviving k-mers (all the chain and the segmentation ever look up).  Same counts, same anchors, same
+       lists in the same order: tests/test_oracle_units.py compares this build with the plain one. */
+    const bool flat = k <= 11;
+    static thread_local std::vector<uint32_t> f_cnt, f_stamp;
+    static thread_local std::vector<int32_t> f_slot;
+    static thread_local std::vector<uint8_t> f_rep;
+    std::vector<kmer_t> touched;
+    std::vector<std::vector<Occ>> occs;
+    if (flat) {
+        const size_t K4 = (size_t)1 << (2 * k);
+        if (f_cnt.size() < K4) { f_cnt.assign(K4, 0); f_stamp.assign(K4, 0); f_slot.assign(K4, -1); f_rep.assign(K4, 0); }
+        for (uint32_t s = 0; s < pile.size(); ++s) {
+            const std::string& r = pile[s];
+            if (r.size() < k) continue;
+            kmer_t v = 0;
+            for (size_t i = 0; i < r.size(); ++i) {
+                v = ((v << 2) | base_code(r[i])) & mask;
+                if (i + 1 < k) continue;
+                if (f_cnt[v]++ == 0) touched.push_back(v);
+                if (f_stamp[v] == s + 1) f_rep[v] = 1; else f_stamp[v] = s + 1;
+            }
+            if (st) st->kmers += r.size() - k + 1;
+        }
+        counts.reserve(counts.size() + touched.size());
+        for (kmer_t v : touched) counts[v] += f_cnt[v];
+        if (!pile.empty() && pile[0].size() >= k) {
+            kmer_t v = 0;
+            for (size_t i = 0; i < pile[0].size(); ++i) {
+                v = ((v << 2) | base_code(pile[0][i])) & mask;
+                if (i + 1 >= k && !f_rep[v] && (double)f_cnt[v] >= anchor_support) tpl.push_back(v);
+            }
+        }
+        occs.resize(tpl.size());
+        for (size_t a = 0; a < tpl.size(); ++a) { f_slot[tpl[a]] = (int32_t)a; occs[a].reserve(f_cnt[tpl[a]]); }
+        for (uint32_t s = 0; s < pile.size(); ++s) {
+            const std::string& r = pile[s];
+            if (r.size() < k) continue;
+            kmer_t v = 0;
+            for (size_t i = 0; i < r.size(); ++i) {
+                v = ((v << 2) | base_code(r[i])) & mask;
+                if (i + 1 >= k && f_slot[v] >= 0) occs[(size_t)f_slot[v]].push_back(Occ{s, (int32_t)(i + 1 - k)});
+            }
+        }
+    } else
+#endif
+    {
     /* A4a: pile-wide counts + occurrence lists; a k-mer seen twice in one sequence is repeated. */
     for (uint32_t s = 0; s < pile.size(); ++s) {
         const std::string& r = pile[s];
@@ -329,7 +427,6 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
     }
 
     /* Template anchors in template order. */
-    std::vector<kmer_t> tpl;
     if (!pile.empty() && pile[0].size() >= k) {
         kmer_t v = 0;
         for (size_t i = 0; i < pile[0].size(); ++i) {
@@ -337,12 +434,23 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
             if (i + 1 >= k && index.count(v)) tpl.push_back(v);
         }
     }
+    }
+    /* the occurrence list of a surviving template k-mer, in (sequence, position) order */
+    auto occ_of = [&](kmer_t a) -> const std::vector<Occ>& {
+#ifdef CWO_FAST
+        if (flat) return occs[(size_t)f_slot[a]];
+#endif
+        return index[a];
+    };
+#ifdef CWO_FAST
+    struct Cleaner { std::vector<kmer_t>& t; bool on; ~Cleaner() { if (on) for (kmer_t v : t) { f_cnt[v] = 0; f_stamp[v] = 0; f_rep[v] = 0; f_slot[v] = -1; } } } cleaner{touched, flat};
+#endif
     if (st) st->tpl_anchors += tpl.size();
 
     /* A4b: longest ordered chain. */
     auto pair_score = [&](kmer_t a, kmer_t b) -> int {
-        const std::vector<Occ>& va = index[a];
-        const std::vector<Occ>& vb = index[b];
+        const std::vector<Occ>& va = occ_of(a);
+        const std::vector<Occ>& vb = occ_of(b);
         size_t i = 0, j = 0;
         int n = 0;
         while (i < va.size() && j < vb.size()) {
@@ -356,10 +464,19 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
     const int A = (int)tpl.size();
     std::vector<int> len(A, 0), nxt(A, -1);
     std::vector<long> sc(A, 0);
+#ifdef CWO_FAST
+    std::vector<int> smax(A + 1, -1); /* smax[b] = longest chain from any anchor >= b (baseline build only, see below) */
+#endif
     for (int a = A - 1; a >= 0; --a) {
         int best_len = -1, best_next = -1;
         long best_sc = 0;
         for (int b = a + 1; b < A; ++b) {
+#ifdef CWO_FAST
+            /* CPU-baseline build: an exact shortcut the straightforward restatement does without -- a successor replaces the best link only
+               with a longer chain, or an equally long one of higher score, so once no anchor from b on has a chain as long as the best
+               found, the scan is over.  Same links, same chain (tests/test_oracle_units.py compares the two builds); ~50x fewer pair tests. */
+            if (smax[b] < best_len) break;
+#endif
             int s = pair_score(tpl[a], tpl[b]);
             if ((double)s >= anchor_support) {
                 if (len[b] > best_len) { best_len = len[b]; best_sc = sc[b] + s; best_next = b; }
@@ -367,6 +484,9 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
             }
         }
         len[a] = best_len + 1; sc[a] = best_sc; nxt[a] = best_next;
+#ifdef CWO_FAST
+        smax[a] = std::max(smax[a + 1], len[a]);
+#endif
     }
     int start = -1, top_len = 0;
     long top_sc = 0;
@@ -381,7 +501,14 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
 
     /* A4c + A4d */
     auto pos_in = [&](kmer_t a, uint32_t s) -> int32_t {
-        for (const Occ& o : index[a]) if (o.seq == s) return o.pos;
+#ifdef CWO_FAST
+        { /* (baseline build: the list is sorted by sequence and an anchor occurs at most once per sequence) */
+            const std::vector<Occ>& v = occ_of(a);
+            auto it = std::lower_bound(v.begin(), v.end(), s, [](const Occ& o, uint32_t q) { return o.seq < q; });
+            return it != v.end() && it->seq == s ? it->pos : -1;
+        }
+#endif
+        for (const Occ& o : occ_of(a)) if (o.seq == s) return o.pos;
         return -1;
     };
     const size_t m = chain.size();

@@ -121,3 +121,47 @@ def test_window_positions_refuses_the_parameters_the_reference_hangs_on():
     for ws, wo in ((0, 0), (500, 500), (500, 600), (500, -1)):
         assert lib.cw_window_positions(1000, ov.ctypes.data, 1, 1, ws, wo, out.ctypes.data, 32, C.byref(n)) == -1
     assert lib.cw_window_positions(1000, ov.ctypes.data, 1, 1, 500, 50, out.ctypes.data, 32, C.byref(n)) == 0 and n.value == 3
+
+
+def test_the_baseline_build_of_the_oracle_gives_the_checkers_results(tmp_path):
+    """bench.py's cpu_baseline leg times a second build of the restatement (oracle/Makefile simd_pair / native_simd: -DCWO_FAST -DCWO_SIMD --
+    direct-addressed k-mer tables, the chain scan's early stop, AVX2 row-vectorised POA fill).  It must be the same function: status,
+    consensus and solid set of every window, over depths, k, thresholds and low-complexity piles."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    import pytest
+
+    if "avx2" not in open("/proc/cpuinfo").read():
+        pytest.skip("no AVX2 on this host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "simd_pair", f"OUT={tmp_path}"])
+    child = r"""
+import hashlib, os, random, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tools"))
+import numpy as np
+import consent_amd as ca
+from consent_amd.engine import synth_host
+import oracle_lib, fuzz_parity
+h = hashlib.sha256()
+rng = random.Random(5)
+for depth, n, msa, k, solid, common, fam in ((150, 6, 150, 9, 4, 8, None), (30, 24, 20, 9, 4, 8, None), (12, 24, 150, 7, 2, 4, None), (60, 8, 50, 11, 3, 12, None),
+                                              (40, 8, 150, 13, 4, 8, None), (30, 8, 150, 9, 4, 8, "tandem"), (30, 8, 150, 9, 4, 8, "identical"), (20, 8, 150, 8, 1, 2, "homopolymer")):
+    prm = ca.Params(k, solid, common, 2, msa)
+    hb = synth_host(ca.SynthSpec.pacbio(n, depth, first_window=300 + depth))
+    if fam:
+        fuzz_parity.low_complexity(hb, rng, fam)
+    res, st = oracle_lib.oracle_run(prm, hb, threads=2)
+    for w in range(n):
+        h.update(res.consensus(w).encode()); h.update(bytes([int(res.status[w])])); h.update(res.solid_kmers(w).tobytes())
+    h.update(str(int(st["dp_cells"])).encode())
+print("DIGEST", h.hexdigest())
+"""
+    def run(env):
+        out = subprocess.run([sys.executable, "-c", child, root], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1]
+
+    assert run({}) == run({"CW_ORACLE_LIB": str(tmp_path / "liboracle_simd.so")})

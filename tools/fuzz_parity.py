@@ -15,11 +15,45 @@ from consent_amd.engine import synth_host  # noqa: E402
 import oracle_lib  # noqa: E402
 
 
+WHY = {1: "SETUP", 2: "COUNT", 3: "SOLIDCAP", 4: "TEMPLATE", 5: "MATRIX", 6: "SEGMENTS", 7: "TASKS", 8: "POA", 9: "FIN_LEN", 10: "FIN_SOLID", 11: "FIN_POLISH",
+       12: "OUT_CONS", 13: "OUT_SOLID"}  # cw_device.h CW_WHY_*
+MAX_OVERFLOW_SHARE = 0.001  # a capacity stop is never a wrong answer, but more than one window in a thousand is a regression
+
+
+def low_complexity(batch, rng, kind):
+    """Rewrites the piles of a synthetic batch in place into a family the random generator never draws: "homopolymer" (runs of one base),
+    "tandem" (a short unit repeated with 3 % noise: every k-mer of the template repeats, so few anchors survive), "identical" (every sequence
+    a copy of the template: every template k-mer is an anchor and the position matrix is at its largest)."""
+    nrng = np.random.default_rng(rng.getrandbits(32))
+    wfs, slen, off, bases = batch.win_first_seq, batch.seq_len, batch.seq_word_off, batch.bases
+    shifts = (30 - 2 * np.arange(16, dtype=np.uint32))
+    for w in range(batch.n_windows):
+        s0, s1 = int(wfs[w]), int(wfs[w + 1])
+        unit = nrng.integers(0, 4, rng.choice([1, 2, 3, 5, 7, 11]))
+        tpl = nrng.integers(0, 4, int(slen[s0:s1].max()) + 64)
+        for s in range(s0, s1):
+            n = int(slen[s])
+            if kind == "homopolymer":
+                runs = nrng.integers(3, 40, n // 3 + 2)
+                codes = np.repeat((np.cumsum(nrng.integers(1, 4, len(runs))) & 3), runs)[:n]
+            elif kind == "tandem":
+                codes = unit[(np.arange(n) + (s - s0)) % len(unit)]
+                noise = nrng.random(n) < 0.03
+                codes = np.where(noise, nrng.integers(0, 4, n), codes)
+            else:
+                codes = tpl[:n]
+            pad = np.zeros((n + 15) // 16 * 16, np.uint32)
+            pad[:n] = codes
+            o = int(off[s])
+            bases[o : o + len(pad) // 16] = (pad.reshape(-1, 16) << shifts[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t_end = time.time() + seconds
-    n_cfg = n_win_total = bad = 0
+    n_cfg = n_win_total = bad = n_over_total = 0
+    why_hist = {}
     while time.time() < t_end:
         k = rng.choice([5, 6, 7, 8, 9, 9, 9, 10, 11, 13])
         solid = rng.choice([1, 2, 3, 4, 4, 6])
@@ -34,9 +68,13 @@ def main():
         spec = ca.SynthSpec(rng.getrandbits(40), rng.getrandbits(20), nw, depth, wlen, err, mix[0], mix[1], mix[2], (wlen + 60 + wlen // 3) // 16 + 2)
         prm = ca.Params(k, solid, common, min_anchors, max_msa)
         batch = synth_host(spec)
+        family = rng.choice(["random"] * 8 + ["homopolymer", "tandem", "identical"])
+        if family != "random":
+            low_complexity(batch, rng, family)
         eng = ca.Engine(prm)
         try:
             got = eng.run(batch)
+            info = eng.win_info(nw)
         finally:
             eng.close()
         exp, _ = oracle_lib.oracle_run(prm, batch, threads=16)
@@ -47,12 +85,20 @@ def main():
             if got.status[w] != exp.status[w] or got.consensus(w) != exp.consensus(w) or not np.array_equal(got.solid_kmers(w), exp.solid_kmers(w)):
                 diff += 1
         n_over = int((got.status == ca.WIN_OVERFLOW).sum())
+        for w in range(nw):
+            if got.status[w] == ca.WIN_OVERFLOW:
+                why_hist[WHY.get(int(info[w, 15]), str(int(info[w, 15])))] = why_hist.get(WHY.get(int(info[w, 15]), str(int(info[w, 15]))), 0) + 1
         n_cfg += 1
         n_win_total += nw
+        n_over_total += n_over
         bad += diff
-        print(f"k={k} solid={solid} c={common} A={min_anchors} depth={depth} M={max_msa} len={wlen} err={err} mix={mix} windows={nw} overflow={n_over} "
+        print(f"k={k} solid={solid} c={common} A={min_anchors} depth={depth} M={max_msa} len={wlen} err={err} mix={mix} family={family} windows={nw} overflow={n_over} "
               f"template={int((got.status == ca.WIN_TEMPLATE).sum())} DIFF={diff}", flush=True)
-    print(f"{n_cfg} configurations, {n_win_total} windows, {bad} differences")
+    share = n_over_total / max(1, n_win_total)
+    print(f"{n_cfg} configurations, {n_win_total} windows, {bad} differences, {n_over_total} windows stopped by a capacity ({share:.5f} of all; by reason: {why_hist})")
+    if share > MAX_OVERFLOW_SHARE:
+        print(f"FAILED: capacity stops above {MAX_OVERFLOW_SHARE} of the windows")
+        return 1
     return 1 if bad else 0
 
 
