@@ -84,7 +84,7 @@ struct Shared {
     bool closed = false;
     /* finished jobs, keyed by sequence number (workers -> emitter) */
     std::map<uint64_t, Job*> finished;
-    bool abort = false;
+    std::atomic<bool> abort{false}; /* written under mu, also read outside it by the producer loop */
     int first_error = CW_OK;
     std::string first_error_msg;
 };
@@ -468,6 +468,12 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     cw_read_index* index = nullptr;
     int rc = cw_index_reads(a->reads_file, &index);
     if (rc != CW_OK) { fprintf(stderr, "[consent_amd] cannot index %s: %s\n", a->reads_file, cw_strerror(rc)); return rc; }
+    uint64_t tpl_bases = 0; /* bases of the templates (the sequences of reads_file: every one of them may be a pile's query): sizes the jobs */
+    {
+        cw_read_set v0; uint64_t w0 = 0;
+        cw_read_index_view(index, &v0, &w0);
+        for (uint32_t i = 0; i < v0.n_reads; ++i) tpl_bases += v0.read_len[i];
+    }
     if (has_proof && (rc = cw_index_reads_append(index, a->proof_file)) != CW_OK) {
         fprintf(stderr, "[consent_amd] cannot index %s: %s\n", a->proof_file, cw_strerror(rc));
         cw_read_index_free(index);
@@ -539,7 +545,16 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
        few hundred at a time; the window positions of one such round are computed on helper threads -- piles are independent -- while
        this thread already reads the next round; jobs are then put together in pile order, so their contents do not depend on the
        number of helpers.  One thread did all three before: 3 M windows/s, within 2x of what eight GPUs take. */
-    const uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
+    /* Windows per job.  The caller's figure, else 32768 -- unless the run is too short for that many workers: a job is the unit the workers
+       share, and with fewer than about four jobs per worker the last ones leave most engines idle (the E. coli-scale set is 3.2e5 windows:
+       ten jobs of 32768 for the sixteen workers of an 8-GPU node).  The number of windows is not known before the alignments are read, but
+       it is close to template bases / (window size - overlap); floor 4096 windows (below that a job no longer fills a GPU). */
+    uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
+    if (!a->windows_per_batch) {
+        const uint64_t est_windows = tpl_bases / (a->window_size - a->window_overlap) + 1;
+        const uint64_t want = est_windows / (4ull * devs.size()) + 1;
+        if (want < per_job) per_job = (uint32_t)(want < 4096 ? 4096 : want);
+    }
     cw_paf_reader* paf = nullptr;
     rc = cw_paf_open(a->alignment_file, index, a->max_support, &paf);
     uint64_t n_piles = 0, n_windows = 0, n_overlaps = 0;

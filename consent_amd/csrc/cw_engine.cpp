@@ -24,7 +24,7 @@
 namespace {
 
 /* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
-static_assert(6 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: six work-groups per CU");
+static_assert(5 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: five work-groups per CU");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
 static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
@@ -51,18 +51,18 @@ TierMix tier_mix(bool deep) {
     auto knob = [](const char* name, uint32_t dflt) { const char* v = getenv(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
     if (m.s > 6) m.s = 6;
-    if (m.m1 > 5) m.m1 = 5;
-    if (m.m2 > 4) m.m2 = 4;
-    if (m.l > 4) m.l = 4;
+    if (m.m1 > 6) m.m1 = 6;
+    if (m.m2 > 8) m.m2 = 8;
+    if (m.l > 8) m.l = 8;
     return m;
 }
 
 void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
     t[0] = {(uint32_t)cus * 8 * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
     /* slabs: one per wave the hardware can hold at once (LDS-bound: 5, 4 and 4 work-groups per CU) plus a margin; waves claim them (slot_busy) */
-    t[1] = {(uint32_t)cus * 6 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
-    t[2] = {(uint32_t)cus * 5 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
-    t[3] = {(uint32_t)cus * 5 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
+    t[1] = {(uint32_t)cus * 7 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
+    t[2] = {(uint32_t)cus * 9 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
+    t[3] = {(uint32_t)cus * 9 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
     t[4] = {big_slots, big_slab_bytes()};
     t[5] = {(uint32_t)cus * 6 * 2 * CW_POAH_WAVES, CW_POAH_SLAB_BYTES}; /* tier H: a slab per 32-lane half, at most five work-groups of four halves per CU */
 }

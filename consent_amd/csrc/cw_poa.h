@@ -70,7 +70,10 @@
 #define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
 #define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + 16 * 64 * 2 + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
 #define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
-#define CW_POA_SLAB_BYTES CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
+#ifndef CW_S_EDGES_LDS
+#define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */
+#endif
+#define CW_POA_SLAB_BYTES (CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + (CW_S_EDGES_LDS ? 4 * CW_POA_EC + 2 * CW_POA_NC : 0)) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
@@ -1082,7 +1085,13 @@ __device__ __forceinline__ void poa_producer_done(const DevScratch& sc) {
  * where graph, merge arrays, a 2048-cell matrix and the code words took 12.9), everything only the merge and the rank bookkeeping touch,
  * the matrix of the rare member of more than 63 bases, flagged rows and the code words in a slab the wave claims (sc.slab[0]).
  * Capacities: CW_POA_NC nodes, CW_POA_LC bases; the 2048-cell limit is gone. */
-__global__ void __launch_bounds__(64 * CW_POA_WAVES, 5) cw_poa_kernel(DevBatch b, DevScratch sc) { /* five waves per SIMD: 96 VGPRs */
+#ifndef CW_S_EU
+#define CW_S_EU 5
+#endif
+#ifndef CW_M1_EU
+#define CW_M1_EU 5
+#endif
+__global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevBatch b, DevScratch sc) { /* five waves per SIMD: 96 VGPRs */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t gw = 0;
@@ -1102,7 +1111,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, 5) cw_poa_kernel(DevBatch b
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC) + CW_POA_DSLAB_BYTES(CW_POA_NC, CW_POA_LC);
-    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, (CW_POA_NC + 1) * (CW_POA_LC + 1), 0, hslab, dslab, cold, true, true);
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, (CW_POA_NC + 1) * (CW_POA_LC + 1), 0, hslab, dslab, cold, !CW_S_EDGES_LDS, true);
     M.H = hslab; M.dirs = dslab;
     {
         uint8_t* extra = lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(CW_POA_NC));
@@ -1155,7 +1164,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, 5) cw_poa_kernel(DevBatch b
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? 5 : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
+__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1201,7 +1210,10 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
-    else if (TIER == 2) __builtin_amdgcn_s_setprio(1);
+#ifndef CW_M2_PRIO
+#define CW_M2_PRIO 1
+#endif
+    else if (TIER == 2) __builtin_amdgcn_s_setprio(CW_M2_PRIO);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];

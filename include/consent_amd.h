@@ -277,7 +277,7 @@ typedef struct cw_driver_args {
     int32_t polishing;
     const int32_t* devices;     /* NULL = choose as described above */
     int32_t n_devices;
-    uint32_t windows_per_batch; /* 0 = 32768: windows per job */
+    uint32_t windows_per_batch; /* windows per job; 0 = 32768, fewer (down to 4096) when the templates are too few for four such jobs per worker */
 } cw_driver_args;
 
 typedef struct cw_driver_stats {
