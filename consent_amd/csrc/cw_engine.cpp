@@ -75,13 +75,15 @@ struct ScratchPlan {
     TierCfg tier[CW_TIERS];
 };
 
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t big_slots) {
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t big_slots, uint32_t scale = 1) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
     p.seg_cap = (uint64_t)n_windows * (CW_TMAX + 2);
-    p.arena_cap = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096);
-    uint64_t tc = 64ull * n_windows + 1024, mc = 2048ull * n_windows + 4096;
+    /* scale: 1, or 4 / 16 / 64 after a run whose windows stopped on the task / member / arena capacities -- heuristics of the batch, which a batch of
+       few, heavy windows (900-base windows at depth 100) outgrows: cw_run_device_sync runs such a batch again with the larger plan */
+    p.arena_cap = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096) * scale;
+    uint64_t tc = (64ull * n_windows + 1024) * scale, mc = (2048ull * n_windows + 4096) * scale;
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
     /* test aid: shrink the two heuristic capacities so that the overflow path of the chain kernel's task emission can be exercised */
@@ -274,7 +276,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     uint32_t big_slots = 256;
     if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots);
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots, e->cap_scale);
     if (p.solid_cap > 0xFFFFFFFFull || p.seg_cap > 0xFFFFFFFFull || p.arena_cap > 0xFFFFFFFFull) return CW_E_INVALID; /* see CW_MAX_BATCH_WINDOWS */
     e->last_windows = batch->n_windows; e->last_seqs = batch->n_seqs; e->last_words = batch->n_words; e->last_big_slots = big_slots;
     e->last_ctr_off = p.ctr;
@@ -375,7 +377,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(db, sc, e->prm);
-    cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap);
+    cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap, e->cap_scale);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "index");
     {
@@ -987,11 +989,48 @@ int cw_wait(cw_engine* e, int ticket) {
     return fail(rc);
 }
 
+/* After a finished run: did windows stop on a capacity that a larger scratch plan cures (CW_WHY_TASKS: the task, member and arena slots are
+   heuristics of the batch)?  Then the plan grows (x4, up to x64) and the caller runs the batch again. */
+static int grow_if_that_helps(cw_engine* e, bool* again) {
+    *again = false;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->scratch || e->last_windows == 0 || e->cap_scale >= 64u) return CW_OK;
+    CW_HIP(hipSetDevice(e->device));
+    uint32_t flag = 0;
+    CW_HIP(hipMemcpy(&flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost));
+    if (!flag) return CW_OK;
+    std::vector<WinInfo> wi(e->last_windows);
+    CW_HIP(hipMemcpy(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost));
+    bool any = false; /* (windows stopped for other reasons stay stopped: the loop ends when no window names these capacities, or at x64) */
+    for (const WinInfo& w : wi) any = any || (w.status == CW_WIN_OVERFLOW && w.pad_ == CW_WHY_TASKS);
+    if (any) { e->cap_scale *= 4u; *again = true; }
+    return CW_OK;
+}
+
+/* cw_run_device, then wait for the stream, then -- when windows stopped on the batch's task / member / arena capacities only -- once more
+   with a larger plan (cw_private.h; what the native driver and cw_run call: the asynchronous cw_run_device cannot look at its own result) */
+int cw_run_device_sync(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
+    for (;;) {
+        int rc = cw_run_device(e, batch, res, hip_stream);
+        if (rc != CW_OK) return rc;
+        CW_HIP(hipSetDevice(e->device));
+        CW_HIP(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream));
+        bool again = false;
+        if ((rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
+        if (!again) return CW_OK;
+    }
+}
+
 int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
-    int t = -1;
-    const int rc = cw_submit(e, b, r, &t);
-    if (rc != CW_OK) return rc;
-    return cw_wait(e, t);
+    for (;;) {
+        int t = -1;
+        int rc = cw_submit(e, b, r, &t);
+        if (rc != CW_OK) return rc;
+        if ((rc = cw_wait(e, t)) != CW_OK) return rc;
+        bool again = false;
+        if (!e || (rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
+        if (!again) return CW_OK;
+    }
 }
 
 /* pinned host memory for batches and results: copies from and to it are real DMA transfers that overlap the kernels; plain

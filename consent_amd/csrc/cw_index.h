@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) cw_setup_need_kernel(DevBatch b, DevScrat
 }
 
 __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch sc, cw_params prm, uint64_t solid_total_cap,
-                                                         uint64_t seg_total_cap, uint64_t arena_total_cap) {
+                                                         uint64_t seg_total_cap, uint64_t arena_total_cap, uint32_t arena_scale) {
     __shared__ uint32_t part[4][1024];
     __shared__ uint64_t run[4];
     const int tid = threadIdx.x;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(1024) cw_setup_kernel(DevBatch b, DevScratch s
             ns = sc.win[w].n_seqs; tl = sc.win[w].tpl_len; nk = sc.win[w].n_kmers; /* cw_setup_need_kernel */
             need_solid = nk / prm.solid + 1;
             need_seg = (tl >= prm.k) ? tl - prm.k + 3 : 1;
-            need_arena = 16 * tl + 4096;
+            need_arena = (16 * tl + 4096) * arena_scale;
             const uint32_t nk0 = (tl >= prm.k && tl - prm.k + 1 <= CW_TMAX) ? tl - prm.k + 1 : 0;
             need_ab = (uint32_t)(cw_ab_bytes(nk0, ns, ns) >> 4);
         }
@@ -391,7 +391,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
             uint32_t np2 = 2;
             while (np2 < written) np2 <<= 1;
-            if (fits && np2 > HS) fits = false;
+            /* the sort runs in LDS when the set fits (16384 keys), else in this work-group's global table (262144: round 4 -- a k > 9 run with a low
+               solid threshold, e.g. -k 13 --solid 1 on 900-base windows, has more solid keys than LDS holds and used to stop on a capacity) */
+            if (fits && np2 > (uint32_t)CW_EXG_SLOTS) fits = false;
             if (tid == 0) {
                 wi->n_solid = fits ? written : 0;
                 if (!fits) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_COUNT; sc.ctr->any_overflow = 1; }
@@ -400,25 +402,27 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             __syncthreads();
             if (!fits) continue;
             if (written > 1) {
+                unsigned long long* const sort_tab = np2 <= HS ? hs_tab : sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS;
                 for (uint32_t x = tid; x < np2; x += CW_IDX_THREADS)
-                    hs_tab[x] = x < written ? (((unsigned long long)sc.solid_key[w_solid_base + x] << 32) | sc.solid_cnt[w_solid_base + x]) : ~0ull;
+                    sort_tab[x] = x < written ? (((unsigned long long)sc.solid_key[w_solid_base + x] << 32) | sc.solid_cnt[w_solid_base + x]) : ~0ull;
                 __syncthreads();
                 for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
                     for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
                         for (uint32_t x = tid; x < np2; x += CW_IDX_THREADS) {
                             const uint32_t y = x ^ j2;
                             if (y > x) {
-                                const unsigned long long ax = hs_tab[x], ay = hs_tab[y];
+                                const unsigned long long ax = sort_tab[x], ay = sort_tab[y];
                                 const bool up = (x & k2) == 0;
-                                if ((ax > ay) == up) { hs_tab[x] = ay; hs_tab[y] = ax; }
+                                if ((ax > ay) == up) { sort_tab[x] = ay; sort_tab[y] = ax; }
                             }
                         }
+                        __threadfence_block();
                         __syncthreads();
                     }
                 }
                 for (uint32_t x = tid; x < written; x += CW_IDX_THREADS) {
-                    sc.solid_key[w_solid_base + x] = (uint32_t)(hs_tab[x] >> 32);
-                    sc.solid_cnt[w_solid_base + x] = (uint32_t)hs_tab[x];
+                    sc.solid_key[w_solid_base + x] = (uint32_t)(sort_tab[x] >> 32);
+                    sc.solid_cnt[w_solid_base + x] = (uint32_t)sort_tab[x];
                 }
                 __syncthreads();
             }

@@ -92,7 +92,10 @@ __global__ void __launch_bounds__(256) cw_plan_need_kernel(PlanArgs a) {
     for (uint32_t s = s0 + lane; s < s1; s += 64) { const uint32_t l = a.seq_len[s]; nk += l >= a.k ? l - a.k + 1 : 0; }
     for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o);
     if (lane == 0) {
-        a.cons_off[w] = s1 > s0 ? 3ull * a.seq_len[s0] + 256ull : 256ull;
+        /* three templates + 256, and never less than the finish kernel's own string capacity (CW_FIN_CB 3072): the slot is then not what stops a
+           window whose consensus comes out several times its template (short k, spurious anchors) */
+        const unsigned long long c3 = s1 > s0 ? 3ull * a.seq_len[s0] + 256ull : 256ull;
+        a.cons_off[w] = c3 < 3072ull ? 3072ull : c3;
         a.solid_off[w] = nk / a.solid + 16ull;
     }
 }

@@ -13,7 +13,7 @@
  *   decision  a cell's value is at least every candidate, so a candidate explains the cell iff it is the largest of its kind and equal
  *             to it: the fill keeps the largest diagonal and the largest vertical candidate (on equal values the earlier in-edge has the
  *             larger key and wins, as cw_policy.h demands: diagonal through the in-edges in order, then vertical through them, then
- *             horizontal) and compares them with the finished cell.  Four bits per cell: ordinal | move << 2, eight rows of a lane's
+ *             horizontal) and compares them with the finished cell.  Four bits per cell: in-edge | move << 2, eight rows of a lane's
  *             column to a 32-bit word.
  *   row store a predecessor one or two ranks back is in registers; up to CW_RING ranks back it comes from a ring of rows in LDS (tiers
  *             M1 / M2; tier S keeps its whole matrix in LDS); only rows that a later row needs from further back, and the rows round a node
@@ -57,7 +57,7 @@ __device__ __forceinline__ int cwc_gload_i16_wait(cwc_g16 p) {
    Returns the DP row of the end cell (best sink in the last column, lowest rank on ties).
    A stored value is 4 * W | 3: the low bits of a row as it is read back are already the ordinal of in-edge 0, so a row with one in-edge
    never touches them and in-edge q of a longer list subtracts min(q, 3).
-   A code is ordinal | move << 2 with move 0 diagonal, 1 vertical, 2 horizontal and ordinal 3 - q (0: fourth in-edge or later).
+   A code is q | move << 2 with move 0 diagonal, 1 vertical, 2 horizontal and q the in-edge the move goes through (3: the fourth or a later one).
    The loop is written for the scalar unit as much as for the vector unit: a SIMD issues one scalar and one vector instruction per
    four cycles, from different waves, so with four waves resident a row costs max(scalar, vector) instructions x 16 cycles -- and
    the first version of this loop, like the matrix fill before it, had 50 scalar instructions per row (branches on where a
@@ -82,8 +82,11 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
         const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - r0));
         uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, 0);
         int s_l = (sq == (int)(meta & 3u)) ? ms_l : xs_l;
-        uint32_t acc = 0u; /* the codes of eight rows of this lane's column */
-        for (int rl = 0; rl < cnt; ++rl) {
+        for (int g = 0; g < cnt; g += 8) { /* eight rows to a code word */
+        uint32_t acc = 0u;
+        const int ge = min(g + 8, cnt);
+        int sh = 0;
+        for (int rl = g; rl < ge; ++rl, sh += 4) {
             const int i = r0 + rl + 1;
             int kD, kV;
             if (CW_RM_LIN(meta)) {
@@ -139,9 +142,9 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
             }
 #endif
             const int nv = cw_wave_scan_max(v) | 3;
-            const bool cd = (uint32_t)(kD ^ nv) < 4u, cv = (uint32_t)(kV ^ nv) < 4u;
-            const uint32_t nib = ((uint32_t)(cd ? kD : kV) & 3u) | (cd ? 0u : cv ? 4u : 8u);
-            acc |= nib << (4 * (rl & 7));
+            /* the code: in-edge q (low bits of candidate ^ cell, the cell's being 3) for a diagonal, 4 + q for a vertical, 8 for a horizontal move */
+            const uint32_t t = (uint32_t)(kD ^ nv), u4 = __builtin_elementwise_add_sat((uint32_t)(kV ^ nv), 4u); /* saturating: candidate and cell may differ in sign */
+            acc |= min(min(t < 4u ? t : 8u, u4), 8u) << sh;
             rowst[(i & (CW_RING - 1)) * 64] = (int16_t)nv;
             if (meta & 24u) { /* rarely: a sink (the end cell is the best of them), a row some later row or the traceback reads from the slab */
                 if (meta & 16u) cwc_gstore_b16(Hg + i * 64, nv);
@@ -150,10 +153,10 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
                     if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
                 }
             }
-            if ((rl & 7) == 7) { cwc_gstore_b32(Cg + ((r0 + rl) >> 3) * 64, acc); acc = 0u; }
             rc0 = nv; meta = meta_n; s_l = s_l_n;
         }
-        if (cnt & 7) cwc_gstore_b32(Cg + ((r0 + cnt - 1) >> 3) * 64, acc);
+        cwc_gstore_b32(Cg + ((r0 + g) >> 3) * 64, acc);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cw_wave_sync();
@@ -183,11 +186,11 @@ __device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int 
             const uint32_t cw = Cg[((row - 1) >> 3) * cs + col];
             nib = (cw >> (((row - 1) & 7) * 4)) & 15u;
         }
-        const int mv = (int)(nib >> 2), ob = (int)(nib & 3u);
+        const int mv = (int)(nib >> 2), qn = (int)(nib & 3u);
         /* 0 diagonal, 1 vertical (both through in-edge 0: the next tile row), 2 horizontal; 3 through another in-edge, 5 neighbours outside
            the tile, 6 the virtual start row */
         const bool c_start = row <= 0, c_edge = tr == 7 || (tc == 7 && col > 0) || col < 0;
-        const int code = c_start ? 6 : c_edge ? 5 : mv == 2 ? 2 : ob != 3 ? 3 : mv;
+        const int code = c_start ? 6 : c_edge ? 5 : mv == 2 ? 2 : qn != 0 ? 3 : mv;
         const unsigned long long m_d = __ballot(code == 0), m_v = __ballot(code == 1), m_h = __ballot(code == 2);
         int pos = 0;
         unsigned long long on_diag = 0ull;
@@ -207,11 +210,11 @@ __device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int 
         j -= pos & 7;
         if (end_code == 6) i = 0;
         else if (end_code == 3) { /* the move goes through in-edge q > 0 */
-            const int mv_e = __builtin_amdgcn_readlane(mv, pos), ob_e = __builtin_amdgcn_readlane(ob, pos);
+            const int mv_e = __builtin_amdgcn_readlane(mv, pos), q_e = __builtin_amdgcn_readlane(qn, pos);
             const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.rmeta[i - 1]);
             const int np = CW_RM_NP(meta), off = CW_RM_X(meta);
-            int q = 3 - ob_e;
-            if (ob_e == 0) { /* fourth in-edge or later: the first of them whose candidate equals the cell (values of these rows are kept) */
+            int q = q_e;
+            if (q_e == 3) { /* fourth in-edge or later: the first of them whose candidate equals the cell (values of these rows are kept) */
                 const int base = (int)(meta & 3u);
                 const int h = (int)((cwc_g16)M.H)[i * cs + j];
                 const int sx = (j > 0 && (int)M.sq[j - 1] == base) ? MS4 : XS4;

