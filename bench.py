@@ -109,7 +109,8 @@ def driver_mode(args):
             raise SystemExit(f"driver failed ({pr.returncode}): {err[-1500:]}")
         return wall, json.loads([ln for ln in err.splitlines() if ln.startswith("{")][-1])
 
-    dry_wall, dry = min((run({"CW_DRIVER_DRY": "1"}, os.devnull) for _ in range(3)), key=lambda x: x[0])
+    # (the dry run is a test aid: only the -DCW_TEST_AIDS build of the library has it -- consent_amd/aids/, csrc/cw_env.h)
+    dry_wall, dry = min((run({"CW_DRIVER_DRY": "1", "LD_LIBRARY_PATH": os.path.join(ROOT, "consent_amd", "aids")}, os.devnull) for _ in range(3)), key=lambda x: x[0])
     best = None
     for _ in range(max(1, args.driver_reps)):
         wall, st = run({}, out_fa)

@@ -8,6 +8,10 @@ SRC = [os.path.join(HERE, "csrc", f) for f in ("cw_engine.cpp", "cw_synth.cpp", 
 HDR = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".h")]
 HDR += [os.path.join(HERE, "..", "include", f) for f in ("consent_amd.h", "cw_policy.h")]
 OUT = os.path.join(HERE, "libconsent_amd.so")
+# the same sources with -DCW_TEST_AIDS (csrc/cw_env.h): test aids, experiment knobs and the opt-in kernels exist only here; same file name in its
+# own directory so that the executables of bin/ run against it with LD_LIBRARY_PATH (tests, tools/, bench.py --mode driver's dry run)
+AIDS_DIR = os.path.join(HERE, "aids")
+AIDS_OUT = os.path.join(AIDS_DIR, "libconsent_amd.so")
 
 
 def hipcc():
@@ -18,9 +22,9 @@ def hipcc():
 
 
 def stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(AIDS_OUT):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(AIDS_OUT))
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SRC + HDR)
 
 
@@ -59,10 +63,17 @@ def build_bins(verbose=True):
 
 def build(force=False, verbose=True):
     if force or stale():
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *SRC, "-o", OUT]
-        if verbose:
-            print("[consent_amd] " + " ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        os.makedirs(AIDS_DIR, exist_ok=True)
+        cmds = [[hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *SRC, "-o", OUT],
+                [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCW_TEST_AIDS", *SRC, "-o", AIDS_OUT]]
+        procs = []
+        for cmd in cmds:  # side by side: each takes most of a minute
+            if verbose:
+                print("[consent_amd] " + " ".join(cmd), file=sys.stderr)
+            procs.append(subprocess.Popen(cmd))
+        for cmd, pr in zip(cmds, procs):
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
         force = True
     if force or bins_stale():
         build_bins(verbose)

@@ -194,8 +194,8 @@ struct Worker {
            or a contig of any length -- may span slices and runs.  (Usually: one slice, one run.) */
         uint64_t desc_budget = 1ull << 26;
         uint32_t run_windows = CW_MAX_BATCH_WINDOWS;
-        if (const char* env = getenv("CW_DRIVER_SLICE_DESC")) { const long long v = atoll(env); if (v >= 1) desc_budget = (uint64_t)v; }           /* test aids */
-        if (const char* env = getenv("CW_DRIVER_RUN_WINDOWS")) { const long v = atol(env); if (v >= 1 && v < (long)run_windows) run_windows = (uint32_t)v; }
+        if (const char* env = CW_AID_ENV("CW_DRIVER_SLICE_DESC")) { const long long v = atoll(env); if (v >= 1) desc_budget = (uint64_t)v; }           /* test aids */
+        if (const char* env = CW_AID_ENV("CW_DRIVER_RUN_WINDOWS")) { const long v = atol(env); if (v >= 1 && v < (long)run_windows) run_windows = (uint32_t)v; }
         struct Slice { uint32_t w0, w1, n_seqs; uint64_t n_words, seq_base, word_base; };
         std::vector<Slice> slices;
         uint64_t tot_seqs = 0, tot_words = 0;
@@ -460,9 +460,9 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
        loaded; an embedding application does the same (include/consent_amd.h "Threading").  A library call does not change its caller's
        environment. */
     /* the HIP runtime takes ~0.1 s to start (first call of the process): let it start while the reads are indexed */
-    if (const char* dr = getenv("CW_DRIVER_DRY")) sh.dry = dr[0] && dr[0] != '0';
+    if (const char* dr = CW_AID_ENV("CW_DRIVER_DRY")) sh.dry = dr[0] && dr[0] != '0';
     const bool dry = sh.dry;
-    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([dry] { if (dry || getenv("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warm{std::thread([dry] { if (dry || CW_AID_ENV("CW_NO_WARM")) return; int n = 0; (void)hipGetDeviceCount(&n); if (n > 0) (void)hipFree(nullptr); })};
 
     /* ---- indexReads (+ the proof file into the same index) ---- */
     cw_read_index* index = nullptr;
@@ -570,7 +570,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         std::vector<cw_overlap> ov(a->max_support ? a->max_support : 1);
         Job* cur = new Job();
         uint64_t job_cost_cap = 1ull << 26;
-        if (const char* env = getenv("CW_JOB_COST_CAP")) { const long long v = atoll(env); if (v >= 1) job_cost_cap = (uint64_t)v; } /* test aid */
+        if (const char* env = CW_AID_ENV("CW_JOB_COST_CAP")) { const long long v = atoll(env); if (v >= 1) job_cost_cap = (uint64_t)v; } /* test aid */
         auto push_job = [&]() {
             if (cur->wj.empty()) return true;
             cur->seq = n_jobs_total;

@@ -48,7 +48,7 @@ size_t big_slab_bytes() {
 struct TierMix { uint32_t s, m1, m2, l; };
 TierMix tier_mix(bool deep) {
     TierMix m = deep ? TierMix{4, 5, 4, 2} : TierMix{4, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
-    auto knob = [](const char* name, uint32_t dflt) { const char* v = getenv(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
+    auto knob = [](const char* name, uint32_t dflt) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
     if (m.s > 6) m.s = 6;
     if (m.m1 > 6) m.m1 = 6;
@@ -57,14 +57,28 @@ TierMix tier_mix(bool deep) {
     return m;
 }
 
-void tier_config(int cus, uint32_t big_slots, TierCfg (&t)[CW_TIERS]) {
-    t[0] = {(uint32_t)cus * 8 * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
-    /* slabs: one per wave the hardware can hold at once (LDS-bound: 5, 4 and 4 work-groups per CU) plus a margin; waves claim them (slot_busy) */
-    t[1] = {(uint32_t)cus * 7 * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
-    t[2] = {(uint32_t)cus * 9 * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
-    t[3] = {(uint32_t)cus * 9 * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
-    t[4] = {big_slots, big_slab_bytes()};
-    t[5] = {(uint32_t)cus * 6 * 2 * CW_POAH_WAVES, CW_POAH_SLAB_BYTES}; /* tier H: a slab per 32-lane half, at most five work-groups of four halves per CU */
+/* Work-groups of tier t (0 = S, 1 = M1, 2 = M2, 3 = L) worth launching for a batch of n_windows: the full persistent grid for a full batch,
+   fewer for a small one (a 16384-window batch at depth 150 has ~5 tier-S, ~4 tier-M1, ~0.7 tier-M2 and ~0.25 tier-L tasks per window) --
+   and with the grids the slabs: an engine used to hold ~10 GB of them whatever the batch, a 24-window batch now holds ~0.3 GB. */
+uint32_t tier_wgs_cap(int t, uint32_t n_windows, uint32_t full) {
+    static const uint32_t div[4] = {2, 4, 8, 8};
+    const uint64_t want = (uint64_t)n_windows / div[t] + 4u;
+    return want < full ? (uint32_t)want : full;
+}
+
+void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[CW_TIERS]) {
+    /* slabs: one per wave the hardware can hold at once plus a margin; waves claim them (slot_busy) */
+    const TierMix mix = tier_mix(false);
+    const uint32_t pass1 = 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u;
+    uint32_t l_wgs = tier_wgs_cap(3, n_windows, (uint32_t)cus * 9u);
+    if (l_wgs < pass1) l_wgs = pass1; /* the overflow pass launches its own tier-L work-groups */
+    t[0] = {(tier_wgs_cap(0, n_windows, (uint32_t)cus * mix.s) * 2u + 8u) * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
+    t[1] = {(tier_wgs_cap(1, n_windows, (uint32_t)cus * mix.m1) * 3u / 2u + 8u) * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
+    t[2] = {(tier_wgs_cap(2, n_windows, (uint32_t)cus * mix.m2) * 3u / 2u + 8u) * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
+    t[3] = {(l_wgs * 3u / 2u + 8u) * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
+    const uint64_t bs = (uint64_t)n_windows / 16u + 8u;
+    t[4] = {bs < big_slots ? (uint32_t)bs / 4u * 4u : big_slots, big_slab_bytes()};
+    t[5] = {CW_AID_ENV("CW_TIER_H") ? (uint32_t)cus * 6 * 2 * CW_POAH_WAVES : 8u, CW_POAH_SLAB_BYTES}; /* tier H (opt-in): a slab per 32-lane half, at most five work-groups of four halves per CU */
 }
 
 struct ScratchPlan {
@@ -84,12 +98,13 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
        few, heavy windows (900-base windows at depth 100) outgrows: cw_run_device_sync runs such a batch again with the larger plan */
     p.arena_cap = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096) * scale;
     uint64_t tc = (64ull * n_windows + 1024) * scale, mc = (2048ull * n_windows + 4096) * scale;
+    if (const char* v = CW_AID_ENV("CW_PLAN_DIV")) { const long x = atol(v); if (x >= 2) { tc = tc / (uint64_t)x + 1; mc = mc / (uint64_t)x + 1; } } /* test aid: a first plan that is too small, so that the growth of cw_run / cw_run_device_sync is exercised */
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
     p.member_cap = (uint32_t)(mc > 0x7FFFFFFFull ? 0x7FFFFFFFull : mc);
     /* test aid: shrink the two heuristic capacities so that the overflow path of the chain kernel's task emission can be exercised */
-    if (const char* v = getenv("CW_TASK_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.task_cap) p.task_cap = (uint32_t)x; }
-    if (const char* v = getenv("CW_MEMBER_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.member_cap) p.member_cap = (uint32_t)x; }
-    tier_config(cus, big_slots, p.tier);
+    if (const char* v = CW_AID_ENV("CW_TASK_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.task_cap) p.task_cap = (uint32_t)x; }
+    if (const char* v = CW_AID_ENV("CW_MEMBER_CAP")) { const long x = atol(v); if (x >= 1 && (uint64_t)x < p.member_cap) p.member_cap = (uint32_t)x; }
+    tier_config(cus, big_slots, n_windows, p.tier);
     size_t o = 0;
     auto put = [&](size_t& slot, size_t bytes) { slot = o; o = align_up(o + bytes, 256); };
     put(p.win, (size_t)n_windows * sizeof(WinInfo));
@@ -110,9 +125,10 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     p.ablock_units = ((uint64_t)n_seqs * (2ull * CW_TMAX + 2 + CW_TMAX / 8) + (uint64_t)n_windows * (CW_TMAX * (4ull + 8 + 8 + 8) + 256)) / 16 + 64;
     put(p.ablock, (size_t)p.ablock_units * 16);
     p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
-    put(p.pfall, (size_t)cus * p.pfall_elems * 2);
+    const size_t idx_wgs = n_windows < (uint32_t)cus ? n_windows : (size_t)cus; /* work-groups of the index kernel: one fallback slot each */
+    put(p.pfall, idx_wgs * p.pfall_elems * 2);
     for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
-    put(p.exg, (size_t)cus * CW_EXG_SLOTS * 8);
+    put(p.exg, idx_wgs * CW_EXG_SLOTS * 8);
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
     put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
     p.total = o;
@@ -149,7 +165,9 @@ int set_kernel_attributes() {
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
+#ifdef CW_TEST_AIDS
         hipFuncSetAttribute((const void*)cw_poa_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES) != hipSuccess ||
+#endif
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -164,9 +182,12 @@ int set_kernel_attributes() {
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
+#ifdef CW_TEST_AIDS
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_STN_QMAX, CW_STN_RMAX, 5, CW_STN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX)) != hipSuccess)
+                            CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX)) != hipSuccess ||
+#endif
+        false)
         return CW_E_NO_DEVICE;
     return CW_OK;
 }
@@ -274,7 +295,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
 
     uint32_t big_slots = 256;
-    if (const char* env = getenv("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
+    if (const char* env = CW_AID_ENV("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots, e->cap_scale);
     if (p.solid_cap > 0xFFFFFFFFull || p.seg_cap > 0xFFFFFFFFull || p.arena_cap > 0xFFFFFFFFull) return CW_E_INVALID; /* see CW_MAX_BATCH_WINDOWS */
@@ -314,7 +335,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (sc.task_dbg) CW_HIP(hipMemsetAsync(sc.task_dbg, 0, (size_t)p.task_cap * 16, st));
     sc.fin_vis = (uint32_t*)(base + p.finvis); sc.fin_vis_words = CW_FIN_VIS_GLB_WORDS;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
-    if (const char* env = getenv("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
+    if (const char* env = CW_AID_ENV("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     /* grids of the four concurrent tier kernels: `yield` work-groups that run one chunk of tasks and end, then `persist` ones that loop
        until the list is empty (see cw_poa_slab_kernel).  The yielding part is sized for the lists of a full batch and shrinks with the
        batch, so that a small batch does not pay for thousands of empty work-groups. */
@@ -324,8 +345,9 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     uint32_t yield_wgs[4] = {ymin(8192u, W_ / 2u + 1u), ymin(16384u, W_), ymin(4096u, W_ / 4u + 1u), ymin(4096u, W_ / 4u + 1u)};
     /* measured: with every tier on the machine all the time the stage is SLOWER (depth 150: 86-92 ms against 69-82; depth 30:
        25.3 against 19.6) -- the CUs are short of issue slots, not of resident waves -- so yielding is off unless CW_YIELD is set */
-    if (!getenv("CW_YIELD")) yield_wgs[0] = yield_wgs[1] = yield_wgs[2] = yield_wgs[3] = 0;
-    sc.persist_wgs[0] = (uint32_t)cus * mix.s; sc.persist_wgs[1] = (uint32_t)cus * mix.m1; sc.persist_wgs[2] = (uint32_t)cus * mix.m2; sc.persist_wgs[3] = (uint32_t)cus * mix.l;
+    if (!CW_AID_ENV("CW_YIELD")) yield_wgs[0] = yield_wgs[1] = yield_wgs[2] = yield_wgs[3] = 0;
+    sc.persist_wgs[0] = tier_wgs_cap(0, W_, (uint32_t)cus * mix.s); sc.persist_wgs[1] = tier_wgs_cap(1, W_, (uint32_t)cus * mix.m1);
+    sc.persist_wgs[2] = tier_wgs_cap(2, W_, (uint32_t)cus * mix.m2); sc.persist_wgs[3] = tier_wgs_cap(3, W_, (uint32_t)cus * mix.l);
     sc.persist_wgs[4] = 0;
     const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
                    wgs_l = yield_wgs[3] + sc.persist_wgs[3];
@@ -341,18 +363,18 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        handed over instead of ~195, and the step (two engines) goes from 73.1 to 68.8 ms on the same box.  CW_S_ROUTE_CELLS /
        CW_M1_ROUTE_DEPTH=0 give the old routing (experiments; results do not depend on the tier). */
     sc.s_route_cells = 112; /* round 4: tier S has no cell limit any more; it takes a task whose graph is expected to stay below this many NODES (its capacity: CW_POA_NC) */
-    if (const char* env = getenv("CW_S_ROUTE_NODES")) { const int v = atoi(env); if (v >= 8 && v <= CW_POA_NC) sc.s_route_cells = (uint32_t)v; }
-    sc.m1_route_depth = getenv("CW_M1_ROUTE_DEPTH") ? (uint32_t)atoi(getenv("CW_M1_ROUTE_DEPTH")) : 1u;
+    if (const char* env = CW_AID_ENV("CW_S_ROUTE_NODES")) { const int v = atoi(env); if (v >= 8 && v <= CW_POA_NC) sc.s_route_cells = (uint32_t)v; }
+    sc.m1_route_depth = CW_AID_ENV("CW_M1_ROUTE_DEPTH") ? (uint32_t)atoi(CW_AID_ENV("CW_M1_ROUTE_DEPTH")) : 1u;
     sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
-    if (const char* env = getenv("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
-    if (const char* env = getenv("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
+    if (const char* env = CW_AID_ENV("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
+    if (const char* env = CW_AID_ENV("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
     uint32_t wgs_h = 0;
-    if (sc.use_h) { uint32_t per_cu = 4; if (const char* env = getenv("CW_WGS_H")) { const int v = atoi(env); if (v >= 1 && v <= 5) per_cu = (uint32_t)v; } wgs_h = (uint32_t)cus * per_cu; }
+    if (sc.use_h) { uint32_t per_cu = 4; if (const char* env = CW_AID_ENV("CW_WGS_H")) { const int v = atoi(env); if (v >= 1 && v <= 5) per_cu = (uint32_t)v; } wgs_h = (uint32_t)cus * per_cu; }
     sc.persist_wgs[5] = wgs_h;
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2 + wgs_h;
-    if (getenv("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
+    if (CW_AID_ENV("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
-    sc.use_q = getenv("CW_NO_TIER_Q") ? 0u : 1u;
+    sc.use_q = CW_AID_ENV("CW_NO_TIER_Q") ? 0u : 1u;
     for (int t = 0; t < CW_TIERS; ++t) {
         if (t) { sc.tier_list[t] = (uint32_t*)(base + p.list[t]); sc.over_list[t] = (uint32_t*)(base + p.over[t]); }
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
@@ -392,7 +414,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
-    auto knob_u = [](const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) { const char* v = getenv(name); if (!v) return dflt; const long x = atol(v); return x >= (long)lo && x <= (long)hi ? (uint32_t)x : dflt; };
+    auto knob_u = [](const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const long x = atol(v); return x >= (long)lo && x <= (long)hi ? (uint32_t)x : dflt; };
     /* Launch shapes chosen for two batches in flight on one GPU (two engines, or the driver's two workers): while the other batch's
        persistent tier kernels hold the LDS of every CU, a work-group that needs most of a CU waits for tens of milliseconds in the
        middle of this batch's chain (rocprofv3 timeline, depth 150: tier sort 0.45 -> 13-34 ms, tier Q 8.7 -> 55-94 ms with tier S
@@ -405,13 +427,13 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t q_waves = knob_u("CW_Q_WAVES", 2, 1, CW_POAQ_WAVES);          /* waves per tier-Q work-group (four tasks per wave) */
     const uint32_t q_per_cu = knob_u("CW_Q_WGS_PER_CU", CW_POAQ_WAVES / q_waves, 1, CW_POAQ_WAVES / q_waves);
     const uint32_t q_grid = (uint32_t)cus * q_per_cu;
-    const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64, 1, (uint32_t)cus * 2);
+    const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u, 1, 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u);
     const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
     const uint32_t big_wgs = knob_u("CW_BIG_WGS", big_cap < 16 ? big_cap : 16, 1, big_cap);
     cw_sort_tier_kernel<<<5, sort_thr, sort_lds, st>>>(sc, sort_lds); /* tiers M1, M2 and L: largest tasks first; tiers Q and H: like with like */
     /* pass 0: every tier works through its own routed list, all four concurrently; the long-running large tiers are
        dispatched first so that their tail overlaps the bulk of the small tasks */
-    const char* ph_env = getenv("CW_PHASES");
+    const char* ph_env = CW_AID_ENV("CW_PHASES");
     const int phases = ph_env ? atoi(ph_env) : 0;
     const uint32_t grid_l = wgs_l;
     if (phases == 2) {
@@ -426,7 +448,11 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         stage_end(e, e->side[1], sid);
         if (wgs_h) {
             sid = stage_begin(e, e->side[0], "poa_h");
-            cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
+#ifdef CW_TEST_AIDS
+    #ifdef CW_TEST_AIDS
+        cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
+#endif
+#endif
             stage_end(e, e->side[0], sid);
         }
         sid = stage_begin(e, e->side[0], "poa_m1");
@@ -452,7 +478,9 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     stage_end(e, e->side[1], sid);
     if (wgs_h) { /* tier H shares tier M1's stream (a stream of its own would be a fifth hardware queue per engine): H first, then what is left for M1 */
         sid = stage_begin(e, e->side[0], "poa_h");
+#ifdef CW_TEST_AIDS
         cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
+#endif
         stage_end(e, e->side[0], sid);
     }
     sid = stage_begin(e, e->side[0], "poa_m1");
@@ -768,7 +796,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     std::lock_guard<std::mutex> lk(e->mu);
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    const bool want_trace = getenv("CW_STITCH_TRACE") != nullptr;
+    const bool want_trace = CW_AID_ENV("CW_STITCH_TRACE") != nullptr;
     const size_t trace_bytes = want_trace ? (size_t)batch->n_windows * 32 : 0;
     int rc = ensure(&e->xscratch, &e->xscratch_bytes, 256 + trace_bytes + (size_t)n_reads * 4);
     if (rc) return rc;
@@ -787,7 +815,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     /* one work-group of the wide kernel per CU, i.e. one wave per SIMD: the launch lasts as long as its longest read, and that read's wave is
        faster alone on its SIMD (measured with the register count deciding it: 55.3 ms per job at one wave per SIMD, 60.5 at two).  The kernel
        fits two per CU by registers and LDS; asking for more than half of the LDS keeps the second one off (CW_STITCH_TWO_PER_CU=1: don't). */
-    const size_t lds_one = getenv("CW_STITCH_TWO_PER_CU") ? 0 : (size_t)84 * 1024;
+    const size_t lds_one = CW_AID_ENV("CW_STITCH_TWO_PER_CU") ? 0 : (size_t)84 * 1024;
     const size_t lds_need = (size_t)CW_ST_WAVES * CW_ST_SLAB;
     const size_t lds = lds_need > lds_one ? lds_need : lds_one, lds_n = (size_t)CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX);
     uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
@@ -800,29 +828,33 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
        63 ms per job where the wide one takes ~75 -- a launch lasts as long as its longest read's serial chain of windows (a 30 kbp read: 66
        windows), which twice the resident waves do not shorten -- and the reads it hands on (a consensus above 640 in any of their windows)
        cost a second such tail, 51 ms: 114 ms per job against 75.  DESIGN.md "Round 3". */
-    const bool narrow = getenv("CW_STITCH_NARROW") && (uint64_t)window_size + 2ull * window_overlap <= CW_STN_RMAX;
+    const bool narrow = CW_AID_ENV("CW_STITCH_NARROW") && (uint64_t)window_size + 2ull * window_overlap <= CW_STN_RMAX;
     /* several waves per read (cw_stitch.h, st_sweep_sys): one read per work-group of five waves */
-    const bool sys = !narrow && getenv("CW_STITCH_SYS") && (uint64_t)window_size + 2ull * window_overlap <= CW_STS_RMAX;
+    const bool sys = !narrow && CW_AID_ENV("CW_STITCH_SYS") && (uint64_t)window_size + 2ull * window_overlap <= CW_STS_RMAX;
     const size_t lds_s = (((size_t)CW_ST_SLAB_OF(CW_STS_QMAX, CW_STS_RMAX) + 15u) & ~(size_t)15u) + sizeof(StSys);
     uint32_t wgs_s = n_reads;
     if (wgs_s > (uint32_t)cus_st * 6u) wgs_s = (uint32_t)cus_st * 6u;
     uint32_t wgs_max = narrow && wgs_n > wgs ? wgs_n : wgs;
     if (sys && (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES > wgs_max) wgs_max = (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES;
     /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
-    a.dir_bytes = getenv("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(getenv("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
+    a.dir_bytes = CW_AID_ENV("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(CW_AID_ENV("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
     if (a.dir_bytes < 64) a.dir_bytes = 64;
     rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs_max * CW_ST_WAVES * a.dir_bytes);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
-    a.prio = getenv("CW_STITCH_PRIO") ? atoi(getenv("CW_STITCH_PRIO")) : 1; /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
+    a.prio = CW_AID_ENV("CW_STITCH_PRIO") ? atoi(CW_AID_ENV("CW_STITCH_PRIO")) : 1; /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
+#ifdef CW_TEST_AIDS /* the two opt-in re-assembly kernels (bit-identical, measured no faster: DESIGN.md) exist in the test-aid build only */
     if (sys) {
         cw_stitch_kernel<CW_STS_QMAX, CW_STS_RMAX, 5, 1, false, true><<<wgs_s, 64 * CW_STS_WAVES, lds_s, st>>>(a);
         cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a); /* the reads it marked (a consensus above 1280: normally none) */
     } else if (narrow) {
         cw_stitch_kernel<CW_STN_QMAX, CW_STN_RMAX, 5, CW_STN_WAVES, false><<<wgs_n, 64 * CW_STN_WAVES, lds_n, st>>>(a);
         cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a); /* the reads it marked (normally none) */
-    } else {
+    } else
+#endif
+    {
+        (void)lds_n; (void)lds_s; (void)wgs_n; (void)wgs_s; (void)narrow; (void)sys;
         cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
     }
     CW_HIP(hipGetLastError());
@@ -995,6 +1027,7 @@ static int grow_if_that_helps(cw_engine* e, bool* again) {
     *again = false;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->scratch || e->last_windows == 0 || e->cap_scale >= 64u) return CW_OK;
+    if (CW_AID_ENV("CW_TASK_CAP") || CW_AID_ENV("CW_MEMBER_CAP")) return CW_OK; /* (test aids that shrink exactly these capacities) */
     CW_HIP(hipSetDevice(e->device));
     uint32_t flag = 0;
     CW_HIP(hipMemcpy(&flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost));
@@ -1026,10 +1059,11 @@ int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
         int t = -1;
         int rc = cw_submit(e, b, r, &t);
         if (rc != CW_OK) return rc;
-        if ((rc = cw_wait(e, t)) != CW_OK) return rc;
+        const int wrc = cw_wait(e, t);
+        if (wrc != CW_OK && wrc != CW_E_CAPACITY) return wrc;
         bool again = false;
-        if (!e || (rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
-        if (!again) return CW_OK;
+        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
+        if (!again) return wrc;
     }
 }
 

@@ -20,6 +20,7 @@
  *   simply end.
  */
 #include "../../include/consent_amd.h"
+#include "cw_env.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>

@@ -31,6 +31,8 @@ struct cw_slot {
     uint64_t cons_cap = 0, solid_cap = 0;
 };
 
+#include "cw_env.h"
+
 struct cw_engine {
     std::mutex mu; /* every entry point that touches the engine takes it: one engine = one caller at a time (see consent_amd.h "Threading") */
     cw_params prm{};

@@ -37,6 +37,8 @@
 #define CW_POAH_ROUTE_NODES 104 /* tasks whose graph is expected to stay below this many nodes come here (1.7 x longest member) */
 #define CW_POAH_MIN_LEN 32     /* shorter members: tiers Q and S */
 
+#ifdef CW_TEST_AIDS /* the kernel itself exists in the test-aid build only (measured slower in the mix: DESIGN.md); the constants above are the chain kernel's */
+
 /* ---- 32-lane half primitives ----------------------------------------------------------------------------------------------- */
 __device__ __forceinline__ unsigned h_ballot(bool p) { return (unsigned)(__ballot(p) >> (threadIdx.x & 32u)); }
 __device__ __forceinline__ int h_bcast(int v, int src) { return __shfl(v, (int)(threadIdx.x & 32u) + src); }
@@ -534,5 +536,7 @@ __global__ void __launch_bounds__(64 * CW_POAH_WAVES) cw_poa_h_kernel(DevBatch b
     if (gl == 0) __hip_atomic_store(&sc.slot_busy[CW_TIER_H][gw], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); /* the slab goes back */
     poa_producer_done(sc);
 }
+
+#endif /* CW_TEST_AIDS */
 
 #endif

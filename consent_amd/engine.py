@@ -79,6 +79,19 @@ def lib_path():
 
 
 _LIB = None
+_LIBS = {}  # path -> loaded library
+AIDS_LIB = os.path.join(_HERE, "aids", "libconsent_amd.so")  # the -DCW_TEST_AIDS build of the same sources (csrc/cw_env.h): tests and tools only
+
+
+def use_library(path=None):
+    """Make `path` (None: the default, lib_path()) the library every later Engine / helper of this process uses; returns the previous choice.
+    What the tests that need a test aid do for their duration (tests/conftest.py `aids`): both builds can be loaded side by side."""
+    global _LIB
+    prev = _LIB
+    _LIB = None
+    if path is not None:
+        _LIB = _load(path)
+    return prev
 
 
 def load_library():
@@ -86,6 +99,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    _LIB = _load(lib_path())
+    return _LIB
+
+
+def _load(p):
+    if p in _LIBS:
+        return _LIBS[p]
     try:  # PyTorch-ROCm ships its own HIP runtime: let it initialise first so both sides share one runtime and one context
         import torch
 
@@ -93,7 +113,6 @@ def load_library():
             torch.cuda.init()
     except Exception:
         pass
-    p = lib_path()
     if not os.path.exists(p):
         raise EngineError(f"{p} is missing: build it with `python -m consent_amd._build` (hipcc --offload-arch=gfx950)")
     lib = C.CDLL(p)
@@ -143,7 +162,7 @@ def load_library():
     lib.cw_synth_sizes.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.cw_synth_host.argtypes = [C.POINTER(SynthSpec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cw_synth_device.argtypes = [C.c_void_p, C.POINTER(SynthSpec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    _LIB = lib
+    _LIBS[p] = lib
     return lib
 
 

@@ -31,3 +31,16 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture
+def aids(monkeypatch):
+    """For the duration of a test: the -DCW_TEST_AIDS build of the library (consent_amd/aids/), in this process and -- through
+    LD_LIBRARY_PATH -- in the executables of bin/ it starts.  Only that build reads the test aids (CW_TASK_CAP, CW_DRIVER_DRY, ...), the
+    experiment knobs and holds the opt-in kernels; the product library ignores them (csrc/cw_env.h)."""
+    from consent_amd import engine
+
+    prev = engine.use_library(engine.AIDS_LIB)
+    monkeypatch.setenv("LD_LIBRARY_PATH", os.path.dirname(engine.AIDS_LIB) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    yield engine.AIDS_LIB
+    engine._LIB = prev

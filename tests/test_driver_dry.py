@@ -16,7 +16,8 @@ BIN = os.path.join(ROOT, "bin")
 
 def dry_run(fa, paf, threads, per_batch_env=None, j=3):
     argv = [os.path.join(BIN, "CONSENT-correction"), "-a", paf, "-s", "3", "-S", "150", "-l", "500", "-k", "9", "-c", "8", "-A", "2", "-f", "4", "-m", "50", "-j", str(j), "-r", fa, "-M", "150", "-p", "x"]
-    env = dict(os.environ, CW_DRIVER_DRY="1", CW_DRIVER_STATS="1", CW_PRODUCER_THREADS=str(threads))
+    # the dry run is a test aid: it exists in the -DCW_TEST_AIDS build of the library only (consent_amd/aids/, csrc/cw_env.h)
+    env = dict(os.environ, CW_DRIVER_DRY="1", CW_DRIVER_STATS="1", CW_PRODUCER_THREADS=str(threads), LD_LIBRARY_PATH=os.path.join(ROOT, "consent_amd", "aids"))
     out = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-1500:]
     assert out.stdout == ""  # a dry run corrects nothing

@@ -312,7 +312,7 @@ def test_config4_e_coli_scale_ont_correction_at_full_size_with_an_oracle_sample(
         assert recs[n] == s_, n
 
 
-def test_a_read_or_contig_may_span_extraction_slices_and_engine_runs(tmp_path):
+def test_a_read_or_contig_may_span_extraction_slices_and_engine_runs(tmp_path, aids):
     """One engine call takes at most CW_MAX_BATCH_WINDOWS windows and one extraction call a bounded number of (window, overlap) descriptors, but
     a job -- and a single contig inside it -- may be larger: the worker extracts in slices into one batch, corrects in runs over it and
     re-assembles once.  With the two limits shrunk (test aids) reads and contigs span many slices and runs; the FASTA must not change."""

@@ -238,7 +238,7 @@ def test_long_and_outlier_segments_exercise_all_tiers(engines):
     assert_same(got, exp, len(piles), "tiers")
 
 
-def test_tier_h_two_tasks_per_wave(engines, monkeypatch):
+def test_tier_h_two_tasks_per_wave(aids, monkeypatch):
     """Tier H (cw_poa_h.h): segments whose longest member has 32..63 bases, two tasks per wave on 32-lane halves, traceback over
     direction words.  Windows with few anchors give such segments; deep piles make nodes with many predecessors (the ordinal of the
     direction bytes covers four, the rest is decided from the cell values); CW_TIER_H=1 sends it what tier M1 would take, 2 also the
@@ -256,7 +256,7 @@ def test_tier_h_two_tasks_per_wave(engines, monkeypatch):
     prm = (9, 4, 8, 2, 150)
     hb = ca.pack_piles(piles)
     exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
-    e = engines(*prm)
+    e = ca.Engine(ca.Params(*prm))  # of the test-aid build (fixture `aids`): tier H exists there only
     monkeypatch.setenv("CW_TIER_H", "1")  # the tier is off by default (DESIGN.md "Round 3": correct, not faster)
     got = e.run(hb)
     ctr, _ = e.profile()
@@ -274,6 +274,7 @@ def test_tier_h_two_tasks_per_wave(engines, monkeypatch):
     monkeypatch.setenv("CW_TIER_H", "2")
     monkeypatch.setenv("CW_H_MIN_LEN", "8")  # nearly everything that is not tier Q's
     assert_same(e.run(hb2), exp2, 96, "depth 150, tier H for every task it can hold")
+    e.close()
 
 
 def test_empty_batch_and_capacity_overflow(engines):
@@ -401,13 +402,13 @@ def test_full_size_batch_properties_depth_150(engines):
     assert crc == whole
 
 
-def test_running_out_of_task_slots_flags_windows_and_never_runs_stale_tasks(engines, monkeypatch):
+def test_running_out_of_task_slots_flags_windows_and_never_runs_stale_tasks(aids, monkeypatch):
     """The chain kernel's task / member / list capacities are heuristics (64 tasks and 2048 members per window).  With the capacity shrunk
     (CW_TASK_CAP, CW_MEMBER_CAP: test aids read when a batch is planned) the windows that do not fit come back as overflow, every other window
     is what the oracle says, and a second, different batch on the same engine -- whose reserved-but-unwritten slots hold the first batch's
     records -- behaves the same way."""
     prm = (9, 4, 8, 2, 20)
-    e = engines(*prm)
+    e = ca.Engine(ca.Params(*prm))  # of the test-aid build (fixture `aids`)
     for first, depth in ((0, 30), (500, 12)):
         hb = synth_host(ca.SynthSpec.pacbio(48, depth, first_window=first))
         exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=os.cpu_count() or 1)
@@ -425,6 +426,27 @@ def test_running_out_of_task_slots_flags_windows_and_never_runs_stale_tasks(engi
                 if int(got.status[w]) != ca.WIN_OVERFLOW:
                     assert got.consensus(w) == exp.consensus(w), f"{env}: window {w} differs"
         assert_same(e.run(hb), exp, 48, "after the capped runs")
+    e.close()
+
+
+def test_a_batch_that_outgrows_its_task_capacities_is_run_again_with_a_larger_plan(aids, monkeypatch):
+    """Task, member and arena slots are sized per batch from its window count (64 tasks, 2048 members a window); a batch of few, heavy windows
+    can need more.  cw_run notices that windows stopped on exactly these capacities (CW_WHY_TASKS), plans x4 and runs the batch again
+    (cw_engine.cpp grow_if_that_helps; the native driver does the same through cw_run_device_sync).  Exercised with the first plan divided by
+    64 (CW_PLAN_DIV, a test aid): the result is the oracle's, no window is left stopped, and the engine keeps the larger plan."""
+    prm = ca.Params(9, 4, 8, 2, 20)
+    hb = synth_host(ca.SynthSpec.pacbio(48, 30, first_window=8100))
+    exp, _ = oracle_lib.oracle_run(prm, hb, threads=os.cpu_count() or 1)
+    monkeypatch.setenv("CW_PLAN_DIV", "64")
+    e = ca.Engine(prm)
+    try:
+        got = e.run(hb)
+        ctr, _ = e.profile()
+        assert int(ctr[1]) > (2048 * 48 + 4096) // 64 + 1, ctr[:2]  # more members than the first plan held
+        assert_same(got, exp, 48, "after the plan grew")
+        assert_same(e.run(hb), exp, 48, "second batch on the grown engine")
+    finally:
+        e.close()
 
 
 def test_cpp_adapter_runs_on_the_gpu(tmp_path):

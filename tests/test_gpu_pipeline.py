@@ -132,7 +132,7 @@ def test_other_parameters_and_max_support_cut(tmp_path):
     assert got == want and len(got) > 5
 
 
-def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, monkeypatch, capfd):
+def test_capacity_stops_the_run_or_leaves_the_read_out(tmp_path, aids, monkeypatch, capfd):
     """With the banded-traceback scratch shrunk some reads cannot be re-assembled: the default raises, "skip" leaves exactly those
     out (named on stderr) and every other read is still identical."""
     fa, paf = make_dataset(tmp_path, 35, n_reads=24)

@@ -177,7 +177,7 @@ def test_stitch_many_reads_in_one_launch():
     assert len(got) == 40 and n_up > 0
 
 
-def test_stitch_capacity_path_reports_status_and_does_not_disturb_other_reads(monkeypatch):
+def test_stitch_capacity_path_reports_status_and_does_not_disturb_other_reads(aids, monkeypatch):
     """Shrink the banded-traceback scratch: reads that need it report CW_READ_CAPACITY (2) with an empty result, the others
     are still bit-exact."""
     spec = make_reads(102, 4, 14)
@@ -198,7 +198,7 @@ def test_stitch_capacity_path_reports_status_and_does_not_disturb_other_reads(mo
         assert (st == 2 and g == "") or (st == 0 and g == f)
 
 
-def test_stitch_narrow_kernel_hands_long_consensuses_to_the_wide_one(monkeypatch):
+def test_stitch_narrow_kernel_hands_long_consensuses_to_the_wide_one(aids, monkeypatch):
     """CW_STITCH_NARROW=1: the five-chunk kernel (consensus and slice <= 640) takes every read first; a read with a longer consensus in any window is
     marked and redone by the wide kernel in a second launch -- same strings either way (the oracle's restatement decides)."""
     monkeypatch.setenv("CW_STITCH_NARROW", "1")
@@ -207,7 +207,7 @@ def test_stitch_narrow_kernel_hands_long_consensuses_to_the_wide_one(monkeypatch
     assert len(got) == 40 and n_up > 0
 
 
-def test_stitch_several_waves_per_read(monkeypatch):
+def test_stitch_several_waves_per_read(aids, monkeypatch):
     """CW_STITCH_SYS=1: one read per work-group of five waves, every sweep shared between them as a pipeline over the query's chunks (one chunk
     per wave up to 640 positions, two up to 1280; longer consensuses are handed to the wide kernel) -- same strings as the oracle's restatement in
     every case the one-wave kernels are tested on."""

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tier L / M2 launch-shape sweep + M2 with and without the recorded-decision path.  GPU box only.
 cd "$(dirname "$0")/.."
+export CONSENT_AMD_LIB=${CONSENT_AMD_LIB:-$PWD/consent_amd/aids/libconsent_amd.so} # the experiment knobs exist in the test-aid build only (csrc/cw_env.h)
 W=${1:-pacbio_d150_msa150}
 SRC="consent_amd/csrc/cw_engine.cpp consent_amd/csrc/cw_synth.cpp consent_amd/csrc/cw_hostio.cpp consent_amd/csrc/cw_driver.cpp"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DCW_M2_CODES=1 $SRC -o /tmp/libconsent_amd_m2c.so
