@@ -232,6 +232,7 @@ struct Worker {
         const double t1 = now_ms();
 
         /* ---- consensus per window ---- */
+        const double t_a0 = now_ms();
         DRV_RC(r_coff.ensure((size_t)(n_win + 1) * 8), j, "device memory (results)");
         DRV_RC(r_soff.ensure((size_t)(n_win + 1) * 8), j, "device memory (results)");
         uint64_t cons_total = 0, solid_total = 0;
@@ -243,6 +244,7 @@ struct Worker {
         DRV_RC(r_stat.ensure(n_win), j, "device memory (results)");
         DRV_HIP(hipMemsetAsync(r_stat.p, 0xFF, n_win, st), j, "memset");
         cw_result res{r_cons.as<char>(), r_coff.as<uint64_t>(), r_clen.as<uint32_t>(), r_stat.as<uint8_t>(), r_solid.as<uint32_t>(), r_soff.as<uint64_t>(), r_slen.as<uint32_t>()};
+        const double t_alloc = now_ms() - t_a0; /* result planning + allocation (inspection) */
         for (size_t s0 = 0; s0 < slices.size();) { /* runs = whole slices, at most run_windows windows */
             size_t s1 = s0 + 1;
             while (s1 < slices.size() && slices[s1].w1 - slices[s0].w0 <= run_windows) ++s1;
@@ -375,7 +377,7 @@ struct Worker {
         windows += n_win; reads += n_piles; jobs++;
         ms_extract += j.ms_extract; ms_consensus += j.ms_consensus; ms_stitch += j.ms_stitch;
         if (const char* tv = getenv("CW_DRIVER_TIMING")) if (tv[0] == '2') /* inspection: when each job's phases ran, per worker */
-            fprintf(stderr, "[job %llu] worker %p windows %u: start %.1f extract %.1f consensus %.1f stitch %.1f ms\n", (unsigned long long)j.seq, (void*)this, n_win, t0 - sh.t_start, t1 - t0, t2 - t1, t4 - t2);
+            fprintf(stderr, "[job %llu] worker %p windows %u: start %.1f extract %.1f consensus %.1f (alloc %.1f) stitch %.1f ms\n", (unsigned long long)j.seq, (void*)this, n_win, t0 - sh.t_start, t1 - t0, t2 - t1, t_alloc, t4 - t2);
     }
 };
 

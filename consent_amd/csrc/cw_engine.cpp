@@ -70,7 +70,7 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
     /* slabs: one per wave the hardware can hold at once plus a margin; waves claim them (slot_busy) */
     const TierMix mix = tier_mix(false);
     const uint32_t pass1 = 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u;
-    uint32_t l_wgs = tier_wgs_cap(3, n_windows, (uint32_t)cus * 9u);
+    uint32_t l_wgs = tier_wgs_cap(3, n_windows, (uint32_t)cus * mix.l); /* (3.5 MB a slab: a generous count here was 12 GB, and allocating it stalled an engine's first job by 1-2 s) */
     if (l_wgs < pass1) l_wgs = pass1; /* the overflow pass launches its own tier-L work-groups */
     t[0] = {(tier_wgs_cap(0, n_windows, (uint32_t)cus * mix.s) * 2u + 8u) * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
     t[1] = {(tier_wgs_cap(1, n_windows, (uint32_t)cus * mix.m1) * 3u / 2u + 8u) * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
@@ -158,8 +158,18 @@ int check_params(const cw_params* p) {
     return CW_OK;
 }
 
-int set_kernel_attributes() {
-    const int lds_st = CW_ST_WAVES * CW_ST_SLAB > 84 * 1024 ? CW_ST_WAVES * CW_ST_SLAB : 84 * 1024; /* see cw_stitch_device: one work-group per CU */
+/* LDS request of the wide re-assembly kernel: what it needs, or -- to keep a second work-group off the CU (cw_stitch_device) -- a little more than
+   half of what the DEVICE's CUs have (the constant 84 KB encoded gfx950's 160 KB), never more than a work-group may ask for */
+size_t stitch_lds_one(const hipDeviceProp_t& prop) {
+    size_t need = (size_t)CW_ST_WAVES * CW_ST_SLAB, half = prop.sharedMemPerMultiprocessor / 2 + 4096, cap = prop.sharedMemPerBlock;
+    if (prop.sharedMemPerMultiprocessor == 0) half = 84u * 1024u;
+    size_t want = half > need ? half : need;
+    if (cap >= need && want > cap) want = cap;
+    return want;
+}
+
+int set_kernel_attributes(const hipDeviceProp_t& prop) {
+    const int lds_st = (int)stitch_lds_one(prop);
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
@@ -244,7 +254,7 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
         ok = hipEventCreateWithFlags(&e->slot[i].ev_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->slot[i].ev_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { cw_destroy(e); return CW_E_NO_DEVICE; }
     /* kernel attributes are per device: set them here, once per engine (not behind a process-wide flag) */
-    if (set_kernel_attributes() != CW_OK) { cw_destroy(e); return CW_E_NO_DEVICE; }
+    if (set_kernel_attributes(e->prop) != CW_OK) { cw_destroy(e); return CW_E_NO_DEVICE; }
     *out = e;
     return CW_OK;
 }
@@ -815,7 +825,7 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     /* one work-group of the wide kernel per CU, i.e. one wave per SIMD: the launch lasts as long as its longest read, and that read's wave is
        faster alone on its SIMD (measured with the register count deciding it: 55.3 ms per job at one wave per SIMD, 60.5 at two).  The kernel
        fits two per CU by registers and LDS; asking for more than half of the LDS keeps the second one off (CW_STITCH_TWO_PER_CU=1: don't). */
-    const size_t lds_one = CW_AID_ENV("CW_STITCH_TWO_PER_CU") ? 0 : (size_t)84 * 1024;
+    const size_t lds_one = CW_AID_ENV("CW_STITCH_TWO_PER_CU") ? 0 : stitch_lds_one(e->prop);
     const size_t lds_need = (size_t)CW_ST_WAVES * CW_ST_SLAB;
     const size_t lds = lds_need > lds_one ? lds_need : lds_one, lds_n = (size_t)CW_STN_WAVES * CW_ST_SLAB_OF(CW_STN_QMAX, CW_STN_RMAX);
     uint32_t wgs = (n_reads + CW_ST_WAVES - 1) / CW_ST_WAVES;
@@ -1023,20 +1033,26 @@ int cw_wait(cw_engine* e, int ticket) {
 
 /* After a finished run: did windows stop on a capacity that a larger scratch plan cures (CW_WHY_TASKS: the task, member and arena slots are
    heuristics of the batch)?  Then the plan grows (x4, up to x64) and the caller runs the batch again. */
-static int grow_if_that_helps(cw_engine* e, bool* again) {
+static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st) {
     *again = false;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->scratch || e->last_windows == 0 || e->cap_scale >= 64u) return CW_OK;
     if (CW_AID_ENV("CW_TASK_CAP") || CW_AID_ENV("CW_MEMBER_CAP")) return CW_OK; /* (test aids that shrink exactly these capacities) */
     CW_HIP(hipSetDevice(e->device));
-    uint32_t flag = 0;
-    CW_HIP(hipMemcpy(&flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost));
-    if (!flag) return CW_OK;
+    /* copies on the caller's stream, not hipMemcpy: the null stream would wait for every other stream of the device -- the other worker's job */
+    uint32_t* flag = e->host_fb + 8; /* pinned */
+    CW_HIP(hipMemcpyAsync(flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost, st));
+    CW_HIP(hipStreamSynchronize(st));
+    if (!*flag) return CW_OK;
     std::vector<WinInfo> wi(e->last_windows);
-    CW_HIP(hipMemcpy(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost));
+    CW_HIP(hipMemcpyAsync(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost, st));
+    CW_HIP(hipStreamSynchronize(st));
     bool any = false; /* (windows stopped for other reasons stay stopped: the loop ends when no window names these capacities, or at x64) */
     for (const WinInfo& w : wi) any = any || (w.status == CW_WIN_OVERFLOW && w.pad_ == CW_WHY_TASKS);
-    if (any) { e->cap_scale *= 4u; *again = true; }
+    if (any) {
+        e->cap_scale *= 4u; *again = true;
+        fprintf(stderr, "[consent_amd] windows stopped on the batch's task / member / arena capacities: running the batch again with the plan x%u\n", e->cap_scale);
+    }
     return CW_OK;
 }
 
@@ -1049,7 +1065,7 @@ int cw_run_device_sync(cw_engine* e, const cw_batch* batch, const cw_result* res
         CW_HIP(hipSetDevice(e->device));
         CW_HIP(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream));
         bool again = false;
-        if ((rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
+        if ((rc = grow_if_that_helps(e, &again, hip_stream ? (hipStream_t)hip_stream : e->stream)) != CW_OK) return rc;
         if (!again) return CW_OK;
     }
 }
@@ -1062,7 +1078,7 @@ int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
         const int wrc = cw_wait(e, t);
         if (wrc != CW_OK && wrc != CW_E_CAPACITY) return wrc;
         bool again = false;
-        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again)) != CW_OK) return rc;
+        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again, e->stream)) != CW_OK) return rc;
         if (!again) return wrc;
     }
 }

@@ -547,7 +547,15 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         }
         const int cols = L + 1;
         const bool packed = PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN); /* two columns per lane (int16 tiers, wide rows) */
+        /* pad64 rests on an ordering the HSA memory model does not spell out: a lane beyond the member's columns stores into the first
+           cells of LATER rows, which another lane of the same wave overwrites when that row is finished -- correct iff two stores of one wave to
+           one address commit in issue order (they do on gfx9: one wave's vector memory instructions reach the L2 in order).  -DCW_NO_PAD64 builds
+           the masked variant; tests/test_gpu_variants.py runs both against the oracle. */
+#ifdef CW_NO_PAD64
+        const bool pad = false;
+#else
         const bool pad = PK != 0 && !packed && M.pad64 && cols <= 64;
+#endif
         const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
         if ((uint32_t)((n + 1) * hs + (pad ? 64 : 0)) > M.h_cap) return 2;
 

@@ -1,0 +1,42 @@
+"""What the job size costs on ONE GPU, for the multi-GPU model of DESIGN.md: the E. coli-scale ONT set (BASELINE configs[3]:
+4.6 Mbp, 30x, ~3.2e5 windows) through cw_run_correction with two workers on device 0 and the job size forced to what N GPUs would get --
+32768 windows (the default on one or two GPUs) down to the floor the driver picks for sixteen workers (windows / (4 x 16)).  Prints, per job
+size, jobs, seconds inside the driver, the serial part (read index) and windows/s; the model for N GPUs is then
+    T(N) = t_index + t_first_job_latency + windows / (N x rate(job size of N)).
+GPU box only."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pipeline_bench as pb
+from consent_amd.pipeline import run_correction
+
+d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
+fa, paf, _, n_reads, n_ovl = pb.generate(d, 4600000, 30, "ont")
+rows = []
+for per_job in (32768, 20000, 10000, 5000, 4096):
+    best = None
+    for rep in range(2):
+        fd = os.open(os.devnull, os.O_WRONLY)
+        t0 = time.perf_counter()
+        st = run_correction(fa, paf, fd, min_support=3, max_support=150, window_size=500, mer_size=9, common_kmers=8, min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150,
+                            nb_threads=1, devices=[0, 0], windows_per_batch=per_job)
+        wall = time.perf_counter() - t0
+        os.close(fd)
+        if best is None or st.ms_total < best[0]:
+            best = (st.ms_total, st.ms_index, int(st.windows), int(st.jobs), wall)
+    ms_total, ms_index, windows, jobs, wall = best
+    rows.append({"windows_per_job": per_job, "jobs": jobs, "windows": windows, "s_total": ms_total / 1e3, "s_index": ms_index / 1e3, "windows_per_s_after_index": windows / ((ms_total - ms_index) / 1e3)})
+    print(json.dumps(rows[-1]), flush=True)
+base = rows[0]
+print("model: T(N) = s_index + windows / (N x rate(job size)) with the job size the driver picks for 2N workers (windows / (8N), floor 4096, cap 32768)")
+for n in (1, 2, 4, 8):
+    want = max(4096, min(32768, base["windows"] // (8 * n) + 1))
+    r = min(rows, key=lambda x: abs(x["windows_per_job"] - want))
+    t = base["s_index"] + base["windows"] / (n * r["windows_per_s_after_index"])
+    print(f"N={n}: job size {want} (measured at {r['windows_per_job']}), modelled {t:.3f} s, speed-up over N=1 {((base['s_index'] + base['windows'] / rows[0]['windows_per_s_after_index']) / t):.2f}x")
