@@ -24,7 +24,7 @@
 namespace {
 
 /* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
-static_assert(5 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: five work-groups per CU");
+static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
 static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
@@ -374,7 +374,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        CW_M1_ROUTE_DEPTH=0 give the old routing (experiments; results do not depend on the tier). */
     sc.s_route_cells = 112; /* round 4: tier S has no cell limit any more; it takes a task whose graph is expected to stay below this many NODES (its capacity: CW_POA_NC) */
     if (const char* env = CW_AID_ENV("CW_S_ROUTE_NODES")) { const int v = atoi(env); if (v >= 8 && v <= CW_POA_NC) sc.s_route_cells = (uint32_t)v; }
-    sc.m1_route_depth = CW_AID_ENV("CW_M1_ROUTE_DEPTH") ? (uint32_t)atoi(CW_AID_ENV("CW_M1_ROUTE_DEPTH")) : 1u;
+    sc.m1_route_depth = 1u;
+    if (const char* env = CW_AID_ENV("CW_M1_ROUTE_DEPTH")) sc.m1_route_depth = (uint32_t)atoi(env);
     sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
     if (const char* env = CW_AID_ENV("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
     if (const char* env = CW_AID_ENV("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
@@ -847,12 +848,14 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     uint32_t wgs_max = narrow && wgs_n > wgs ? wgs_n : wgs;
     if (sys && (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES > wgs_max) wgs_max = (wgs_s + CW_ST_WAVES - 1) / CW_ST_WAVES;
     /* test aid: CW_STITCH_DIR_BYTES shrinks the banded-traceback scratch so that the capacity path can be exercised */
-    a.dir_bytes = CW_AID_ENV("CW_STITCH_DIR_BYTES") ? (uint32_t)strtoul(CW_AID_ENV("CW_STITCH_DIR_BYTES"), nullptr, 10) : CW_ST_DIR_BYTES;
+    a.dir_bytes = CW_ST_DIR_BYTES;
+    if (const char* env = CW_AID_ENV("CW_STITCH_DIR_BYTES")) a.dir_bytes = (uint32_t)strtoul(env, nullptr, 10);
     if (a.dir_bytes < 64) a.dir_bytes = 64;
     rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs_max * CW_ST_WAVES * a.dir_bytes);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
-    a.prio = CW_AID_ENV("CW_STITCH_PRIO") ? atoi(CW_AID_ENV("CW_STITCH_PRIO")) : 1; /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
+    a.prio = 1;
+    if (const char* env = CW_AID_ENV("CW_STITCH_PRIO")) a.prio = atoi(env); /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
 #ifdef CW_TEST_AIDS /* the two opt-in re-assembly kernels (bit-identical, measured no faster: DESIGN.md) exist in the test-aid build only */
     if (sys) {

@@ -59,7 +59,8 @@
 #define CW_POAB_HC ((CW_POAB_NC + 1) * (CW_POAB_LC + 1))
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
-#define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
+#define CW_POA_EW_BYTES(EC) (CW_CONS_HEAVIEST_BUNDLE ? 2 * (EC) : 0) /* edge weights, kept only under the heaviest-bundle policy (cw_policy.h) */
+#define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + CW_POA_EW_BYTES(EC) + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
    predecessors, rank <-> node maps, in-edge heads and degrees, bases, sequence ranks); what only the rank bookkeeping before a fill
@@ -69,11 +70,11 @@
    waves in 38 KB), L 37 KB (it fits the holes the other tiers leave). */
 #define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
 #define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + 16 * 64 * 2 + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
-#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + 4 * ((LC) + 1) + 255) / 256 * 256)
+#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + CW_POA_EW_BYTES(EC) + 4 * ((LC) + 1) + 255) / 256 * 256)
 #ifndef CW_S_EDGES_LDS
 #define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */
 #endif
-#define CW_POA_SLAB_BYTES (CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + (CW_S_EDGES_LDS ? 4 * CW_POA_EC + 2 * CW_POA_NC : 0)) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
+#define CW_POA_SLAB_BYTES (CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + (CW_S_EDGES_LDS ? 4 * CW_POA_EC + CW_POA_EW_BYTES(CW_POA_EC) + 2 * CW_POA_NC : 0)) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
@@ -104,6 +105,7 @@ struct PoaMem {
     uint16_t* indeg;
     uint16_t* efrom;    /* edge -> source node                                                                   */
     uint16_t* enext;    /* edge -> next in-edge of the same target                                               */
+    uint16_t* ew;       /* edge -> sequences whose path uses it (heaviest-bundle policy only, else NULL)         */
     uint16_t* r2n;      /* rank -> node                                                                          */
     uint16_t* n2r;
     uint16_t* rtmp;     /* new rank order while fresh nodes are being placed                                     */
@@ -142,7 +144,8 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     else { M.dirs = (unsigned long long*)p; p += (size_t)dc * 16; }
     M.rmeta = (uint32_t*)p; p += 4 * nc;
     M.plist = (uint16_t*)p; p += 2 * ec;   /* 4-byte aligned: follows rmeta */
-    if (!(pc && cold_edges)) { M.efrom = (uint16_t*)p; p += 2 * ec; M.enext = (uint16_t*)p; p += 2 * ec; }
+    M.ew = nullptr;
+    if (!(pc && cold_edges)) { M.efrom = (uint16_t*)p; p += 2 * ec; M.enext = (uint16_t*)p; p += 2 * ec; if (CW_CONS_HEAVIEST_BUNDLE) { M.ew = (uint16_t*)p; p += 2 * ec; } }
     M.rpred0 = (uint16_t*)p; p += 2 * nc;
     if (chain_tabs) { M.p2 = (uint16_t*)p; p += 2 * nc; M.p4 = (uint16_t*)p; p += 2 * nc; } else { M.p2 = nullptr; M.p4 = nullptr; }
     if (!(pc && cold_edges)) { M.ncov = (uint16_t*)p; p += 2 * nc; }
@@ -156,7 +159,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.seqrank = (uint16_t*)p; p += 2 * (lc + 1);
     if (pc) { M.pcur = (uint16_t*)pc; pc += 2 * (lc + 1); M.pat = (uint16_t*)pc; pc += 2 * (lc + 1); }
     else { M.pcur = (uint16_t*)p; p += 2 * (lc + 1); M.pat = (uint16_t*)p; p += 2 * (lc + 1); }
-    if (pc && cold_edges) { M.efrom = (uint16_t*)pc; pc += 2 * ec; M.enext = (uint16_t*)pc; pc += 2 * ec; M.ncov = (uint16_t*)pc; pc += 2 * nc; }
+    if (pc && cold_edges) { M.efrom = (uint16_t*)pc; pc += 2 * ec; M.enext = (uint16_t*)pc; pc += 2 * ec; if (CW_CONS_HEAVIEST_BUNDLE) { M.ew = (uint16_t*)pc; pc += 2 * ec; } M.ncov = (uint16_t*)pc; pc += 2 * nc; }
     M.nbase = p; p += nc;
     M.nalc = p; p += nc;
     M.has_out = p; p += nc;
@@ -502,6 +505,40 @@ __device__ __forceinline__ bool poa_slow_step(const PoaMem<HT>& M, const int i, 
     return found;
 }
 
+
+#if CW_CONS_HEAVIEST_BUNDLE
+/* cw_policy.h CW_POA_CONSENSUS_HEAVIEST_BUNDLE, on ONE lane: a recurrence over the nodes in rank order, once per task (scores by node in
+   rmeta, the chosen source in rpred0 -- both free after the last member).  Returns the consensus length; writes it if it fits. */
+template <typename HT>
+__device__ __forceinline__ uint32_t poa_consensus_hb(const PoaMem<HT>& M, const int n, const PoaTask& t, const DevScratch& sc) {
+    uint32_t* score = M.rmeta;
+    uint16_t* pred = M.rpred0;
+    int end = -1;
+    uint32_t end_score = 0;
+    for (int r = 0; r < n; ++r) {
+        const int v = M.r2n[r];
+        int p = -1;
+        uint32_t wb = 0, ps = 0;
+        for (uint32_t e = M.in_head[v]; e != CW_NONE16; e = M.enext[e]) {
+            const int u = M.efrom[e];
+            const uint32_t w = M.ew[e], su = score[u];
+            if (p < 0 || wb < w || (wb == w && ps <= su)) { wb = w; p = u; ps = su; }
+        }
+        const uint32_t s = p < 0 ? 0u : wb + ps;
+        score[v] = s;
+        pred[v] = p < 0 ? (uint16_t)CW_NONE16 : (uint16_t)p;
+        if (!M.has_out[v] && (end < 0 || end_score < s)) { end = v; end_score = s; }
+    }
+    uint32_t len = 0;
+    for (int v = end; v >= 0; v = pred[v] == CW_NONE16 ? -1 : (int)pred[v]) ++len;
+    if (len <= t.out_cap) {
+        uint32_t k = len;
+        for (int v = end; v >= 0; v = pred[v] == CW_NONE16 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = "ACGT"[M.nbase[v]];
+    }
+    return len;
+}
+#endif
+
 /* Returns 1 = done, 2 = a capacity of this memory class was exceeded, 3 = output capacity exceeded / internal. */
 /* PK: 0 = one column per lane (int32 tier G); 1 = two columns per lane in packed int16 for rows wider than 64 columns (tiers S, M1,
    M2, whose capacities keep every score far inside int16); 2 = the same for tier L while nodes + columns <= CW_POA_PK_SPAN, i.e.
@@ -539,7 +576,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                 M.in_head[j] = j ? (uint16_t)(j - 1) : CW_NONE16; M.in_tail[j] = M.in_head[j];
                 M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
                 M.r2n[j] = (uint16_t)j; M.n2r[j] = (uint16_t)j;
-                if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; }
+                if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
             }
             n = L; ne = L - 1; tpl_nodes = L; meta_ok = false;
             cw_wave_sync();
@@ -993,7 +1030,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     head = M.pcur[j - 1]; cur = M.pcur[j];
                     add = true;
                     for (uint32_t e = M.in_head[cur]; e != CW_NONE16; e = M.enext[e])
-                        if (M.efrom[e] == (uint16_t)head) { add = false; break; }
+                        if (M.efrom[e] == (uint16_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint16_t)(M.ew[e] + 1); break; } /* (a path uses an edge once: no two lanes meet here) */
                 }
                 const unsigned long long ab = __ballot(add);
                 const int total = __popcll(ab);
@@ -1001,6 +1038,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                 if (add) {
                     const int e = ne + __popcll(ab & lt_mask);
                     M.efrom[e] = (uint16_t)head; M.enext[e] = CW_NONE16;
+                    if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = 1;
                     const uint32_t tl = M.in_tail[cur];
                     if (tl == CW_NONE16) M.in_head[cur] = (uint16_t)e; else M.enext[tl] = (uint16_t)e;
                     M.in_tail[cur] = (uint16_t)e;
@@ -1014,8 +1052,13 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         POA_PROF(3);
     }
 
-    /* ---- column-majority consensus ---- */
+    /* ---- consensus: column-majority vote, or the heaviest bundle (cw_policy.h CW_POA_CONSENSUS) ---- */
     uint32_t out_len = 0;
+#if CW_CONS_HEAVIEST_BUNDLE
+    cw_wave_sync();
+    if (lane == 0) out_len = poa_consensus_hb(M, n, t, sc);
+    out_len = (uint32_t)__shfl((int)out_len, 0);
+#else
     for (int r0 = 0; r0 < n; r0 += 64) {
         const int r = r0 + lane;
         int emit = -1;
@@ -1051,6 +1094,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
         out_len += (uint32_t)__popcll(bal);
     }
+#endif
     if (out_len > t.out_cap) return 3;
     if (lane == 0) sc.seg_len[t.seg_slot] = out_len;
     POA_PROF(4);

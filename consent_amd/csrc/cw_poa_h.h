@@ -37,6 +37,9 @@
 #define CW_POAH_ROUTE_NODES 104 /* tasks whose graph is expected to stay below this many nodes come here (1.7 x longest member) */
 #define CW_POAH_MIN_LEN 32     /* shorter members: tiers Q and S */
 
+#if defined(CW_TEST_AIDS) && CW_CONS_HEAVIEST_BUNDLE
+#error "tier H (test-aid build) has no heaviest-bundle consensus: build it with the column vote"
+#endif
 #ifdef CW_TEST_AIDS /* the kernel itself exists in the test-aid build only (measured slower in the mix: DESIGN.md); the constants above are the chain kernel's */
 
 /* ---- 32-lane half primitives ----------------------------------------------------------------------------------------------- */

@@ -112,7 +112,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                 M.in_head[j] = j ? (uint16_t)(j - 1) : CW_NONE16; M.in_tail[j] = M.in_head[j];
                 M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
                 M.r2n[j] = (uint16_t)j; M.n2r[j] = (uint16_t)j;
-                if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; }
+                if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
             }
             n = L; ne = L - 1; tpl_nodes = L; meta_ok = false;
             cw_wave_sync();
@@ -335,7 +335,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                     head = M.pcur[j - 1]; cur = M.pcur[j];
                     add = true;
                     for (uint32_t e = M.in_head[cur]; e != CW_NONE16; e = M.enext[e])
-                        if (M.efrom[e] == (uint16_t)head) { add = false; break; }
+                        if (M.efrom[e] == (uint16_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint16_t)(M.ew[e] + 1); break; }
                 }
                 const unsigned ab = q_ballot(add);
                 const int total = __popc(ab);
@@ -343,6 +343,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                 if (add) {
                     const int e = ne + __popc(ab & lt_mask);
                     M.efrom[e] = (uint16_t)head; M.enext[e] = CW_NONE16;
+                    if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = 1;
                     const uint32_t tl = M.in_tail[cur];
                     if (tl == CW_NONE16) M.in_head[cur] = (uint16_t)e; else M.enext[tl] = (uint16_t)e;
                     M.in_tail[cur] = (uint16_t)e;
@@ -356,8 +357,13 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         POAQ_PROF(3);
     }
 
-    /* ---- column-majority consensus ---- */
+    /* ---- consensus: column-majority vote, or the heaviest bundle (cw_policy.h CW_POA_CONSENSUS) ---- */
     uint32_t out_len = 0;
+#if CW_CONS_HEAVIEST_BUNDLE
+    cw_wave_sync();
+    if (gl == 0) out_len = poa_consensus_hb(M, n, t, sc);
+    out_len = (uint32_t)__shfl((int)out_len, (int)(threadIdx.x & 48u));
+#else
     for (int r0 = 0; r0 < n; r0 += 16) {
         const int r = r0 + gl;
         int emit = -1;
@@ -393,6 +399,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
         out_len += (uint32_t)__popc(bal);
     }
+#endif
     if (out_len > t.out_cap) return 3;
     if (gl == 0) sc.seg_len[t.seg_slot] = out_len;
     POAQ_PROF(4);

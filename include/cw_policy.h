@@ -59,7 +59,12 @@
 #define CW_POA_MODE CW_POA_MODE_NW
 #endif
 #define CW_POA_CONSENSUS_MAJORITY 0        /* column-majority vote over the MSA (implemented)        */
-#define CW_POA_CONSENSUS_HEAVIEST_BUNDLE 1 /* spoa's heaviest bundle                                  */
+#define CW_POA_CONSENSUS_HEAVIEST_BUNDLE 1 /* heaviest bundle (Lee 2002, as in spoa's generate_consensus): implemented on both sides since round 4:
+                                              edge weight = sequences whose path uses the edge; nodes in rank order: the in-edge of largest weight
+                                              is the node's choice, on equal weights the one whose source has the larger score, on equal scores
+                                              the LATER in-edge (spoa's `<=`); score = that weight + the source's score (0 without in-edges); the
+                                              consensus ends in the best-scoring SINK (lowest rank on ties: where spoa completes a branch that
+                                              stops inside the graph, this rule never starts one) and is read back along the choices */
 #ifndef CW_POA_CONSENSUS
 #define CW_POA_CONSENSUS CW_POA_CONSENSUS_MAJORITY
 #endif
@@ -83,13 +88,14 @@
 #ifndef CW_SEG_MISSING_ANCHOR
 #define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
 #endif
-#if CW_POA_MODE != CW_POA_MODE_NW || CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY || CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || \
-    CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
+#if CW_POA_MODE != CW_POA_MODE_NW || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
+    CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
 #error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
 #endif
 /* the column vote, one place for both sides: drop the column? / take the template's base on a tie? */
 #define CW_CONS_DROPS(gaps, top_count) (CW_POA_CONS_GAP == CW_CONS_GAP_STRICT ? (gaps) > (top_count) : (gaps) >= (top_count))
 #define CW_CONS_TEMPLATE_WINS_TIES (CW_POA_CONS_TIE == CW_CONS_TIE_TEMPLATE)
+#define CW_CONS_HEAVIEST_BUNDLE (CW_POA_CONSENSUS == CW_POA_CONSENSUS_HEAVIEST_BUNDLE)
 
 /* --- anchor index (A4a) --------------------------------------------------------------------- */
 /* A k-mer occurring twice inside ANY single sequence of the pile is never an anchor.            */

@@ -76,7 +76,7 @@ static std::string upper_copy(std::string s) {
  * ---------------------------------------------------------------------------------------------- */
 namespace {
 
-struct PoaEdge { int from, to; };
+struct PoaEdge { int from, to; int weight; /* sequences whose path uses the edge (heaviest-bundle consensus) */ };
 struct PoaNode {
     char base;
     int coverage;                         /* sequences whose path runs through this node */
@@ -97,8 +97,8 @@ struct PoaGraph {
     }
     void add_edge(int from, int to) {
         for (int e : nodes[from].out_edges)
-            if (edges[e].to == to) return;
-        edges.push_back(PoaEdge{from, to});
+            if (edges[e].to == to) { edges[e].weight++; return; }
+        edges.push_back(PoaEdge{from, to, 1});
         nodes[from].out_edges.push_back((int)edges.size() - 1);
         nodes[to].in_edges.push_back((int)edges.size() - 1);
     }
@@ -309,7 +309,30 @@ struct PoaGraph {
        topological order).  A column whose gap count strictly exceeds every base count is dropped;
        otherwise the most frequent base is emitted; ties between bases go to the template's base when
        it is among the tied, else to the smallest code (A<C<G<T).  See cw_policy.h. */
+    /* cw_policy.h CW_POA_CONSENSUS_HEAVIEST_BUNDLE */
+    std::string consensus_heaviest_bundle() const {
+        const int n = (int)nodes.size();
+        std::vector<long> score(n, 0);
+        std::vector<int> pred(n, -1);
+        int end = -1;
+        for (int r = 0; r < n; ++r) {
+            const int v = rank2node[r];
+            long w_best = -1;
+            for (int e : nodes[v].in_edges) {
+                const int u = edges[e].from;
+                if (w_best < edges[e].weight || (w_best == edges[e].weight && score[pred[v]] <= score[u])) { w_best = edges[e].weight; pred[v] = u; }
+            }
+            score[v] = pred[v] == -1 ? 0 : w_best + score[pred[v]];
+            if (nodes[v].out_edges.empty() && (end == -1 || score[end] < score[v])) end = v;
+        }
+        std::string out;
+        for (int v = end; v != -1; v = pred[v]) out.push_back(nodes[v].base);
+        std::reverse(out.begin(), out.end());
+        return out;
+    }
+
     std::string consensus() const {
+        if (CW_CONS_HEAVIEST_BUNDLE) return consensus_heaviest_bundle();
         std::string out;
         const int n = (int)nodes.size();
         for (int r = 0; r < n;) {

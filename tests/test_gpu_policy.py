@@ -57,3 +57,20 @@ def test_non_default_consensus_policy_is_honoured_by_engine_and_oracle(tmp_path)
     mixed1, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     mixed2, _ = run_child({"CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
     assert not mixed1 and not mixed2
+
+
+@pytest.mark.timeout(1200)
+def test_heaviest_bundle_consensus_is_implemented_on_both_sides(tmp_path):
+    """-DCW_POA_CONSENSUS=1 (cw_policy.h CW_POA_CONSENSUS_HEAVIEST_BUNDLE, round 4): edge weights kept by the merge, the consensus read back
+    along the heaviest in-edges from the best-scoring sink -- in the oracle and in every POA tier of the engine (Q, S, M1, M2, L, G).  The two
+    sides agree window by window under that policy, and the consensus is not the column vote's."""
+    from consent_amd import _build
+
+    hb = ["-DCW_POA_CONSENSUS=1"]
+    alt_lib = str(tmp_path / "libconsent_amd_hb.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *hb, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(hb)])
+    same_default, digest_default = run_child({})
+    same_hb, digest_hb = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_hb
+    assert digest_default != digest_hb
