@@ -254,7 +254,11 @@ struct Worker {
             cw_batch run{w1 - w0, (uint32_t)rs, rw, b_wfs.as<uint32_t>() + w0, b_len.as<uint32_t>(), b_off.as<uint64_t>(), b_bases.as<uint32_t>()};
             cw_result rres{r_cons.as<char>(), r_coff.as<uint64_t>() + w0, r_clen.as<uint32_t>() + w0, r_stat.as<uint8_t>() + w0, r_solid.as<uint32_t>(), r_soff.as<uint64_t>() + w0,
                            r_slen.as<uint32_t>() + w0};
+            #ifdef CW_DRIVER_NO_SYNC /* experiment: without the wait + capacity check between consensus and re-assembly */
+            DRV_RC(cw_run_device(eng, &run, &rres, st), j, "cw_run_device");
+#else
             DRV_RC(cw_run_device_sync(eng, &run, &rres, st), j, "cw_run_device");
+#endif
             s0 = s1;
         }
 

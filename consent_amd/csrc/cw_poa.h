@@ -799,10 +799,10 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #endif
                     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
                     int row = i;
-                    if (M.p2) { /* tr steps up the chain: 4 + 2 + 1 */
-                        if (tr & 4) { const uint32_t v = M.p4[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; }
-                        if (tr & 2) { if (row > 0) { const uint32_t v = M.p2[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; } else row = -1; }
-                        if (tr & 1) row = row > 0 ? (int)M.rpred0[row - 1] : -1;
+                    if (M.p2) { /* tr steps up the chain: 4 + 2 + 1 (unconditional reads and selects, see cw_poa_c.h) */
+                        { uint32_t v = M.p4[row - 1]; asm volatile("" : "+v"(v)); row = (tr & 4) ? (v == CW_NONE16 ? -1 : (int)v) : row; }
+                        { uint32_t v = M.p2[max(row, 1) - 1]; asm volatile("" : "+v"(v)); row = (tr & 2) ? ((row > 0 && v != CW_NONE16) ? (int)v : -1) : row; }
+                        { uint32_t v = M.rpred0[max(row, 1) - 1]; asm volatile("" : "+v"(v)); row = (tr & 1) ? (row > 0 ? (int)v : -1) : row; }
                     } else {
                         int ch[8];
                         ch[0] = i;

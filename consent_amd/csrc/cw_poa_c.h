@@ -176,10 +176,11 @@ __device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int 
     while (i > 0) {
         if (++trips > n + cols + 4) return false;
         i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
-        int row = i; /* tr steps up the first-predecessor chain: 4 + 2 + 1 */
-        if (tr & 4) { const uint32_t v = M.p4[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; }
-        if (tr & 2) { if (row > 0) { const uint32_t v = M.p2[row - 1]; row = v == CW_NONE16 ? -1 : (int)v; } else row = -1; }
-        if (tr & 1) row = row > 0 ? (int)M.rpred0[row - 1] : -1;
+        int row = i; /* tr steps up the first-predecessor chain: 4 + 2 + 1 -- three unconditional reads and selects (as `if (tr & 4) ...` each
+                        level was an execution-mask region of its own: ~45 instructions for what is 15) */
+        { uint32_t v = M.p4[row - 1]; asm volatile("" : "+v"(v)); row = (tr & 4) ? (v == CW_NONE16 ? -1 : (int)v) : row; }
+        { uint32_t v = M.p2[max(row, 1) - 1]; asm volatile("" : "+v"(v)); row = (tr & 2) ? ((row > 0 && v != CW_NONE16) ? (int)v : -1) : row; }
+        { uint32_t v = M.rpred0[max(row, 1) - 1]; asm volatile("" : "+v"(v)); row = (tr & 1) ? (row > 0 ? (int)v : -1) : row; }
         const int col = j - tc;
         uint32_t nib = 0u;
         if (row >= 1 && col >= 0) {
