@@ -503,9 +503,14 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     if (devs.empty()) {
         /* two workers (engine + buffers each) per device: while one job is in its re-assembly -- one wave per read, the longest read sets
            the time, most of the GPU idle -- the other worker's consensus kernels run (measured on one GPU: 717 -> 550 ms for 112 k windows) */
-        int per_dev = 2;
-        if (const char* env = getenv("CW_WORKERS_PER_DEVICE")) { const int v = atoi(env); if (v >= 1 && v <= 8) per_dev = v; }
         const int want = a->nb_threads < 1 ? 1 : (int)a->nb_threads;
+        /* A run that gives a device fewer than ~1e5 windows (the E. coli-scale set on eight GPUs: 4e4 each) is cut into jobs of a few
+           thousand windows, whose fixed costs -- the longest POA task, the longest read of the re-assembly, the synchronisation points of a
+           run -- no longer hide behind one other job: four workers per device then (measured on one GPU with jobs of 5000 windows:
+           1.97e5 windows/s with two workers, 2.36e5 with three, 2.77e5 with four; with jobs of 32768: 3.3e5 / 2.8e5 / 2.8e5) */
+        const uint64_t est_per_dev = (tpl_bases / (a->window_size - a->window_overlap) + 1) / (uint64_t)(n_dev < want ? n_dev : want);
+        int per_dev = est_per_dev < 100000ull ? (int)std::min<uint64_t>(4, est_per_dev / 4096 + 1) : 2; /* (no more workers than jobs: an engine costs ~60 ms and 1.3 GB to set up) */
+        if (const char* env = getenv("CW_WORKERS_PER_DEVICE")) { const int v = atoi(env); if (v >= 1 && v <= 8) per_dev = v; }
         for (int k = 0; k < per_dev; ++k) for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d);
     }
     for (int d : devs) if (d < 0 || d >= n_dev) { cw_read_index_free(index); return CW_E_INVALID; }
@@ -552,13 +557,15 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
        this thread already reads the next round; jobs are then put together in pile order, so their contents do not depend on the
        number of helpers.  One thread did all three before: 3 M windows/s, within 2x of what eight GPUs take. */
     /* Windows per job.  The caller's figure, else 32768 -- unless the run is too short for that many workers: a job is the unit the workers
-       share, and with fewer than about four jobs per worker the last ones leave most engines idle (the E. coli-scale set is 3.2e5 windows:
-       ten jobs of 32768 for the sixteen workers of an 8-GPU node).  The number of windows is not known before the alignments are read, but
+       share, and with fewer than about eight jobs per device the last ones leave most engines idle (the E. coli-scale set is 3.2e5 windows:
+       ten jobs of 32768 for an 8-GPU node).  The number of windows is not known before the alignments are read, but
        it is close to template bases / (window size - overlap); floor 4096 windows (below that a job no longer fills a GPU). */
+    size_t n_distinct_devs;
+    { std::vector<int> distinct(devs); std::sort(distinct.begin(), distinct.end()); distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end()); n_distinct_devs = distinct.size(); }
     uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
     if (!a->windows_per_batch) {
         const uint64_t est_windows = tpl_bases / (a->window_size - a->window_overlap) + 1;
-        const uint64_t want = est_windows / (4ull * devs.size()) + 1;
+        const uint64_t want = est_windows / (8ull * n_distinct_devs) + 1; /* eight jobs per device: four per worker with two workers, two with four */
         if (want < per_job) per_job = (uint32_t)(want < 4096 ? 4096 : want);
     }
     cw_paf_reader* paf = nullptr;
@@ -713,8 +720,8 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         }
     }
     if (getenv("CW_DRIVER_STATS")) { /* counters on stderr; stdout stays pure FASTA */
-        fprintf(stderr, "{\"dry\": %s, \"producer_threads\": %u, \"ms_producer\": %.1f, \"workers\": %zu, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
-                dry ? "true" : "false", n_help, t_produced - t_indexed, devs.size(), (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
+        fprintf(stderr, "{\"dry\": %s, \"producer_threads\": %u, \"ms_producer\": %.1f, \"workers\": %zu, \"workers_per_device\": %zu, \"windows_per_job\": %u, \"piles\": %llu, \"windows\": %llu, \"jobs\": %llu, \"records\": %llu, \"bases_out\": %llu, \"ms_index\": %.1f, \"ms_engines\": %.1f, \"ms_paf_parse\": %.1f, \"ms_window_positions\": %.1f, \"ms_total\": %.1f, \"windows_per_s\": %.1f, \"per_device\": [",
+                dry ? "true" : "false", n_help, t_produced - t_indexed, devs.size(), devs.size() / (size_t)std::max<size_t>(1, n_distinct_devs), per_job, (unsigned long long)n_piles, (unsigned long long)n_windows, (unsigned long long)n_jobs_total, (unsigned long long)records, (unsigned long long)bases_out,
                 t_indexed - t_begin, *std::max_element(ms_init.begin(), ms_init.end()), ms_parse, ms_windows, t_end - t_begin, n_windows / ((t_end - t_indexed) * 1e-3 + 1e-9));
         for (size_t i = 0; i < workers.size(); ++i)
             fprintf(stderr, "%s{\"device\": %d, \"windows\": %llu, \"jobs\": %llu, \"ms_extract\": %.1f, \"ms_consensus\": %.1f, \"ms_stitch\": %.1f}", i ? ", " : "", workers[i].device,

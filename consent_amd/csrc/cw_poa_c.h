@@ -76,6 +76,9 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
     const cwc_g32 Cg = (cwc_g32)M.codes + lane;
     int rc0 = 3;                                     /* row i-1 (row 0, the virtual start, is all zero in this form) */
     int bs = (int)0x80000000, bi = 0;
+#ifdef CW_DIAG /* rows by kind (0, 1, 2-3, generic), in-edges and slab loads of the generic rows, rows with a flag, all rows */
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int r0 = 0; r0 < n; r0 += 64) {
         /* the row words of the next 64 rows, one per lane: a row costs a v_readlane, not an LDS round trip */
         const uint32_t meta_v = (r0 + lane < n) ? M.rmeta[r0 + lane] : 0u;
@@ -89,6 +92,14 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
         for (int rl = g; rl < ge; ++rl, sh += 4) {
             const int i = r0 + rl + 1;
             int kD, kV;
+#ifdef CW_DIAG
+            {
+                const uint32_t kd_ = CW_RM_LIN(meta) ? 0u : (meta >> 5) & 7u;
+                dg[kd_ == 0u ? 0 : kd_ == 1u ? 1 : kd_ <= 3u ? 2 : 3]++; dg[7]++;
+                if (meta & 24u) dg[6]++;
+                if (kd_ > 3u) { const int np_ = CW_RM_NP(meta); dg[4] += (uint32_t)np_; for (int q = 0; q < np_; ++q) { const int pr_ = np_ == 1 ? CW_RM_X(meta) : (int)M.plist[CW_RM_X(meta) + q]; if (pr_ != 0 && i - pr_ > CW_RING) dg[5]++; } }
+            }
+#endif
             if (CW_RM_LIN(meta)) {
                 kD = cw_wave_shr1(rc0, 0) + s_l; kV = rc0 + G4;
             } else {
@@ -160,6 +171,9 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cw_wave_sync();
+#ifdef CW_DIAG
+    if (lane == 0) { for (int k = 0; k < 7; ++k) atomicAdd(&M.diag[k], (unsigned long long)dg[k]); atomicAdd(&M.diag[10], (unsigned long long)dg[7]); if (cols <= 32) atomicAdd(&M.diag[11], (unsigned long long)dg[7]); }
+#endif
     return bi;
 }
 

@@ -32,7 +32,7 @@ def test_dry_run_counts_do_not_depend_on_the_helpers_and_match_the_oracle(tmp_pa
     b = dry_run(fa, paf, 5, j=7)
     for k in ("piles", "windows", "jobs"):
         assert a[k] == b[k], (k, a[k], b[k])
-    assert a["workers"] == 6 and b["workers"] == 14  # two workers per "device", no device touched
+    assert a["workers"] == 3 * a["workers_per_device"] and b["workers"] == 7 * b["workers_per_device"] and 1 <= a["workers_per_device"] <= 4  # no device touched
     o = oracle_lib.oracle()
     ix = ca.ReadIndex(fa)
     n_win = n_piles = 0

@@ -18,20 +18,50 @@ from consent_amd.pipeline import run_correction
 
 d = os.environ.get("CW_KEEP_DATA") or tempfile.mkdtemp()
 fa, paf, _, n_reads, n_ovl = pb.generate(d, 4600000, 30, "ont")
+
+
+def run(fa_, paf_, devices, per_job):
+    best = None
+    for rep in range(2):
+        fd = os.open(os.devnull, os.O_WRONLY)
+        st = run_correction(fa_, paf_, fd, min_support=3, max_support=150, window_size=500, mer_size=9, common_kmers=8, min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150,
+                            nb_threads=1, devices=devices, windows_per_batch=per_job)
+        os.close(fd)
+        if best is None or st.ms_total < best.ms_total:
+            best = st
+    return best
+
+
+if os.environ.get("JSM_MODE") == "parts":
+    # What ONE of N GPUs sees of this set, with the driver's own choices (workers per device, windows per job): a set of 1/N of the genome.
+    # T(N) = index of the whole set + the 1/N set's time after its index.
+    full = run(fa, paf, None, 0)
+    print(json.dumps({"set": "x1", "windows": int(full.windows), "jobs": int(full.jobs), "s_total": full.ms_total / 1e3, "s_index": full.ms_index / 1e3}), flush=True)
+    for n in (2, 4, 8):
+        dn = os.path.join(d, "part%d" % n)
+        os.makedirs(dn, exist_ok=True)
+        fa_n, paf_n, _, _, _ = pb.generate(dn, 4600000 // n, 30, "ont")
+        st = run(fa_n, paf_n, None, 0)
+        t_n = full.ms_index / 1e3 + (st.ms_total - st.ms_index) / 1e3
+        print(json.dumps({"set": "x1 / %d" % n, "windows": int(st.windows), "jobs": int(st.jobs), "s_total": st.ms_total / 1e3, "s_index": st.ms_index / 1e3,
+                          "modelled_T_N": t_n, "speed_up_over_one_gpu": full.ms_total / 1e3 / t_n}), flush=True)
+    sys.exit(0)
 rows = []
-for per_job in (32768, 20000, 10000, 5000, 4096):
+n_workers = int(os.environ.get("JSM_WORKERS", "2"))  # workers (engines) on device 0
+sizes = [int(x) for x in os.environ.get("JSM_SIZES", "32768,20000,10000,5000,4096").split(",")]
+for per_job in sizes:
     best = None
     for rep in range(2):
         fd = os.open(os.devnull, os.O_WRONLY)
         t0 = time.perf_counter()
         st = run_correction(fa, paf, fd, min_support=3, max_support=150, window_size=500, mer_size=9, common_kmers=8, min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150,
-                            nb_threads=1, devices=[0, 0], windows_per_batch=per_job)
+                            nb_threads=1, devices=[0] * n_workers, windows_per_batch=per_job)
         wall = time.perf_counter() - t0
         os.close(fd)
         if best is None or st.ms_total < best[0]:
             best = (st.ms_total, st.ms_index, int(st.windows), int(st.jobs), wall)
     ms_total, ms_index, windows, jobs, wall = best
-    rows.append({"windows_per_job": per_job, "jobs": jobs, "windows": windows, "s_total": ms_total / 1e3, "s_index": ms_index / 1e3, "windows_per_s_after_index": windows / ((ms_total - ms_index) / 1e3)})
+    rows.append({"workers": n_workers, "windows_per_job": per_job, "jobs": jobs, "windows": windows, "s_total": ms_total / 1e3, "s_index": ms_index / 1e3, "windows_per_s_after_index": windows / ((ms_total - ms_index) / 1e3)})
     print(json.dumps(rows[-1]), flush=True)
 base = rows[0]
 print("model: T(N) = s_index + windows / (N x rate(job size)) with the job size the driver picks for 2N workers (windows / (8N), floor 4096, cap 32768)")
