@@ -60,6 +60,7 @@
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_EW_BYTES(EC) (CW_CONS_HEAVIEST_BUNDLE ? 2 * (EC) : 0) /* edge weights, kept only under the heaviest-bundle policy (cw_policy.h) */
+#define CW_POA_OV (CW_POA_MODE == CW_POA_MODE_OV) /* overlap mode (cw_policy.h): column 0 is free, the end cell is the best cell of a sink row, the walk stops in column 0 */
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + CW_POA_EW_BYTES(EC) + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
@@ -259,6 +260,7 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
                 v[c] = max(v[c], max(dgv[c], upv[c]));
             }
         }
+        if (CW_POA_OV) v[0] = lane == 0 ? 0 : v[0]; /* overlap mode: the graph's prefix is free */
         int carry = CW_NEG;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -415,6 +417,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
                 v[c] = pk_max(v[c], pk_max(dgv[c], upv[c]));
             }
         }
+        if (CW_POA_OV) v[0] = lane == 0 ? (int)((unsigned)v[0] & 0xFFFF0000u) : v[0]; /* overlap mode: column 0 (lane 0's even half) is free */
         unsigned carry = 0u; /* biased (value + 32768): 0 is "nothing yet" */
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
@@ -546,7 +549,7 @@ __device__ __forceinline__ uint32_t poa_consensus_hb(const PoaMem<HT>& M, const 
 #define CW_POA_PK_SPAN 2600
 /* CM: 0 = the matrix path only; 2 = members of <= 63 bases take the recorded-decision path of cw_poa_c.h (tiers S / M1 / M2) */
 #ifndef CW_POA_CODES
-#define CW_POA_CODES 1
+#define CW_POA_CODES (CW_POA_OV ? 0 : 1) /* (the overlap mode is implemented on the matrix path) */
 #endif
 template <typename HT, int PK, int CM = 0, int LCAP = 1023> /* LCAP: the tier's longest member -- fills for wider rows are not compiled into its kernel */
 __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
@@ -672,7 +675,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
         cw_wave_sync();
         const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
-        const bool use_dirs = (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap;
+        const bool use_dirs = !CW_POA_OV && (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap; /* (overlap mode: the tile walk below only) */
         if constexpr (PK != 0) {
             if (!packed) {
                 if (cols <= 64) { if (pad) poa_fill<HT, 1, PK == 2, true>(M, n, cols, lane, use_dirs); else poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs); }
@@ -702,8 +705,23 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         if (PK == 2 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
-        int bi;
-        {
+        int bi, bj = L;
+        if (CW_POA_OV) { /* overlap mode: the best cell of a sink's row, columns 1..L; lowest rank, then lowest column on ties */
+            int bs = CW_NEG * 2, br = 0x7FFFFFFF, bc = L;
+            for (int r = lane; r < n; r += 64) {
+                if (M.has_out[M.r2n[r]]) continue;
+                for (int j = 1; j <= L; ++j) {
+                    const int h = M.H[(r + 1) * hs + j];
+                    if (h > bs) { bs = h; br = r; bc = j; } /* ranks ascend within a lane, columns within a row */
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o), oc = __shfl_xor(bc, o);
+                if (os > bs || (os == bs && orr < br)) { bs = os; br = orr; bc = oc; }
+            }
+            bi = __builtin_amdgcn_readfirstlane(br) + 1;
+            bj = __builtin_amdgcn_readfirstlane(bc);
+        } else {
             int bs = CW_NEG * 2, br = 0x7FFFFFFF;
             for (int r = lane; r < n; r += 64) {
                 if (M.has_out[M.r2n[r]]) continue;
@@ -719,7 +737,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 
         /* ---- traceback (wave-uniform); records seqrank[j] = rank aligned to sequence position j ---- */
         {
-            int i = bi, j = L;
+            int i = bi, j = bj;
             if (use_dirs && M.runs) {
                 /* Direction words: every lane looks at the cell it would reach if the path kept going the way it starts
                    (diagonal: (i-t, j-t); vertical: (i-t, j); horizontal: (i, j-t)) along a linear stretch of the graph
@@ -820,7 +838,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     /* 0 diagonal, 1 vertical, 2 horizontal; 3 several predecessors, 4 no move explains the cell, 5 neighbours outside
                        the tile, 6 the virtual start row */
                     /* (selects, not branches: as an if-chain this was six nested execution-mask regions per tile) */
-                    const bool c_start = row <= 0, c_edge = tr == 7 || (tc == 7 && col > 0);
+                    const bool c_start = row <= 0 || (CW_POA_OV && col <= 0), c_edge = tr == 7 || (tc == 7 && col > 0); /* (overlap mode: the walk stops in column 0) */
                     const bool c_d = col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS);
                     const bool c_m = CW_RM_NP((uint32_t)meta_r) != 1, c_v = hv == bv + G, c_h = col > 0 && hv == lv + G;
                     const int code = c_start ? 6 : c_edge ? 5 : c_d ? 0 : c_m ? 3 : c_v ? 1 : c_h ? 2 : 4;

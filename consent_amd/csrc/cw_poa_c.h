@@ -70,7 +70,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
     const int NEGD = -(1 << 24);
     const int L = cols - 1;
     const int sq = (lane > 0 && lane < cols) ? (int)M.sq[lane - 1] : -1;
-    const int ms_l = lane == 0 ? NEGD : MS4, xs_l = lane == 0 ? NEGD : XS4; /* column 0 has no diagonal */
+    const int xs_l = lane == 0 ? NEGD : XS4; /* column 0 has no diagonal */
     const cwc_l16 rowst = (cwc_l16)M.ring + lane;    /* this lane's column of the row ring */
     const cwc_g16 Hg = (cwc_g16)M.H + lane;          /* flagged rows in the slab, stride 64 */
     const cwc_g32 Cg = (cwc_g32)M.codes + lane;
@@ -79,17 +79,45 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
 #ifdef CW_DIAG /* rows by kind (0, 1, 2-3, generic), in-edges and slab loads of the generic rows, rows with a flag, all rows */
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    /* the substitution score of a row without a compare and a select (and the two wait states between them): bit b + 4k of a lane's word says
+       "my base is b", so bit (row word & 31) is the answer whatever the flag bits above the base are */
+    const uint32_t onehot8 = sq >= 0 ? 0x11111111u << sq : 0u;
+#define CWC_SCORE(m) ((int)(__builtin_amdgcn_ubfe(onehot8, (m), 1u) * (uint32_t)(MS4 - XS4)) + xs_l)
+#define CWC_FLUSH(last_row) do { cwc_gstore_b32(Cg + ((last_row) >> 3) * 64, acc); acc = 0u; sh = 0; } while (0)
+    uint32_t acc = 0u; /* the code word of the current group of eight rows */
+    int sh = 0;
     for (int r0 = 0; r0 < n; r0 += 64) {
         /* the row words of the next 64 rows, one per lane: a row costs a v_readlane, not an LDS round trip */
         const uint32_t meta_v = (r0 + lane < n) ? M.rmeta[r0 + lane] : 0u;
         const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - r0));
+        /* plain rows: one in-edge from the row before, no flag -- nearly half of all rows; runs of them go through a loop of their own */
+        unsigned long long plain = __ballot((meta_v & 0x1Cu) == 0x04u);
         uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, 0);
-        int s_l = (sq == (int)(meta & 3u)) ? ms_l : xs_l;
-        for (int g = 0; g < cnt; g += 8) { /* eight rows to a code word */
-        uint32_t acc = 0u;
-        const int ge = min(g + 8, cnt);
-        int sh = 0;
-        for (int rl = g; rl < ge; ++rl, sh += 4) {
+        int s_l = CWC_SCORE(meta);
+        int rl = 0;
+        while (rl < cnt) {
+            if (plain & 1ull) {
+                do {
+                    const int i = r0 + rl + 1;
+                    const int kD = cw_wave_shr1(rc0, 0) + s_l, kV = rc0 + G4;
+                    const int v = max(kD, kV);
+                    ++rl; plain >>= 1;
+                    meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl);
+                    s_l = CWC_SCORE(meta);
+                    const int nv = cw_wave_scan_max(v) | 3;
+                    /* in-edge 0 throughout, the candidates carry the cell's low bits: 0 if the diagonal candidate is the cell, else 4 if the vertical one is, else 8
+                       (differences, not compares: no condition register between them, no wait states) */
+                    acc |= min(min((uint32_t)(nv - kD) << 1, (uint32_t)(nv - kV) + 4u), 8u) << sh;
+                    rowst[(i & (CW_RING - 1)) * 64] = (int16_t)nv;
+                    rc0 = nv;
+                    sh += 4;
+                    if (sh == 32) CWC_FLUSH(i - 1);
+#ifdef CW_DIAG
+                    dg[0]++; dg[7]++;
+#endif
+                } while (plain & 1ull); /* (rows beyond the graph have no row word: their bits are clear) */
+                continue;
+            }
             const int i = r0 + rl + 1;
             int kD, kV;
 #ifdef CW_DIAG
@@ -135,9 +163,11 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
                 }
             }
             const int v = max(kD, kV);
+            const uint32_t meta_c = meta;
             /* the next row's word and match scores: independent of the scan, they fill the wait states between its DPP steps */
-            const uint32_t meta_n = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl + 1); /* (lane 64 = lane 0: not used) */
-            const int s_l_n = (sq == (int)(meta_n & 3u)) ? ms_l : xs_l;
+            ++rl; plain >>= 1;
+            meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl); /* (lane 64 = lane 0: not used) */
+            s_l = CWC_SCORE(meta);
 #if defined(CW_EXP_SALU) || defined(CW_EXP_VALU) /* experiment (tools/exp_issue.sh): what one more scalar / vector instruction per row costs */
             {
                 int xs_ = rl, xv_ = lane;
@@ -157,18 +187,21 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
             const uint32_t t = (uint32_t)(kD ^ nv), u4 = __builtin_elementwise_add_sat((uint32_t)(kV ^ nv), 4u); /* saturating: candidate and cell may differ in sign */
             acc |= min(min(t < 4u ? t : 8u, u4), 8u) << sh;
             rowst[(i & (CW_RING - 1)) * 64] = (int16_t)nv;
-            if (meta & 24u) { /* rarely: a sink (the end cell is the best of them), a row some later row or the traceback reads from the slab */
-                if (meta & 16u) cwc_gstore_b16(Hg + i * 64, nv);
-                if (CW_RM_SINK(meta)) {
+            if (meta_c & 24u) { /* a sink (the end cell is the best of them), a row some later row or the traceback reads from the slab */
+                if (meta_c & 16u) cwc_gstore_b16(Hg + i * 64, nv);
+                if (CW_RM_SINK(meta_c)) {
                     const int h = __builtin_amdgcn_readlane(nv, L);
                     if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
                 }
             }
-            rc0 = nv; meta = meta_n; s_l = s_l_n;
-        }
-        cwc_gstore_b32(Cg + ((r0 + g) >> 3) * 64, acc);
+            rc0 = nv;
+            sh += 4;
+            if (sh == 32) CWC_FLUSH(i - 1);
         }
     }
+    if (sh) CWC_FLUSH(n - 1);
+#undef CWC_SCORE
+#undef CWC_FLUSH
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cw_wave_sync();
 #ifdef CW_DIAG

@@ -54,7 +54,11 @@
 /* default).  A value that is named here but not implemented stops the build on both sides.          */
 #define CW_POA_MODE_NW 0 /* global alignment of the segment against the graph (implemented)          */
 #define CW_POA_MODE_SW 1 /* local                                                                     */
-#define CW_POA_MODE_OV 2 /* semi-global / overlap                                                     */
+#define CW_POA_MODE_OV 2 /* semi-global / overlap, as spoa's kOV is published: first row gap-penalised, first column free, the alignment
+                            ends in the best cell (columns 1..L, lowest rank then lowest column on ties) of a node without out-edges and stops where
+                            it reaches the first row or column; the bases beyond the end cell and before the stop are insertions.  Implemented on both
+                            sides since round 4; the engine then aligns on the matrix path of tiers S..G (no tier Q, no recorded decisions:
+                            slower, meant as insurance -- see DESIGN.md section 2) */
 #ifndef CW_POA_MODE
 #define CW_POA_MODE CW_POA_MODE_NW
 #endif
@@ -88,7 +92,7 @@
 #ifndef CW_SEG_MISSING_ANCHOR
 #define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
 #endif
-#if CW_POA_MODE != CW_POA_MODE_NW || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
+#if (CW_POA_MODE != CW_POA_MODE_NW && CW_POA_MODE != CW_POA_MODE_OV) || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
     CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
 #error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
 #endif

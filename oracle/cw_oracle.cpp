@@ -177,6 +177,9 @@ struct PoaGraph {
                     const __m256i up = _mm256_loadu_si256((const __m256i*)(pr + j)), dg = _mm256_loadu_si256((const __m256i*)(pr + j - 1));
                     acc = _mm256_max_epi32(acc, _mm256_max_epi32(_mm256_add_epi32(dg, s8), _mm256_add_epi32(up, vg)));
                 }
+#if CW_POA_MODE == CW_POA_MODE_OV
+                if (j == 0) acc = _mm256_blend_epi32(acc, _mm256_setzero_si256(), 0x01); /* overlap mode: column 0 costs nothing */
+#endif
                 __m256i t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh1), vneg, 0x01); acc = _mm256_max_epi32(acc, t);
                 t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh2), vneg, 0x03); acc = _mm256_max_epi32(acc, t);
                 t = _mm256_blend_epi32(_mm256_permutevar8x32_epi32(acc, sh4), vneg, 0x0F); acc = _mm256_max_epi32(acc, t);
@@ -197,7 +200,7 @@ struct PoaGraph {
             const PoaNode& nd = nodes[rank2node[i - 1]];
             int32_t best = nd.in_edges.empty() ? 0 : INT_MIN;
             for (size_t p = 0; p < nd.in_edges.size(); ++p) best = std::max(best, at(pred_row(nd, p), 0));
-            at(i, 0) = best + g;
+            at(i, 0) = CW_POA_MODE == CW_POA_MODE_OV ? 0 : best + g; /* overlap mode: the graph's prefix is free */
         }
         for (int i = 1; i <= n; ++i) {
             const PoaNode& nd = nodes[rank2node[i - 1]];
@@ -215,14 +218,25 @@ struct PoaGraph {
 #endif
         if (st) { st->dp_cells += (uint64_t)n * L; st->alignments++; }
 
-        int bi = -1;
+        int bi = -1, bj = L;
         int32_t bs = INT_MIN;
+#if CW_POA_MODE == CW_POA_MODE_OV
+        /* overlap mode (spoa kOV as published: first row gap-penalised, first column free, the alignment ends in the best cell of a node
+           without out-edges, columns 1..L, and stops where it reaches the first row or the first column): lowest rank, then lowest column on ties.
+           The sequence's bases beyond the end cell and before the stop are on no graph node: insertions, as in the global mode's first row. */
+        for (int i = 1; i <= n; ++i) {
+            if (!nodes[rank2node[i - 1]].out_edges.empty()) continue;
+            for (int j = 1; j <= L; ++j) if (bi == -1 || bs < at(i, j)) { bs = at(i, j); bi = i; bj = j; }
+        }
+        for (int j = L; j > bj; --j) path.emplace_back(-1, j - 1);
+#else
         for (int i = 1; i <= n; ++i) {
             if (!nodes[rank2node[i - 1]].out_edges.empty()) continue;
             if (bi == -1 || bs < at(i, L)) { bs = at(i, L); bi = i; }
         }
-        int i = bi, j = L;
-        while (!(i == 0 && j == 0)) {
+#endif
+        int i = bi, j = bj;
+        while (CW_POA_MODE == CW_POA_MODE_OV ? (i != 0 && j != 0) : !(i == 0 && j == 0)) {
             const int32_t h = at(i, j);
             int pi = i, pj = j;
             bool found = false;
@@ -250,6 +264,9 @@ struct PoaGraph {
             path.emplace_back(i == pi ? -1 : rank2node[i - 1], j == pj ? -1 : j - 1);
             i = pi; j = pj;
         }
+#if CW_POA_MODE == CW_POA_MODE_OV
+        for (; j > 0; --j) path.emplace_back(-1, j - 1); /* stopped in the first row: the bases before are insertions */
+#endif
         std::reverse(path.begin(), path.end());
         return path;
     }

@@ -74,3 +74,23 @@ def test_heaviest_bundle_consensus_is_implemented_on_both_sides(tmp_path):
     same_hb, digest_hb = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
     assert same_default and same_hb
     assert digest_default != digest_hb
+
+
+@pytest.mark.timeout(1500)
+def test_overlap_alignment_mode_is_implemented_on_both_sides(tmp_path):
+    """-DCW_POA_MODE=2 (cw_policy.h CW_POA_MODE_OV, round 4): column 0 of the DP free, the alignment ends in the best cell of a sink's row and
+    stops in the first row or column, the bases outside it become insertions -- in the oracle (scalar and AVX2 fills) and on the engine's
+    matrix path (tiers S..G; tier Q and the recorded-decision path are not used by that build).  The two sides agree window by window
+    under that mode, and the consensus is not the global mode's."""
+    from consent_amd import _build
+
+    ov = ["-DCW_POA_MODE=2"]
+    alt_lib = str(tmp_path / "libconsent_amd_ov.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *ov, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(ov)])
+    same_default, digest_default = run_child({})
+    same_ov, digest_ov = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_ov
+    assert digest_default != digest_ov
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed

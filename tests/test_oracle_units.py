@@ -164,4 +164,11 @@ print("DIGEST", h.hexdigest())
         assert out.returncode == 0, out.stderr[-1500:]
         return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1]
 
-    assert run({}) == run({"CW_ORACLE_LIB": str(tmp_path / "liboracle_simd.so")})
+    d_default = run({})
+    assert d_default == run({"CW_ORACLE_LIB": str(tmp_path / "liboracle_simd.so")})
+    # the overlap alignment mode (cw_policy.h CW_POA_MODE_OV) in both fills: same function again, and not the global mode's
+    ov, ovs = tmp_path / "ov", tmp_path / "ovs"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "policy", f"OUT={ov}", "POLICY=-DCW_POA_MODE=2"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "policy", f"OUT={ovs}", "POLICY=-DCW_POA_MODE=2 -mavx2 -DCWO_SIMD -DCWO_FAST"])
+    d_ov = run({"CW_ORACLE_LIB": str(ov / "liboracle.so")})
+    assert d_ov == run({"CW_ORACLE_LIB": str(ovs / "liboracle.so")}) and d_ov != d_default
