@@ -122,7 +122,7 @@ struct PoaMem {
     uint32_t* codes;    /* cw_poa_c.h: the traceback's decisions, four bits per cell (LDS in tier S, the wave's slab in tiers M1 / M2), c_cap words */
     int16_t* ring;      /* cw_poa_c.h: the last CW_RING rows of the fill (LDS; tiers M1 / M2) */
     uint32_t* gflag;    /* cw_poa_c.h: one bit per rank: the row is also written to the slab (a later row needs it from more than CW_RING ranks back,
-                           or it belongs to a node with more than three in-edges); NULL where every row is kept anyway */
+                           or it belongs to a node with more than three in-edges, or it is the fourth or a later predecessor of such a node); NULL where every row is kept anyway */
     uint32_t c_cap;
 #ifdef CW_DIAG
     unsigned long long* diag; /* diagnostic build: ten counters of this tier in BatchCounters::prof (rows / linear rows / far loads / predecessor trips of the
@@ -620,7 +620,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                         if (q == off) first = pr;
                         M.plist[q++] = (uint16_t)pr;
                         far_ = far_ || r + 1 - pr > CW_RING;
-                        if (CM == 2 && M.gflag && (r + 1 - pr > CW_RING || d > 3))
+                        if (CM == 2 && M.gflag && (r + 1 - pr > CW_RING || q - off > 3)) /* (the fourth in-edge and later: the traceback compares their cells, cw_poa_c.h) */
                             __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                     if (CM == 2 && M.gflag && d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

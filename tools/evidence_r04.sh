@@ -28,6 +28,7 @@ export CW_KEEP_DATA=/tmp/cw_drv_data
 python bench.py --mode driver --gpus 1 --driver-copies 1 > $EV/driver_r04_x1.json 2> $EV/driver_x1.err
 python bench.py --mode driver --gpus 1 --driver-copies 8 > $EV/driver_r04_x8.json 2> $EV/driver_x8.err
 python tools/job_size_model.py > $EV/r04_job_size_model.txt 2>&1
+JSM_MODE=parts python tools/job_size_model.py > $EV/r04_job_size_parts.txt 2>/dev/null
 unset CW_KEEP_DATA
 bash tools/profile_pipeline.sh r04 > $EV/pipeline.log 2>&1
 python - <<'PY' > $EV/r04_pipeline.txt 2>&1
@@ -44,7 +45,9 @@ PY
 rm -rf gpurun_out/prof_r04_pipeline
 python tools/fuzz_parity.py $FZ 20260930 > $EV/fuzz_parity.txt 2>&1
 python tools/fuzz_pipeline.py $FZ 20260930 > $EV/fuzz_pipeline.txt 2>&1
-tail -2 $EV/verify.txt; tail -1 $EV/fuzz_parity.txt; tail -2 $EV/fuzz_pipeline.txt
+bash tools/fuzz_policy.sh "-DCW_POA_MODE=2" $((FZ / 2)) > $EV/fuzz_policy_ov.txt 2>&1
+bash tools/fuzz_policy.sh "-DCW_POA_CONSENSUS=1" $((FZ / 2)) > $EV/fuzz_policy_hb.txt 2>&1
+tail -2 $EV/verify.txt; tail -1 $EV/fuzz_parity.txt; tail -2 $EV/fuzz_pipeline.txt; tail -1 $EV/fuzz_policy_ov.txt; tail -1 $EV/fuzz_policy_hb.txt
 python -c "
 import json
 for f in ('bench_r04_pacbio_d150_msa150','bench_r04_pacbio_d30_msa20','bench_r04_pacbio_d150_msa150_one_engine','driver_r04_x1','driver_r04_x8'):
