@@ -31,6 +31,13 @@ typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or wher
 #define CW_EXP_SLOTS 12 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
+#ifndef CW_IDX_BYTES
+#define CW_IDX_BYTES 1 /* phase A counts in byte counters first (two halves of the key space for k = 9); 0 = the nibble table only */
+#endif
+#ifndef CW_IDX_BYTES_MIN_N
+#define CW_IDX_BYTES_MIN_N 64u /* k = 9: from this many sequences on (below, few keys pass fifteen occurrences and the nibble table's single pass wins:
+                                  depth 30 measured 3.11 ms against 3.32 ms per batch; depth 150: 10.9 against 9.7) */
+#endif
 /* the window's pile staged in LDS (behind the phase A tables, in front of nothing: the position matrix stops short of it): sequence
    lengths, word offsets and the 2-bit words themselves, so that the four passes over the pile's k-mers read LDS instead of walking
    seq_len -> seq_word_off -> bases in global memory (three dependent round trips per sequence and pass, with all 16 waves waiting
@@ -430,6 +437,92 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         /* keys that occur 16 times or more: at most n_kmers / 16 of them.  The LDS table holds every pile of read correction (<= 151
            sequences) in practice; the piles of assembly polishing are as deep as the coverage (maxSupport = 20000, CONSENT-polish:43):
            when the LDS table overflows the count pass is redone with this work-group's table in global memory */
+        /* Round 4: byte counters first.  At read-correction depths no key comes near 255 occurrences (a true k-mer of a depth-150 pile is seen
+           ~50 times), so a counter per key that is one byte wide needs neither the compare-and-swap loop of the nibbles (a read, a CAS and
+           its retries per k-mer) nor the list of the occurrences beyond the fifteenth and its second phase (a quarter of a deep pile's
+           k-mers): one returning add per k-mer.  4^9 bytes are twice the table, so k = 9 counts and exports the lower half of the key space,
+           then the upper half (the pile's k-mers are extracted twice: cheap next to the atomics of a deep pile, not of a shallow one:
+           CW_IDX_BYTES_MIN_N).  A counter that reaches 200 -- low
+           complexity, polishing depths -- sends the window to the nibble path below, which has no such limit. */
+        bool done8 = false;
+        const uint32_t bkeys = n_keys < 131072u ? n_keys : 131072u, bwords = bkeys >> 2, BNI = bwords >> 12;
+        if (CW_IDX_BYTES && N <= 200u && (n_keys <= 131072u || N >= CW_IDX_BYTES_MIN_N) && prm.solid >= 1u && prm.solid <= 127u && (bwords & 4095u) == 0u && BNI >= 1u && BNI <= 8u) {
+            const uint32_t n_half = n_keys / bkeys; /* 1 (k <= 8) or 2 (k = 9) */
+            uint32_t written = 0;
+            bool ok8 = true, fits8 = true;
+            if (tid < 8) flags[tid] = 0;
+            for (uint32_t h = 0; h < n_half; ++h) {
+                for (uint32_t i = tid; i < bwords; i += CW_IDX_THREADS) tab[i] = 0;
+                __syncthreads();
+                if (h == 0) CW_PROF(sc.ctr, 55, tid == 0);
+                CW_IDX_PASS_BLOCKR({
+                    if (n_half > 1u && (key >> 17) != h) continue;
+                    const uint32_t kk = key & (bkeys - 1u), sh8 = (kk & 3u) * 8u;
+                    const uint32_t old = atomicAdd(&tab[kk >> 2], 1u << sh8);
+                    if (((old >> sh8) & 255u) >= 200u) flags[0] = 1; /* (a byte cannot carry into its neighbour unseen: the add that takes it from 255 to 0 returns 255) */
+                })
+                __syncthreads();
+                CW_PROF(sc.ctr, 0, tid == 0);
+                if (flags[0]) { ok8 = false; break; }
+                /* export of this half, as the nibble table's fast export below: wave v owns a sixteenth of the table and reads it lane-interleaved,
+                   four words (sixteen keys) per lane and read; key order = (read, lane, bit) */
+                const uint32_t qbase = (uint32_t)wave * (BNI * 64u) + (uint32_t)lane;
+                const uint32_t addt = (128u - prm.solid) * 0x01010101u;
+                auto cmask8 = [&](const uint32_t v) -> uint32_t { /* bit q = byte q of v is >= the threshold */
+                    const uint32_t c = (((v & 0x7F7F7F7Fu) + addt) | v) & 0x80808080u;
+                    return ((c >> 7) | (c >> 14) | (c >> 21) | (c >> 28)) & 0xFu;
+                };
+                uint32_t m[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    m[i] = 0u;
+                    if ((uint32_t)i < BNI) {
+                        const uint4 v4 = *(const uint4*)&tab[(qbase + (uint32_t)i * 64u) * 4u];
+                        m[i] = cmask8(v4.x) | (cmask8(v4.y) << 4) | (cmask8(v4.z) << 8) | (cmask8(v4.w) << 12);
+                    }
+                }
+                CW_PROF(sc.ctr, 56, tid == 0);
+                uint32_t offs[8], wtot = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t c = (uint32_t)__popc(m[i]);
+                    const uint32_t inc = (uint32_t)cw_wave_scan_add((int)c);
+                    offs[i] = wtot + inc - c;
+                    wtot += (uint32_t)cw_lane_value((int)inc, 63);
+                }
+                uint32_t total;
+                uint32_t woff = cw_block_exscan(lane == 0 ? wtot : 0u, scan_tmp, &total);
+                woff = (uint32_t)cw_lane_value((int)woff, 0);
+                fits8 = written + total <= w_solid_cap;
+                if (!fits8) break;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint32_t mm = m[i], o = w_solid_base + written + woff + offs[i];
+                    const uint32_t wd0 = (qbase + (uint32_t)i * 64u) * 4u;
+                    while (mm) {
+                        const uint32_t bpos = (uint32_t)__ffs((int)mm) - 1u;
+                        mm &= mm - 1u;
+                        const uint32_t wd = wd0 + (bpos >> 2);
+                        sc.solid_key[o] = h * 131072u + wd * 4u + (bpos & 3u);
+                        sc.solid_cnt[o] = (tab[wd] >> (8u * (bpos & 3u))) & 255u;
+                        ++o;
+                    }
+                }
+                written += total;
+                __syncthreads(); /* the table is cleared for the next half */
+            }
+            if (ok8) {
+                if (tid == 0) {
+                    wi->n_solid = fits8 ? written : 0;
+                    if (!fits8) { wi->status = CW_WIN_OVERFLOW; wi->pad_ = CW_WHY_SOLIDCAP; sc.ctr->any_overflow = 1; }
+                }
+                __syncthreads();
+                if (!fits8) continue;
+                done8 = true;
+            }
+            __syncthreads(); /* (fallback: everybody has read the flag before the nibble path clears it) */
+        }
+        if (!done8) {
         bool big_ex = false; /* the LDS table overflowed and the pass was redone with the table in global memory */
         unsigned long long* const exg = sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS;
         /* 4-bit counters in the direct table; occurrences beyond the 15th of a key are counted in a small hash table (key + 1 in the
@@ -699,6 +792,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         }
 
+        } /* the nibble path */
         } /* direct table */
 
         CW_PROF(sc.ctr, 2, tid == 0);
