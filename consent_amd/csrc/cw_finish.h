@@ -17,7 +17,9 @@
 
 #define CW_FIN_WAVES 4
 #define CW_FIN_CB 3072        /* string capacity per buffer              */
+#ifndef CW_FIN_VIS_WORDS
 #define CW_FIN_VIS_WORDS 1024 /* visited bitmap in LDS: up to 32768 solid k-mers */
+#endif
 #define CW_FIN_VIS_GLB_WORDS 8192 /* per-wave bitmap in global memory beyond that: 4^9 keys, the most a direct count table can export */
 #define CW_FIN_FRAMES 56
 #define CW_FIN_SKEYS 1024     /* solid keys staged in LDS (every lookup of the polish is a binary search in them) */
