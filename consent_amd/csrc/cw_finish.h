@@ -23,6 +23,10 @@
 #define CW_FIN_VIS_GLB_WORDS 8192 /* per-wave bitmap in global memory beyond that: 4^9 keys, the most a direct count table can export */
 #define CW_FIN_FRAMES 56
 #define CW_FIN_SKEYS 1024     /* solid keys staged in LDS (every lookup of the polish is a binary search in them) */
+/* 20.4 KB per wave, 81.5 KB per work-group: exactly two work-groups per CU (162.9 of 163.8 KB) -- and the kernel is latency-bound: staging 3072
+   solid keys instead of 1024 (a depth-150 pile has ~2500, so its lookups are binary searches in global memory; round 4 tried) makes the
+   work-group 124 KB, one per CU, and the kernel 1.75x as long at depth 30 and 1.15x at depth 150; a third work-group per CU (smaller buffers) changed nothing */
+#define CW_FIN_K16_MAX ((CW_FIN_VIS_WORDS + CW_FIN_SKEYS) * 32 / 17 / 64 * 64) /* compact table: n / 32 bitmap words + n / 2 words of 16-bit keys in the bitmap's and the key table's space (3840) */
 #define CW_FIN_SLAB (3 * CW_FIN_CB + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256 + 4 * CW_FIN_SKEYS + 16)
 
 struct FinOut {
@@ -40,6 +44,8 @@ struct FinCtx {
     const uint32_t* scnt;
     const uint16_t* scnt16; /* counts staged in LDS (all <= 65535), or NULL */
     bool staged;            /* skey points into LDS and holds at most CW_FIN_SKEYS keys */
+    const uint16_t* k16;    /* or (round 4): more keys than that, k <= 9: their low 16 bits staged in LDS (fin_find), or NULL ... */
+    uint32_t b16[3];        /* ... and where the keys with bits 17:16 = 1, 2, 3 begin */
     uint32_t n_solid;
     uint32_t k, solid, kmask;
     /* pile, for exact recounts */
@@ -69,6 +75,19 @@ __device__ __forceinline__ uint32_t fin_key_at(const uint8_t* s, uint32_t p, uin
 
 /* index of key in the solid table or -1 (per-lane, global memory binary search) */
 __device__ __forceinline__ int fin_find(const FinCtx& c, uint32_t key) {
+    if (c.k16) { /* the compact table: the two high bits pick the range, the search compares 16-bit halves at LDS latency */
+        const uint32_t h = key >> 16, kl = key & 0xFFFFu;
+        int lo = h == 0u ? 0 : h == 1u ? (int)c.b16[0] : h == 2u ? (int)c.b16[1] : (int)c.b16[2];
+        int hi = (h == 0u ? (int)c.b16[0] : h == 1u ? (int)c.b16[1] : h == 2u ? (int)c.b16[2] : (int)c.n_solid) - 1;
+        if (h > 3u) return -1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = (uint32_t)((fin_l16)c.k16)[mid];
+            if (v == kl) return mid;
+            if (v < kl) lo = mid + 1; else hi = mid - 1;
+        }
+        return -1;
+    }
     int lo = 0, hi = (int)c.n_solid - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -445,13 +464,13 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
     M.path = slab + 2 * CW_FIN_CB;
     uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CW_FIN_CB);
     M.vis = vis_lds; M.vis_glb = false;
-    M.f_nbk = vis_lds + CW_FIN_VIS_WORDS;
+    uint32_t* skey_lds = vis_lds + CW_FIN_VIS_WORDS; /* CW_FIN_SKEYS + 4 words, right behind the bitmap: the compact table runs through both */
+    M.f_nbk = skey_lds + CW_FIN_SKEYS + 4;
     M.f_nbi = M.f_nbk + CW_FIN_FRAMES * 4;
     M.f_meta = M.f_nbi + CW_FIN_FRAMES * 4;
     M.f_dist = M.f_meta + CW_FIN_FRAMES;
     M.f_key = M.f_dist + CW_FIN_FRAMES;
     M.tmp = M.f_key + CW_FIN_FRAMES; /* 64 words */
-    uint32_t* skey_lds = M.tmp + 64; /* CW_FIN_SKEYS words */
 
     for (;;) {
         uint32_t w = 0;
@@ -504,7 +523,23 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                 if ((uint32_t)len >= prm.k) { /* correctionMSA.cpp:43-46 */
                     FinCtx c;
                     c.skey = sc.solid_key + wi.solid_base; c.scnt = sc.solid_cnt + wi.solid_base; c.n_solid = wi.n_solid;
-                    c.scnt16 = nullptr; c.staged = false;
+                    c.scnt16 = nullptr; c.staged = false; c.k16 = nullptr;
+                    if (wi.n_solid > CW_FIN_SKEYS && wi.n_solid <= CW_FIN_K16_MAX && prm.k <= 9u && !vis_glb) {
+                        /* a deep pile (depth 150: ~2500 solid k-mers): the keys do not fit as words -- and every lookup of the polish was a
+                           twelve-step binary search in global memory.  Their low halves fit behind the bitmap words this many k-mers need. */
+                        uint16_t* k16 = (uint16_t*)(vis_lds + CW_FIN_K16_MAX / 32);
+                        uint32_t n1 = 0, n2 = 0, n3 = 0;
+#pragma unroll 4
+                        for (uint32_t q = lane; q < wi.n_solid; q += 64) {
+                            const uint32_t key = ((fin_g32)c.skey)[q];
+                            k16[q] = (uint16_t)key;
+                            const uint32_t h = key >> 16;
+                            n1 += h < 1u ? 1u : 0u; n2 += h < 2u ? 1u : 0u; n3 += h < 3u ? 1u : 0u;
+                        }
+                        c.b16[0] = (uint32_t)cw_wave_sum((int)n1); c.b16[1] = (uint32_t)cw_wave_sum((int)n2); c.b16[2] = (uint32_t)cw_wave_sum((int)n3);
+                        c.k16 = k16;
+                        cw_wave_sync();
+                    }
                     if (wi.n_solid <= CW_FIN_SKEYS) { /* the usual case: searches run at LDS latency */
                         /* the visited bitmap needs 32 words for that many k-mers: the counts go behind it, as u16 when they all fit */
                         uint16_t* cnt_lds = (uint16_t*)(vis_lds + 64);
