@@ -357,6 +357,15 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
                     cs[q] = iq >= 0 ? fin_scnt(c, (uint32_t)iq) : fin_count_scan(c, ks[q], lane);
                     cd[q] = jq >= 0 ? fin_scnt(c, (uint32_t)jq) : fin_count_scan(c, kd[q], lane);
                 }
+            } else if (c.k16) { /* the compact table: lanes 0..7 search one k-mer each, their counts come back in one round trip */
+                const uint32_t kq = lane == 0 ? ks[0] : lane == 1 ? ks[1] : lane == 2 ? ks[2] : lane == 3 ? ks[3] : lane == 4 ? kd[0] : lane == 5 ? kd[1] : lane == 6 ? kd[2] : kd[3];
+                const int iq = lane < 8 ? fin_find(c, kq) : -1;
+                const uint32_t cq = iq >= 0 ? fin_scnt(c, (uint32_t)iq) : 0u;
+                for (int q = 0; q < 4; ++q) {
+                    const int is = __builtin_amdgcn_readlane(iq, q), id = __builtin_amdgcn_readlane(iq, 4 + q);
+                    cs[q] = is >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cq, q) : fin_count_scan(c, ks[q], lane);
+                    cd[q] = id >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cq, 4 + q) : fin_count_scan(c, kd[q], lane);
+                }
             } else {
                 for (int q = 0; q < 4; ++q) { cs[q] = fin_count_exact(c, ks[q], lane); cd[q] = fin_count_exact(c, kd[q], lane); }
             }
