@@ -560,7 +560,7 @@ def main():
             dn = ("rows<=64", "linear", "far>RC", "preds(nonlinear)", "rows_packed", "linear_pk", "far_pk", "tb_trips", "tb_slow", "tb_members", "far>16", "far_pk>16")
             for i, t in enumerate(("S", "M1", "M2", "L")):
                 print(f"diag tier {t}:", {n: int(prof[72 + 12 * i + k]) for k, n in enumerate(dn)}, file=sys.stderr)
-            dc = ("kind 0 (linear)", "kind 1", "kinds 2-3", "generic", "in-edges of generic rows", "slab loads of generic rows", "rows with a flag", "tb_trips", "tb_slow", "tb_members", "rows", "rows of members <= 31 bases")
+            dc = ("kind 0 (linear)", "kind 1", "kinds 2-3", "generic", "in-edges of generic rows", "slab loads of generic rows", "rows with a flag", "tb_trips", "members with code words in LDS", "members", "rows", "rows of members <= 31 bases")
             for i, t in enumerate(("S", "M1")):  # the recorded-decision fill (cw_poa_c.h) counts by row kind
                 print(f"diag tier {t}, coded fill:", {n: int(prof[72 + 12 * i + k]) for k, n in enumerate(dc)}, file=sys.stderr)
     if rank == 0:

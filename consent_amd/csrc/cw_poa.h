@@ -75,7 +75,13 @@
 #ifndef CW_S_EDGES_LDS
 #define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */
 #endif
-#define CW_POA_SLAB_BYTES (CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + (CW_S_EDGES_LDS ? 4 * CW_POA_EC + CW_POA_EW_BYTES(CW_POA_EC) + 2 * CW_POA_NC : 0)) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
+#ifndef CW_S_LCODES_WORDS
+#define CW_S_LCODES_WORDS 0 /* tier S: code words of an alignment in LDS when groups of eight rows x columns + 64 fit this many words (cw_poa_c.h), so that the
+                               traceback's tile trips wait for LDS, not for the L2.  Measured with 384 words (93 % of tier S's members fit): traceback -11 %
+                               wave-cycles, tier S's kernel 34.5 -> 33.2 ms -- and the step +1.4 ms, because the 1.5 KB per wave are LDS the other tiers'
+                               work-groups no longer get.  Off. */
+#endif
+#define CW_POA_SLAB_BYTES (CW_POA_HOT2C_BYTES(CW_POA_NC, CW_POA_EC, CW_POA_LC) + (CW_S_EDGES_LDS ? 4 * CW_POA_EC + CW_POA_EW_BYTES(CW_POA_EC) + 2 * CW_POA_NC : 0) + 4 * CW_S_LCODES_WORDS) /* tier S, LDS per wave (round 4: laid out like M1 / M2) */
 #define CW_POA_HSLAB_BYTES(NC, LC) ((((NC) + 1) * ((LC) + 1) * 2 + 255) / 256 * 256)
 #define CW_POA_DSLAB_PAIRS(NC, LC) ((NC) * (((LC) + 64) / 64))
 #define CW_POA_DSLAB_BYTES(NC, LC) ((CW_POA_DSLAB_PAIRS(NC, LC) * 16 + 255) / 256 * 256)
@@ -124,6 +130,8 @@ struct PoaMem {
     uint32_t* gflag;    /* cw_poa_c.h: one bit per rank: the row is also written to the slab (a later row needs it from more than CW_RING ranks back,
                            or it belongs to a node with more than three in-edges, or it is the fourth or a later predecessor of such a node); NULL where every row is kept anyway */
     uint32_t c_cap;
+    uint32_t* lcodes;   /* cw_poa_c.h, tier S: room in LDS for the code words of a small alignment (lc_cap words), or NULL */
+    uint32_t lc_cap;
 #ifdef CW_DIAG
     unsigned long long* diag; /* diagnostic build: ten counters of this tier in BatchCounters::prof (rows / linear rows / far loads / predecessor trips of the
                                  unpacked fill, rows / linear / far loads of the packed fill, traceback trips, slow steps, members) */
@@ -166,7 +174,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     M.has_out = p; p += nc;
     M.sq = p; p += lc + 1;
     M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false; M.pad64 = false;
-    M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0;
+    M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0; M.lcodes = nullptr; M.lc_cap = 0;
 #ifdef CW_DIAG
     M.diag = nullptr;
 #endif
@@ -891,9 +899,13 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         if constexpr (CM != 0 && CW_POA_CODES != 0) {
             if (coded) {
                 cw_wave_sync();
-                const int bi_c = poa_fill_c<CM>(M, n, cols, lane);
+                const bool lc = M.lcodes != nullptr && (uint32_t)(((n + 7) >> 3) * cols + 64) <= M.lc_cap; /* the code words fit the LDS area (stride = columns) */
+#ifdef CW_DIAG
+                if (lane == 0 && M.diag) { atomicAdd(&M.diag[9], 1ull); if (lc) atomicAdd(&M.diag[8], 1ull); } /* members on this path / with their code words in LDS */
+#endif
+                const int bi_c = poa_fill_c<CM>(M, n, cols, lane, lc);
                 POA_PROF(1);
-                if (!poa_trace_c<CM>(M, n, bi_c, cols, lane)) return 3;
+                if (!poa_trace_c<CM>(M, n, bi_c, cols, lane, lc)) return 3;
 #ifdef CW_POA_VERIFY
                 cw_wave_sync();
                 {
@@ -1184,9 +1196,10 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, (CW_POA_NC + 1) * (CW_POA_LC + 1), 0, hslab, dslab, cold, !CW_S_EDGES_LDS, true);
     M.H = hslab; M.dirs = dslab;
     {
-        uint8_t* extra = lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(CW_POA_NC));
+        uint8_t* extra = lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - 4 * CW_S_LCODES_WORDS - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(CW_POA_NC));
         M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);
         M.codes = (uint32_t*)dslab; M.c_cap = (uint32_t)(CW_POA_DSLAB_BYTES(CW_POA_NC, CW_POA_LC) / 4);
+        if (CW_S_LCODES_WORDS) { M.lcodes = (uint32_t*)(lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - 4 * CW_S_LCODES_WORDS)); M.lc_cap = CW_S_LCODES_WORDS; }
     }
     M.pad64 = true;
     const uint32_t n_tasks = min(sc.ctr->n_tasks, sc.task_cap);

@@ -65,7 +65,7 @@ __device__ __forceinline__ int cwc_gload_i16_wait(cwc_g16 p) {
    (CW_RM_WORD: straight-line code per kind, predecessor offsets computed on the vector unit for the whole list at once, no
    prefetch logic) and the branch-free tail. */
 template <int CM>
-__device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n, const int cols, const int lane) {
+__device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n, const int cols, const int lane, const bool lc) {
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     const int NEGD = -(1 << 24);
     const int L = cols - 1;
@@ -74,6 +74,9 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
     const cwc_l16 rowst = (cwc_l16)M.ring + lane;    /* this lane's column of the row ring */
     const cwc_g16 Hg = (cwc_g16)M.H + lane;          /* flagged rows in the slab, stride 64 */
     const cwc_g32 Cg = (cwc_g32)M.codes + lane;
+    /* small alignments keep their code words in LDS, row stride = columns: a lane beyond the columns writes into the NEXT group's first
+       cells, which that group's own flush overwrites later (one wave's LDS writes are ordered; 64 words of slack behind the last group) */
+    const cwc_l32 Cl = (cwc_l32)M.lcodes + lane;
     int rc0 = 3;                                     /* row i-1 (row 0, the virtual start, is all zero in this form) */
     int bs = (int)0x80000000, bi = 0;
 #ifdef CW_DIAG /* rows by kind (0, 1, 2-3, generic), in-edges and slab loads of the generic rows, rows with a flag, all rows */
@@ -83,7 +86,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
        "my base is b", so bit (row word & 31) is the answer whatever the flag bits above the base are */
     const uint32_t onehot8 = sq >= 0 ? 0x11111111u << sq : 0u;
 #define CWC_SCORE(m) ((int)(__builtin_amdgcn_ubfe(onehot8, (m), 1u) * (uint32_t)(MS4 - XS4)) + xs_l)
-#define CWC_FLUSH(last_row) do { cwc_gstore_b32(Cg + ((last_row) >> 3) * 64, acc); acc = 0u; sh = 0; } while (0)
+#define CWC_FLUSH(last_row) do { if (lc) Cl[((last_row) >> 3) * cols] = acc; else cwc_gstore_b32(Cg + ((last_row) >> 3) * 64, acc); acc = 0u; sh = 0; } while (0)
     uint32_t acc = 0u; /* the code word of the current group of eight rows */
     int sh = 0;
     for (int r0 = 0; r0 < n; r0 += 64) {
@@ -213,7 +216,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
 /* Follows the recorded codes from (bi, L) to the virtual start; writes seqrank[j] = rank aligned to sequence position j (diagonal moves).
    Returns false when the walk does not end (cannot happen; reported as an internal error). */
 template <int CM>
-__device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int n, const int bi, const int cols, const int lane) {
+__device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int n, const int bi, const int cols, const int lane, const bool lc) {
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     const int L = cols - 1;
     const int tr = lane >> 3, tc = lane & 7;
@@ -231,7 +234,7 @@ __device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int 
         const int col = j - tc;
         uint32_t nib = 0u;
         if (row >= 1 && col >= 0) {
-            const uint32_t cw = Cg[((row - 1) >> 3) * cs + col];
+            const uint32_t cw = lc ? ((cwc_l32)M.lcodes)[((row - 1) >> 3) * cols + col] : Cg[((row - 1) >> 3) * cs + col];
             nib = (cw >> (((row - 1) & 7) * 4)) & 15u;
         }
         const int mv = (int)(nib >> 2), qn = (int)(nib & 3u);
