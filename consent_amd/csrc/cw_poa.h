@@ -70,7 +70,12 @@
    That is what lets more waves share a CU's LDS where the time goes: M1 6.4 KB per wave (five work-groups per CU), M2 12.9 KB (three
    waves in 38 KB), L 37 KB (it fits the holes the other tiers leave). */
 #define CW_POA_HOT2_BYTES(NC, EC, LC) (((NC) * 17 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16)
-#define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + 16 * 64 * 2 + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
+#ifndef CW_RING
+#define CW_RING 16                               /* cw_poa_c.h: rows of the LDS ring of the recorded-decision fill (a power of two).  8 rows measured: tiers S / M1 +4 % (more rows
+                                                    come back from the slab), tier M2 -10 % (the LDS they give up), step unchanged */
+#endif
+#define CW_POA_RING_BYTES (CW_RING * 64 * 2)
+#define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + CW_POA_RING_BYTES + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
 #define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + CW_POA_EW_BYTES(EC) + 4 * ((LC) + 1) + 255) / 256 * 256)
 #ifndef CW_S_EDGES_LDS
 #define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */

@@ -29,8 +29,6 @@
 #ifndef CW_POA_C_H
 #define CW_POA_C_H
 
-#define CW_RING 16                               /* rows of the LDS ring (tiers M1 / M2) */
-#define CW_POA_RING_BYTES (CW_RING * 64 * 2)
 #define CW_POA_GFLAG_BYTES(NC) ((((NC) / 32 + 2) * 4 + 15) / 16 * 16)
 #define CW_RM_SINK(m) (((m) & 8u) != 0u)
 
