@@ -385,7 +385,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2 + wgs_h;
     if (CW_AID_ENV("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
-    sc.use_q = (CW_POA_MODE == CW_POA_MODE_OV || CW_AID_ENV("CW_NO_TIER_Q")) ? 0u : 1u; /* (the overlap mode of cw_policy.h is implemented on the matrix path of tiers S..G) */
+    sc.use_q = CW_AID_ENV("CW_NO_TIER_Q") ? 0u : 1u;
     for (int t = 0; t < CW_TIERS; ++t) {
         if (t) { sc.tier_list[t] = (uint32_t*)(base + p.list[t]); sc.over_list[t] = (uint32_t*)(base + p.over[t]); }
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;

@@ -562,7 +562,7 @@ __device__ __forceinline__ uint32_t poa_consensus_hb(const PoaMem<HT>& M, const 
 #define CW_POA_PK_SPAN 2600
 /* CM: 0 = the matrix path only; 2 = members of <= 63 bases take the recorded-decision path of cw_poa_c.h (tiers S / M1 / M2) */
 #ifndef CW_POA_CODES
-#define CW_POA_CODES (CW_POA_OV ? 0 : 1) /* (the overlap mode is implemented on the matrix path) */
+#define CW_POA_CODES 1
 #endif
 template <typename HT, int PK, int CM = 0, int LCAP = 1023> /* LCAP: the tier's longest member -- fills for wider rows are not compiled into its kernel */
 __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
@@ -908,9 +908,10 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #ifdef CW_DIAG
                 if (lane == 0 && M.diag) { atomicAdd(&M.diag[9], 1ull); if (lc) atomicAdd(&M.diag[8], 1ull); } /* members on this path / with their code words in LDS */
 #endif
-                const int bi_c = poa_fill_c<CM>(M, n, cols, lane, lc);
+                const int be_c = poa_fill_c<CM>(M, n, cols, lane, lc);
+                const int bi_c = be_c & 0xFFFF, bj_c = be_c >> 16; /* end row, end column (the last one unless cw_policy.h's overlap mode) */
                 POA_PROF(1);
-                if (!poa_trace_c<CM>(M, n, bi_c, cols, lane, lc)) return 3;
+                if (!poa_trace_c<CM>(M, n, bi_c, bj_c, cols, lane, lc)) return 3;
 #ifdef CW_POA_VERIFY
                 cw_wave_sync();
                 {

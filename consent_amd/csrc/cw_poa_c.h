@@ -76,7 +76,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
        cells, which that group's own flush overwrites later (one wave's LDS writes are ordered; 64 words of slack behind the last group) */
     const cwc_l32 Cl = (cwc_l32)M.lcodes + lane;
     int rc0 = 3;                                     /* row i-1 (row 0, the virtual start, is all zero in this form) */
-    int bs = (int)0x80000000, bi = 0;
+    int bs = (int)0x80000000, bi = 0, bj = L; /* (bj: the overlap mode's end column, cw_policy.h CW_POA_MODE_OV) */
 #ifdef CW_DIAG /* rows by kind (0, 1, 2-3, generic), in-edges and slab loads of the generic rows, rows with a flag, all rows */
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -101,7 +101,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
                 do {
                     const int i = r0 + rl + 1;
                     const int kD = cw_wave_shr1(rc0, 0) + s_l, kV = rc0 + G4;
-                    const int v = max(kD, kV);
+                    const int v = CW_POA_OV && lane == 0 ? 3 : max(kD, kV); /* (overlap mode: column 0 is free) */
                     ++rl; plain >>= 1;
                     meta = (uint32_t)__builtin_amdgcn_readlane((int)meta_v, rl);
                     s_l = CWC_SCORE(meta);
@@ -163,7 +163,7 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
                     kD = dm + s_l; kV = vm + G4;
                 }
             }
-            const int v = max(kD, kV);
+            const int v = CW_POA_OV && lane == 0 ? 3 : max(kD, kV);
             const uint32_t meta_c = meta;
             /* the next row's word and match scores: independent of the scan, they fill the wait states between its DPP steps */
             ++rl; plain >>= 1;
@@ -191,8 +191,14 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
             if (meta_c & 24u) { /* a sink (the end cell is the best of them), a row some later row or the traceback reads from the slab */
                 if (meta_c & 16u) cwc_gstore_b16(Hg + i * 64, nv);
                 if (CW_RM_SINK(meta_c)) {
-                    const int h = __builtin_amdgcn_readlane(nv, L);
-                    if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
+                    if (CW_POA_OV) { /* the best cell of the row, columns 1..L, in H form; lowest column on ties */
+                        const int hv = (lane >= 1 && lane <= L) ? (nv >> 2) + lane * CW_POA_GAP : (int)0x80000000;
+                        const int hm = cw_wave_max(hv);
+                        if (hm > bs) { bs = hm; bi = i; bj = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)__ballot(hv == hm)) - 1); }
+                    } else {
+                        const int h = __builtin_amdgcn_readlane(nv, L);
+                        if (h > bs) { bs = h; bi = i; } /* ranks ascend: the lowest rank keeps a tie */
+                    }
                 }
             }
             rc0 = nv;
@@ -208,19 +214,19 @@ __device__ __forceinline__ int poa_fill_c(const PoaMem<int16_t>& M, const int n,
 #ifdef CW_DIAG
     if (lane == 0) { for (int k = 0; k < 7; ++k) atomicAdd(&M.diag[k], (unsigned long long)dg[k]); atomicAdd(&M.diag[10], (unsigned long long)dg[7]); if (cols <= 32) atomicAdd(&M.diag[11], (unsigned long long)dg[7]); }
 #endif
-    return bi;
+    return bi | (bj << 16);
 }
 
 /* Follows the recorded codes from (bi, L) to the virtual start; writes seqrank[j] = rank aligned to sequence position j (diagonal moves).
    Returns false when the walk does not end (cannot happen; reported as an internal error). */
 template <int CM>
-__device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int n, const int bi, const int cols, const int lane, const bool lc) {
+__device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int n, const int bi, const int bj, const int cols, const int lane, const bool lc) {
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     const int L = cols - 1;
     const int tr = lane >> 3, tc = lane & 7;
     const int cs = 64;
     const cwc_g32 Cg = (cwc_g32)M.codes;
-    int i = bi, j = L, trips = 0;
+    int i = bi, j = bj, trips = 0;
     while (i > 0) {
         if (++trips > n + cols + 4) return false;
         i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
@@ -238,7 +244,7 @@ __device__ __forceinline__ bool poa_trace_c(const PoaMem<int16_t>& M, const int 
         const int mv = (int)(nib >> 2), qn = (int)(nib & 3u);
         /* 0 diagonal, 1 vertical (both through in-edge 0: the next tile row), 2 horizontal; 3 through another in-edge, 5 neighbours outside
            the tile, 6 the virtual start row */
-        const bool c_start = row <= 0, c_edge = tr == 7 || (tc == 7 && col > 0) || col < 0;
+        const bool c_start = row <= 0 || (CW_POA_OV && col <= 0), c_edge = tr == 7 || (tc == 7 && col > 0) || col < 0; /* (overlap mode: the walk stops in column 0) */
         const int code = c_start ? 6 : c_edge ? 5 : mv == 2 ? 2 : qn != 0 ? 3 : mv;
         const unsigned long long m_d = __ballot(code == 0), m_v = __ballot(code == 1), m_h = __ballot(code == 2);
         int pos = 0;

@@ -73,6 +73,7 @@ __device__ __forceinline__ void poaq_fill(const PoaMem<int16_t>& M, const int n,
             const int dg = __builtin_amdgcn_alignbit(up, sh, 16);       /* (col 2l-1, col 2l) of the row above */
             v = pk_max(v, pk_max(pk_add(dg, srow), pk_add(up, GPK)));
         }
+        if (CW_POA_OV && gl == 0) v = (int)((unsigned)v & 0xFFFF0000u); /* overlap mode (cw_policy.h): column 0 -- this lane's even half -- is free */
         int w = pk_sub(v, jg);
         w = (w & amask) | (CW_NEGPK & ~amask);
         w = pk_max(w, (w << 16) | 0x8AD0);                              /* odd column sees the even one of its lane */
@@ -156,8 +157,22 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         POAQ_PROF(1);
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
-        int bi;
-        {
+        int bi, bj = L;
+        if (CW_POA_OV) { /* overlap mode: the best cell of a sink's row, columns 1..L; lowest rank, then lowest column on ties */
+            int bs = CW_NEG * 2, br = 0x7FFFFFFF, bc = L;
+            for (int r = gl; r < n; r += 16) {
+                if (M.has_out[M.r2n[r]]) continue;
+                for (int j = 1; j <= L; ++j) {
+                    const int h = M.H[(r + 1) * HS + j];
+                    if (h > bs) { bs = h; br = r; bc = j; }
+                }
+            }
+            for (int o = 8; o > 0; o >>= 1) {
+                const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o), oc = __shfl_xor(bc, o);
+                if (os > bs || (os == bs && orr < br)) { bs = os; br = orr; bc = oc; }
+            }
+            bi = br + 1; bj = bc;
+        } else {
             int bs = CW_NEG * 2, br = 0x7FFFFFFF;
             for (int r = gl; r < n; r += 16) {
                 if (M.has_out[M.r2n[r]]) continue;
@@ -174,8 +189,8 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         /* ---- traceback: every lane of the row walks the same path (diagonal through the in-edges in order, then vertical through them,
            then horizontal); the three candidate cells of a single-predecessor node are requested together ---- */
         {
-            int i = bi, j = L;
-            while (i > 0) {
+            int i = bi, j = bj;
+            while (i > 0 && (!CW_POA_OV || j > 0)) { /* (overlap mode: the walk stops in column 0) */
                 const uint32_t meta = M.rmeta[i - 1];
                 const int pr0 = (int)M.rpred0[i - 1];
                 const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);

@@ -57,8 +57,7 @@
 #define CW_POA_MODE_OV 2 /* semi-global / overlap, as spoa's kOV is published: first row gap-penalised, first column free, the alignment
                             ends in the best cell (columns 1..L, lowest rank then lowest column on ties) of a node without out-edges and stops where
                             it reaches the first row or column; the bases beyond the end cell and before the stop are insertions.  Implemented on both
-                            sides since round 4; the engine then aligns on the matrix path of tiers S..G (no tier Q, no recorded decisions:
-                            slower, meant as insurance -- see DESIGN.md section 2) */
+                            sides since round 4, in every tier and on both POA paths of the engine (matrix and recorded decisions) */
 #ifndef CW_POA_MODE
 #define CW_POA_MODE CW_POA_MODE_NW
 #endif

@@ -79,8 +79,8 @@ def test_heaviest_bundle_consensus_is_implemented_on_both_sides(tmp_path):
 @pytest.mark.timeout(1500)
 def test_overlap_alignment_mode_is_implemented_on_both_sides(tmp_path):
     """-DCW_POA_MODE=2 (cw_policy.h CW_POA_MODE_OV, round 4): column 0 of the DP free, the alignment ends in the best cell of a sink's row and
-    stops in the first row or column, the bases outside it become insertions -- in the oracle (scalar and AVX2 fills) and on the engine's
-    matrix path (tiers S..G; tier Q and the recorded-decision path are not used by that build).  The two sides agree window by window
+    stops in the first row or column, the bases outside it become insertions -- in the oracle (scalar and AVX2 fills) and in every tier
+    and on both POA paths of the engine.  The two sides agree window by window
     under that mode, and the consensus is not the global mode's."""
     from consent_amd import _build
 
