@@ -26,7 +26,7 @@ namespace {
 /* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
 static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
-static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
+static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
 static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
@@ -181,13 +181,13 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
+                            CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
@@ -401,7 +401,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
 #define M2_ARGS CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2
 #define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
     const size_t lds_m1 = CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
-    const size_t lds_m2 = CW_POA_HOT2C_BYTES(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
+    const size_t lds_m2 = CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
     const size_t lds_l = CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));

@@ -76,6 +76,13 @@
 #endif
 #define CW_POA_RING_BYTES (CW_RING * 64 * 2)
 #define CW_POA_HOT2C_BYTES(NC, EC, LC) (CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16 + CW_POA_RING_BYTES + (((NC) / 32 + 2) * 4 + 15) / 16 * 16) /* + the chain tables p2/p4, the row ring and the slab-row flags of cw_poa_c.h (tiers M1 / M2) */
+#ifndef CW_M2_CODES
+#define CW_M2_CODES 0 /* tier M2 on the recorded-decision path (measured slower: 85 % of its rows are linear) */
+#endif
+/* LDS per wave of slab tier T (1 = M1, 2 = M2): the ring and the flags only where the recorded-decision fill runs (tier M2 carried their 2.1 KB
+   per wave unused until round 4: LDS is what the tiers compete for) */
+#define CW_POA_HOTC_OF_TIER(T) ((T) == 1 || CW_M2_CODES)
+#define CW_POA_HOT2T_BYTES(T, NC, EC, LC) (CW_POA_HOTC_OF_TIER(T) ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16)
 #define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + CW_POA_EW_BYTES(EC) + 4 * ((LC) + 1) + 255) / 256 * 256)
 #ifndef CW_S_EDGES_LDS
 #define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */
@@ -1282,11 +1289,11 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
-    constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC);
+    constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2T_BYTES(TIER, NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
                                            true, TIER <= 2);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
-    if (TIER <= 2) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
+    if (TIER <= 2 && CW_POA_HOTC_OF_TIER(TIER)) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
         uint8_t* extra = lds + (size_t)wave * slab + (slab - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(NC));
         M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);
         M.codes = (uint32_t*)dslab; M.c_cap = (uint32_t)(CW_POA_DSLAB_BYTES(NC, LC) / 4);
@@ -1310,9 +1317,6 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
         /* tier M2's rows are 85 % linear (long graphs, short members): there the matrix fill's 37-instruction row beats the recorded
            decisions' 52, and its slower traceback does not make up for it (measured: 35.8 against 38.5 G wave-cycles per batch) */
-#ifndef CW_M2_CODES
-#define CW_M2_CODES 0
-#endif
         const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2), (TIER == 1 || (TIER == 2 && CW_M2_CODES) ? 2 : 0), LC>(M, t, b, sc, lane, acc);
         const unsigned long long _t1 = __builtin_readcyclecounter();
         acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];

@@ -122,6 +122,20 @@ def main():
             k["sq_derived"] = d
             lines.append(f"{short(name)[:58]:58s} " + " ".join(f"{d[x]:10.3f}" for x in ("valu_active_per_wave_cycle", "lds_active_per_wave_cycle", "active_per_wave_cycle", "wait_per_wave_cycle",
                                                                                           "issue_stall_per_wave_cycle", "lds_bank_conflict_share", "share_of_wave_cycles")))
+        # alone on the GPU (the counter passes serialise the kernels): mean resident waves per SIMD and VALU issue rate over the kernel's own duration
+        # (SQ_BUSY_CYCLES is summed over the 32 shader engines: / 32 = the kernel's duration in cycles)
+        lines.append("")
+        lines.append("# per kernel ALONE on the GPU (rocprofv3 counter mode serialises the kernels): duration = SQ_BUSY_CYCLES / 32 shader engines; mean resident waves per SIMD")
+        lines.append("# = wave-cycles / (duration x 1024 SIMDs); VALU issue = INSTS_VALU x 4 cycles / (duration x 1024 SIMDs)")
+        lines.append(f"{'kernel':58s} {'Mcycles':>10s} {'waves/SIMD':>10s} {'VALU issue':>10s}")
+        for name in sorted(sq, key=lambda n: -sq[n].get("SQ_WAVE_CYCLES", 0)):
+            v = sq[name]
+            if not v.get("SQ_BUSY_CYCLES"):
+                continue
+            dur = v["SQ_BUSY_CYCLES"] / 32.0
+            a = {"alone_mcycles": dur / 1e6, "alone_waves_per_simd": v.get("SQ_WAVE_CYCLES", 0) * 4 / (dur * N_SIMD), "alone_valu_issue": v.get("SQ_INSTS_VALU", 0) * 4 / (dur * N_SIMD)}
+            summary["kernels"].setdefault(name, {}).setdefault("sq_derived", {}).update(a)
+            lines.append(f"{short(name)[:58]:58s} {a['alone_mcycles']:10.2f} {a['alone_waves_per_simd']:10.2f} {a['alone_valu_issue']:10.3f}")
         # whole step: VALU issue slots used / available, LDS array cycles used / available, over the step time of the one-engine trace
         ms = step_ms.get("e1")
         if ms:
