@@ -27,7 +27,7 @@ namespace {
 static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
-static_assert(CW_POAL_WAVES * CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
+static_assert(CW_POAL_WAVES * CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -48,11 +48,11 @@ size_t big_slab_bytes() {
 struct TierMix { uint32_t s, m1, m2, l; };
 TierMix tier_mix(bool deep) {
     TierMix m = deep ? TierMix{4, 5, 4, 2} : TierMix{4, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
-    auto knob = [](const char* name, uint32_t dflt) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 8 ? (uint32_t)x : dflt; };
+    auto knob = [](const char* name, uint32_t dflt) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 12 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
     if (m.s > 6) m.s = 6;
-    if (m.m1 > 6) m.m1 = 6;
-    if (m.m2 > 8) m.m2 = 8;
+    if (m.m1 > 12) m.m1 = 12;
+    if (m.m2 > 12) m.m2 = 12;
     if (m.l > 8) m.l = 8;
     return m;
 }
@@ -183,13 +183,13 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
 #ifdef CW_TEST_AIDS
@@ -402,7 +402,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
 #define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
     const size_t lds_m1 = CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
     const size_t lds_m2 = CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
-    const size_t lds_l = CW_POA_HOT2_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
+    const size_t lds_l = CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));

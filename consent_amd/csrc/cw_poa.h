@@ -41,12 +41,16 @@
 #define CW_POAM1_NC 256
 #define CW_POAM1_EC 640
 #define CW_POAM1_LC 255
+#ifndef CW_POAM1_WAVES
 #define CW_POAM1_WAVES 4
+#endif
 #define CW_POAM1_ROUTE 208 /* tasks expected to grow beyond this many nodes go to M2 at once (fewer late hand-overs) */
 #define CW_POAM2_NC 512
 #define CW_POAM2_EC 1280
 #define CW_POAM2_LC 511
+#ifndef CW_POAM2_WAVES
 #define CW_POAM2_WAVES 3
+#endif
 #define CW_POAM2_ROUTE CW_POAM2_NC
 #define CW_POAL_NC 1536
 #define CW_POAL_EC 4096
@@ -83,7 +87,12 @@
    per wave unused until round 4: LDS is what the tiers compete for) */
 #define CW_POA_HOTC_OF_TIER(T) ((T) == 1 || CW_M2_CODES)
 #define CW_POA_HOT2T_BYTES(T, NC, EC, LC) (CW_POA_HOTC_OF_TIER(T) ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16)
-#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 12 + (EC) * 4 + CW_POA_EW_BYTES(EC) + 4 * ((LC) + 1) + 255) / 256 * 256)
+#ifndef CW_L_COLD_NODES
+#define CW_L_COLD_NODES 0 /* 1: tier L keeps in_head / indeg / nbase / nalc / has_out in its slab, not in LDS (37 -> 26 KB per wave).  Measured: depth 150 unchanged within
+                             noise, depth 30 -- where tier L is the long pole -- 1 ms slower with one engine (tier L 16.0 -> 17.1 ms).  Off. */
+#endif
+#define CW_POA_HOT2L_BYTES(NC, EC, LC) (CW_L_COLD_NODES ? ((NC) * 10 + (EC) * 2 + 3 * ((LC) + 1) + 64 + 15) / 16 * 16 : CW_POA_HOT2_BYTES(NC, EC, LC))
+#define CW_POA_COLD2_BYTES(NC, EC, LC) (((NC) * 19 + (EC) * 4 + CW_POA_EW_BYTES(EC) + 4 * ((LC) + 1) + 255) / 256 * 256) /* (NC * 7 of it: tier L's per-node arrays, CW_L_COLD_NODES) */
 #ifndef CW_S_EDGES_LDS
 #define CW_S_EDGES_LDS 1 /* tier S keeps its in-edge lists and coverage counts in LDS (1.8 KB): the metadata pass walks them for every member */
 #endif
@@ -155,7 +164,7 @@ struct PoaMem {
 template <typename HT>
 __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint32_t ec, uint32_t lc, uint32_t hc, uint32_t dc,
                                                 HT* h_ext = nullptr, unsigned long long* d_ext = nullptr, uint8_t* cold = nullptr,
-                                                bool cold_edges = false, bool chain_tabs = false) {
+                                                bool cold_edges = false, bool chain_tabs = false, bool cold_nodes = false) {
     PoaMem<HT> M;
     uint8_t* p = base;
     uint8_t* pc = cold; /* merge-only arrays: in the slab when given, else with the rest */
@@ -171,9 +180,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     if (chain_tabs) { M.p2 = (uint16_t*)p; p += 2 * nc; M.p4 = (uint16_t*)p; p += 2 * nc; } else { M.p2 = nullptr; M.p4 = nullptr; }
     if (!(pc && cold_edges)) { M.ncov = (uint16_t*)p; p += 2 * nc; }
     if (pc) { M.nal = (uint16_t*)pc; pc += 6 * nc; } else { M.nal = (uint16_t*)p; p += 6 * nc; }
-    M.in_head = (uint16_t*)p; p += 2 * nc;
+    if (pc && cold_nodes) { M.in_head = (uint16_t*)pc; pc += 2 * nc; } else { M.in_head = (uint16_t*)p; p += 2 * nc; }
     if (pc) { M.in_tail = (uint16_t*)pc; pc += 2 * nc; } else { M.in_tail = (uint16_t*)p; p += 2 * nc; }
-    M.indeg = (uint16_t*)p; p += 2 * nc;
+    if (pc && cold_nodes) { M.indeg = (uint16_t*)pc; pc += 2 * nc; } else { M.indeg = (uint16_t*)p; p += 2 * nc; }
     M.r2n = (uint16_t*)p; p += 2 * nc;
     M.n2r = (uint16_t*)p; p += 2 * nc;
     if (pc) { M.rtmp = (uint16_t*)pc; pc += 2 * nc; } else { M.rtmp = (uint16_t*)p; p += 2 * nc; }
@@ -181,9 +190,9 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     if (pc) { M.pcur = (uint16_t*)pc; pc += 2 * (lc + 1); M.pat = (uint16_t*)pc; pc += 2 * (lc + 1); }
     else { M.pcur = (uint16_t*)p; p += 2 * (lc + 1); M.pat = (uint16_t*)p; p += 2 * (lc + 1); }
     if (pc && cold_edges) { M.efrom = (uint16_t*)pc; pc += 2 * ec; M.enext = (uint16_t*)pc; pc += 2 * ec; if (CW_CONS_HEAVIEST_BUNDLE) { M.ew = (uint16_t*)pc; pc += 2 * ec; } M.ncov = (uint16_t*)pc; pc += 2 * nc; }
-    M.nbase = p; p += nc;
-    M.nalc = p; p += nc;
-    M.has_out = p; p += nc;
+    if (pc && cold_nodes) { M.nbase = pc; pc += nc; M.nalc = pc; pc += nc; M.has_out = pc; pc += nc; } /* tier L: per-node arrays the metadata pass, the end cell and the merge read once per
+                                                                                                           member -- next to a millisecond of fill -- leave LDS (10.5 of its 37 KB per wave) */
+    else { M.nbase = p; p += nc; M.nalc = p; p += nc; M.has_out = p; p += nc; }
     M.sq = p; p += lc + 1;
     M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false; M.pad64 = false;
     M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0; M.lcodes = nullptr; M.lc_cap = 0;
@@ -1289,9 +1298,9 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     int16_t* hslab = (int16_t*)my_slab;
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
-    constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2T_BYTES(TIER, NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC);
+    constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2T_BYTES(TIER, NC, EC, LC) : CW_POA_HOT2L_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
-                                           true, TIER <= 2);
+                                           true, TIER <= 2, TIER >= 3 && CW_L_COLD_NODES);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     if (TIER <= 2 && CW_POA_HOTC_OF_TIER(TIER)) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
         uint8_t* extra = lds + (size_t)wave * slab + (slab - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(NC));
