@@ -26,7 +26,7 @@ namespace {
 /* LDS budget of the POA tiers (160 KiB per CU): the occupancy the tier table of DESIGN.md states depends on these sums */
 static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
-static_assert(3 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840, "tier M2: three work-groups per CU");
+static_assert(4 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840 || CW_M2_CHAIN_TABS || CW_M2_CODES, "tier M2: four work-groups per CU");
 static_assert(CW_POAL_WAVES * CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 

@@ -86,7 +86,12 @@
 /* LDS per wave of slab tier T (1 = M1, 2 = M2): the ring and the flags only where the recorded-decision fill runs (tier M2 carried their 2.1 KB
    per wave unused until round 4: LDS is what the tiers compete for) */
 #define CW_POA_HOTC_OF_TIER(T) ((T) == 1 || CW_M2_CODES)
-#define CW_POA_HOT2T_BYTES(T, NC, EC, LC) (CW_POA_HOTC_OF_TIER(T) ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC) + (4 * (NC) + 15) / 16 * 16)
+#ifndef CW_M2_CHAIN_TABS
+#define CW_M2_CHAIN_TABS 0 /* 1: tier M2 keeps the traceback's chain tables p2 / p4 in LDS (2 KB per wave: a tile's eight rows in three dependent reads instead of
+                              seven).  Without them its work-group is 38.6 KB -- the size of M1's, L's and Q's: any four fit a CU -- and the two-engine step 1.8 ms
+                              shorter (61.6 -> 59.8 ms, four alternating runs each on one box) */
+#endif
+#define CW_POA_HOT2T_BYTES(T, NC, EC, LC) (CW_POA_HOTC_OF_TIER(T) ? CW_POA_HOT2C_BYTES(NC, EC, LC) : CW_POA_HOT2_BYTES(NC, EC, LC) + (CW_M2_CHAIN_TABS ? (4 * (NC) + 15) / 16 * 16 : 0))
 #ifndef CW_L_COLD_NODES
 #define CW_L_COLD_NODES 0 /* 1: tier L keeps in_head / indeg / nbase / nalc / has_out in its slab, not in LDS (37 -> 26 KB per wave).  Measured: depth 150 unchanged within
                              noise, depth 30 -- where tier L is the long pole -- 1 ms slower with one engine (tier L 16.0 -> 17.1 ms).  Off. */
@@ -1300,7 +1305,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
     constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2T_BYTES(TIER, NC, EC, LC) : CW_POA_HOT2L_BYTES(NC, EC, LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
-                                           true, TIER <= 2, TIER >= 3 && CW_L_COLD_NODES);
+                                           true, TIER == 1 || (TIER == 2 && (CW_M2_CHAIN_TABS || CW_M2_CODES)), TIER >= 3 && CW_L_COLD_NODES);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     if (TIER <= 2 && CW_POA_HOTC_OF_TIER(TIER)) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
         uint8_t* extra = lds + (size_t)wave * slab + (slab - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(NC));
