@@ -24,7 +24,9 @@
 #include "cw_poa_h.h"
 
 #define CW_CH_WAVES 4
+#ifndef CW_CH_SLAB
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
+#endif
 #define CW_CH_LIST_BYTES 1792
 #define CW_CH_TILE_STRIDE 66u /* u16 per row of phase D's tile: 64 sequences + 2 (33 words: a column read by 64 lanes hits every bank twice) */
 
