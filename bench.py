@@ -76,7 +76,7 @@ def self_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def driver_mode(args):
+def driver_measure(args, dry_reps=3):
     """`--mode driver`: the native driver end to end -- ONE host process (bin/CONSENT-correction = cw_run_correction) feeding
     `--gpus` devices from a PAF + read file, piles cut, corrected and re-assembled on the devices, FASTA written in PAF order.  Strong
     scaling: the read set is fixed (BASELINE configs[3] scale: 4.6 Mbp genome, 30x ONT-profile reads, ground-truth overlaps; `--driver-copies 8`
@@ -110,7 +110,7 @@ def driver_mode(args):
         return wall, json.loads([ln for ln in err.splitlines() if ln.startswith("{")][-1])
 
     # (the dry run is a test aid: only the -DCW_TEST_AIDS build of the library has it -- consent_amd/aids/, csrc/cw_env.h)
-    dry_wall, dry = min((run({"CW_DRIVER_DRY": "1", "LD_LIBRARY_PATH": os.path.join(ROOT, "consent_amd", "aids")}, os.devnull) for _ in range(3)), key=lambda x: x[0])
+    dry_wall, dry = min((run({"CW_DRIVER_DRY": "1", "LD_LIBRARY_PATH": os.path.join(ROOT, "consent_amd", "aids")}, os.devnull) for _ in range(max(1, dry_reps))), key=lambda x: x[0])
     best = None
     for _ in range(max(1, args.driver_reps)):
         wall, st = run({}, out_fa)
@@ -136,7 +136,11 @@ def driver_mode(args):
                            "what": "CW_DRIVER_DRY=1: PAF piles -> window positions -> jobs, workers drop the jobs; windows / producer time"},
         "data_generation_s": gen_s,
     }
-    print(json.dumps(out))
+    return out
+
+
+def driver_mode(args):
+    print(json.dumps(driver_measure(args)))
 
 
 def main():
@@ -146,6 +150,7 @@ def main():
     ap.add_argument("--driver-cov", type=int, default=30)
     ap.add_argument("--driver-copies", type=int, default=1)
     ap.add_argument("--driver-reps", type=int, default=2)
+    ap.add_argument("--driver-leg", type=int, default=1, help="kernel mode: after the timed region rank 0 also runs the native driver (ONE process over the --gpus devices) on the fixed BASELINE configs[3]-scale read set and reports it under `driver_strong_scaling` of the same JSON line (strong scaling: the set does not grow with N); 0 disables")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -563,6 +568,32 @@ def main():
             dc = ("kind 0 (linear)", "kind 1", "kinds 2-3", "generic", "in-edges of generic rows", "slab loads of generic rows", "rows with a flag", "tb_trips", "members with code words in LDS", "members", "rows", "rows of members <= 31 bases")
             for i, t in enumerate(("S", "M1")):  # the recorded-decision fill (cw_poa_c.h) counts by row kind
                 print(f"diag tier {t}, coded fill:", {n: int(prof[72 + 12 * i + k]) for k, n in enumerate(dc)}, file=sys.stderr)
+    # --- strong scaling, same JSON line: the weak-scaling line above is N independent processes; what `north_star` means by
+    # "reads sharded across the 8 GPUs" is ONE process feeding N devices from one PAF + read file.  Every rank gives its device back first.
+    if args.driver_leg:
+        for e_ in engines:
+            e_.close()
+        del batches, keep, keep_r, t_cons, t_clen, t_stat, t_solid, t_slen, t_coff, t_soff
+        torch.cuda.empty_cache()
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            try:
+                da = argparse.Namespace(**vars(args))
+                da.driver_copies, da.driver_reps = 1, 2
+                d = driver_measure(da, dry_reps=2)
+                out["driver_strong_scaling"] = {
+                    "windows_per_s": d["value"], "s_total": d["s_inside_cw_run_correction"], "wall_s_process": d["wall_s_process"], "n_gpus": args.gpus,
+                    "windows": d["config"]["windows"], "jobs": d["config"]["jobs"], "workers": d["config"]["workers"],
+                    "per_device_busy": d["per_device"], "ms_index": d["ms_index"], "ms_engines": d["ms_engines"],
+                    "steady_state_windows_per_s": d["steady_state_windows_per_s"], "feeder_ceiling": d["feeder_ceiling"],
+                    "workload": d["config"]["workload"], "scaling": "strong",
+                    "what": "bin/CONSENT-correction (cw_run_correction): one host process, piles cut / corrected / re-assembled on the --gpus devices, FASTA out in PAF order; the set is fixed (4.6 Mbp, 30x), so this value at N = 1, 2, 4, 8 is the strong-scaling curve",
+                }
+            except (SystemExit, Exception) as exc:  # the contract line must survive a failure of the extra leg
+                out["driver_strong_scaling"] = {"error": str(exc)[-400:]}
+        if world > 1:
+            dist.barrier()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -91,7 +91,7 @@ struct BatchCounters {
     uint32_t next_over[CW_TIERS];
     uint32_t done_wgs;            /* work-groups of the producing tiers (S, M1, M2) that have finished */
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
-    unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile; 72 + 10 t ..: row / trip
+    unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile; 72 + 12 t ..: row / trip
                                                counts of tier t in a -DCW_DIAG build (cw_poa.h PoaMem::diag) */
 };
 
@@ -173,14 +173,6 @@ __device__ __forceinline__ void cw_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int cw_wave_max(int v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int cw_wave_sum(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 /* DPP controls (gfx9 family): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
  * With bound_ctrl = false a lane without a source keeps `old`, which is the identity of the reduction. */
 #define CW_DPP(old, src, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xF, false)
@@ -217,6 +209,10 @@ __device__ __forceinline__ int cw_wave_scan_add(int v) {
     v += CW_DPP(0, v, 0x143, 0xC);
     return v;
 }
+/* wave-wide max / sum as a wave-uniform value: the DPP ladder of the scans, then the last lane's value through v_readlane -- all VALU / SALU,
+   no ds_bpermute round trips through the LDS crossbar (round 5; until then six __shfl_xor steps each).  Callers are in wave-uniform control flow. */
+__device__ __forceinline__ int cw_wave_max(int v) { return __builtin_amdgcn_readlane(cw_wave_scan_max(v), 63); }
+__device__ __forceinline__ int cw_wave_sum(int v) { return __builtin_amdgcn_readlane(cw_wave_scan_add(v), 63); }
 /* wave-wide max of a 64-bit key, returned as a wave-uniform value (two 32-bit DPP ladders with a lexicographic select) */
 __device__ __forceinline__ unsigned long long cw_wave_max_u64(unsigned long long v) {
     unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;

@@ -104,7 +104,8 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
     } while (0)
 
 struct Worker {
-    int device = 0;
+    int device = 0; /* the device this worker serves: read-set ownership, statistics */
+    int phys = 0;   /* the HIP device behind it (== device, except under the test aid CW_VIRTUAL_DEVICES: several logical devices on one GPU) */
     cw_engine* eng = nullptr;
     hipStream_t st = nullptr;
     cw_read_set dev_reads{};
@@ -140,7 +141,7 @@ struct Worker {
     int init(const Shared& sh) {
         int rc = CW_OK;
         if (sh.dry) { if (!owner) reads_ready.set_value(CW_OK); return CW_OK; }
-        if (hipSetDevice(device) != hipSuccess) rc = CW_E_NO_DEVICE;
+        if (hipSetDevice(phys) != hipSuccess) rc = CW_E_NO_DEVICE;
         if (!owner) { /* the copy first: the borrowers' engines are being created meanwhile */
             if (rc == CW_OK) rc = upload_reads(sh);
             reads_ready.set_value(rc);
@@ -148,7 +149,7 @@ struct Worker {
         if (rc != CW_OK) return rc;
         const cw_driver_args& a = *sh.a;
         cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
-        rc = cw_create(&prm, device, &eng);
+        rc = cw_create(&prm, phys, &eng);
         if (rc != CW_OK) return rc;
         if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
         if (owner) {
@@ -160,7 +161,7 @@ struct Worker {
 
     void close() {
         if (!eng && !st && !pin) return; /* nothing was created (dry run, or init failed early) */
-        (void)hipSetDevice(device);
+        (void)hipSetDevice(phys);
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
         if (eng) { cw_destroy(eng); eng = nullptr; }
@@ -175,7 +176,7 @@ struct Worker {
         if (n_win == 0 || n_piles == 0) return;
         if (sh.dry) { windows += n_win; reads += n_piles; jobs++; return; }
         const double t0 = now_ms();
-        DRV_HIP(hipSetDevice(device), j, "hipSetDevice");
+        DRV_HIP(hipSetDevice(phys), j, "hipSetDevice");
         DRV_RC(ovl.ensure(j.ovl.size() * sizeof(cw_overlap) + 64), j, "device memory (overlaps)");
         DRV_RC(wj.ensure((size_t)n_win * sizeof(cw_window_job)), j, "device memory (window jobs)");
         DRV_RC(pos.ensure((size_t)n_win * 8), j, "device memory (window positions)");
@@ -500,6 +501,10 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     int n_dev = 0;
     if (dry) { n_dev = a->nb_threads < 1 ? 1 : (int)a->nb_threads; for (int d : devs) n_dev = d + 1 > n_dev ? d + 1 : n_dev; } /* as many "devices" as were asked for */
     else if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { cw_read_index_free(index); fprintf(stderr, "[consent_amd] no HIP device: the engine has no CPU path\n"); return CW_E_NO_DEVICE; }
+    /* test aid (-DCW_TEST_AIDS build only): CW_VIRTUAL_DEVICES=8 makes the one GPU of a test box eight logical devices -- eight read-set uploads,
+       the workers, job size and queue an 8-GPU node gets (tests/test_gpu_driver.py); logical device v runs on HIP device v % (physical count) */
+    const int n_phys = n_dev > 0 ? n_dev : 1;
+    if (!dry) if (const char* env = CW_AID_ENV("CW_VIRTUAL_DEVICES")) { const int v = atoi(env); if (v >= 1 && v <= 64) n_dev = v; }
     if (devs.empty()) {
         /* two workers (engine + buffers each) per device: while one job is in its re-assembly -- one wave per read, the longest read sets
            the time, most of the GPU idle -- the other worker's consensus kernels run (measured on one GPU: 717 -> 550 ms for 112 k windows) */
@@ -518,6 +523,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     std::vector<Worker> workers(devs.size());
     for (size_t i = 0; i < devs.size(); ++i) {
         workers[i].device = devs[i];
+        workers[i].phys = devs[i] % n_phys;
         for (size_t o = 0; o < i; ++o)
             if (!workers[o].owner && workers[o].device == devs[i]) { workers[i].owner = &workers[o]; break; }
     }
@@ -568,6 +574,7 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
         const uint64_t want = est_windows / (8ull * n_distinct_devs) + 1; /* eight jobs per device: four per worker with two workers, two with four */
         if (want < per_job) per_job = (uint32_t)(want < 4096 ? 4096 : want);
     }
+    if (const char* env = CW_AID_ENV("CW_JOB_WINDOWS")) { const long v = atol(env); if (v >= 1 && v <= (long)CW_MAX_BATCH_WINDOWS) per_job = (uint32_t)v; } /* test aid: jobs of a few windows, so that a small data set reaches every worker */
     cw_paf_reader* paf = nullptr;
     rc = cw_paf_open(a->alignment_file, index, a->max_support, &paf);
     uint64_t n_piles = 0, n_windows = 0, n_overlaps = 0;

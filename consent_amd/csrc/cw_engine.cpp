@@ -85,7 +85,7 @@ struct ScratchPlan {
     size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
-    uint32_t task_cap, member_cap;
+    uint32_t task_cap, member_cap, arena_scale;
     TierCfg tier[CW_TIERS];
 };
 
@@ -96,7 +96,13 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     p.seg_cap = (uint64_t)n_windows * (CW_TMAX + 2);
     /* scale: 1, or 4 / 16 / 64 after a run whose windows stopped on the task / member / arena capacities -- heuristics of the batch, which a batch of
        few, heavy windows (900-base windows at depth 100) outgrows: cw_run_device_sync runs such a batch again with the larger plan */
-    p.arena_cap = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096) * scale;
+    /* the arena is addressed with 32-bit offsets (WinInfo, PoaTask): its scale is the largest one <= scale that keeps the batch's arena inside them
+       (x4 of a 52 000-window batch did not, and the re-run ended in CW_E_INVALID); tasks and members scale on their own */
+    const uint64_t arena1 = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096);
+    uint64_t as = scale;
+    while (as > 1 && arena1 * as > 0xFFFFFFFFull) as /= 2;
+    p.arena_scale = (uint32_t)as;
+    p.arena_cap = arena1 * as;
     uint64_t tc = (64ull * n_windows + 1024) * scale, mc = (2048ull * n_windows + 4096) * scale;
     if (const char* v = CW_AID_ENV("CW_PLAN_DIV")) { const long x = atol(v); if (x >= 2) { tc = tc / (uint64_t)x + 1; mc = mc / (uint64_t)x + 1; } } /* test aid: a first plan that is too small, so that the growth of cw_run / cw_run_device_sync is exercised */
     p.task_cap = (uint32_t)(tc > 0x7FFFFFFFull ? 0x7FFFFFFFull : tc);
@@ -410,7 +416,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     CW_HIP(hipMemsetAsync(sc.over_list[3], 0xFF, (size_t)p.task_cap * 4, st)); /* live queue: an entry is its own flag */
     sid = stage_begin(e, st, "setup");
     cw_setup_need_kernel<<<(batch->n_windows + 3) / 4, 256, 0, st>>>(db, sc, e->prm);
-    cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap, e->cap_scale);
+    cw_setup_kernel<<<1, 1024, 0, st>>>(db, sc, e->prm, p.solid_cap, p.seg_cap, p.arena_cap, p.arena_scale);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "index");
     {
@@ -457,15 +463,13 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         sid = stage_begin(e, e->side[1], "poa_m2");
         cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
         stage_end(e, e->side[1], sid);
+#ifdef CW_TEST_AIDS
         if (wgs_h) {
             sid = stage_begin(e, e->side[0], "poa_h");
-#ifdef CW_TEST_AIDS
-    #ifdef CW_TEST_AIDS
-        cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
-#endif
-#endif
+            cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
             stage_end(e, e->side[0], sid);
         }
+#endif
         sid = stage_begin(e, e->side[0], "poa_m1");
         cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
         stage_end(e, e->side[0], sid);
@@ -487,13 +491,13 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, e->side[1], "poa_m2");
     cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
     stage_end(e, e->side[1], sid);
+#ifdef CW_TEST_AIDS
     if (wgs_h) { /* tier H shares tier M1's stream (a stream of its own would be a fifth hardware queue per engine): H first, then what is left for M1 */
         sid = stage_begin(e, e->side[0], "poa_h");
-#ifdef CW_TEST_AIDS
         cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
-#endif
         stage_end(e, e->side[0], sid);
     }
+#endif
     sid = stage_begin(e, e->side[0], "poa_m1");
     cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
@@ -932,7 +936,7 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     sl.o_slen = put((size_t)W * 4);
     sl.o_pc = put(sl.cons_cap); sl.o_ps = put(sl.solid_cap * 4); /* the compacted copies */
     const size_t o_pco = put((size_t)(W + 1) * 8), o_pso = put((size_t)(W + 1) * 8);
-    sl.o_tot = put(16);
+    sl.o_tot = put(24);
     sl.o_cons = o_cons; sl.o_solid = o_solid;
     const size_t out_bytes = o;
     int rc = ensure(&sl.dev_in, &sl.dev_in_bytes, in_bytes);
@@ -969,6 +973,7 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     pa.solid = dr.solid; pa.solid_off = dr.solid_off; pa.solid_len = dr.solid_len;
     pa.pc = (char*)(dout + sl.o_pc); pa.ps = (uint32_t*)(dout + sl.o_ps);
     pa.pc_off = (uint64_t*)(dout + o_pco); pa.ps_off = (uint64_t*)(dout + o_pso); pa.totals = (uint64_t*)(dout + sl.o_tot);
+    pa.win = (const WinInfo*)e->scratch; /* this batch's: the pack kernels follow its finish kernel on the compute stream */
     cw_pack_scan_kernel<<<1, 1024, 0, st>>>(pa);
     cw_pack_copy_kernel<<<(W + 3) / 4, 256, 0, st>>>(pa);
     CW_HIP(hipGetLastError());
@@ -978,7 +983,12 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     return CW_OK;
 }
 
-int cw_wait(cw_engine* e, int ticket) {
+static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks);
+int cw_wait(cw_engine* e, int ticket) { return wait_ticket(e, ticket, nullptr); }
+
+/* why_tasks (may be NULL): how many windows of THIS ticket stopped on the batch's task / member / arena capacities */
+static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks) {
+    if (why_tasks) *why_tasks = 0;
     if (!e || ticket < 0 || ticket >= CW_SLOTS) return CW_E_INVALID;
     cw_slot& sl = e->slot[ticket];
     {
@@ -994,15 +1004,16 @@ int cw_wait(cw_engine* e, int ticket) {
     const cw_result& r = sl.res;
     uint8_t* dout = (uint8_t*)sl.dev_out;
     hipStream_t co = e->copy_out;
-    uint64_t tot[2] = {0, 0};
+    uint64_t tot[3] = {0, 0, 0};
     int rc = CW_OK;
-    if (hipMemcpyAsync(tot, dout + sl.o_tot, 16, hipMemcpyDeviceToHost, co) != hipSuccess ||
+    if (hipMemcpyAsync(tot, dout + sl.o_tot, 24, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.cons_len, dout + sl.o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.win_status, dout + sl.o_stat, W, hipMemcpyDeviceToHost, co) != hipSuccess ||
         (sl.want_solid && hipMemcpyAsync(r.solid_len, dout + sl.o_slen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess) ||
         hipStreamSynchronize(co) != hipSuccess)
         return fail(CW_E_NO_DEVICE);
     if (tot[0] > sl.cons_cap || tot[1] > sl.solid_cap) return fail(CW_E_INTERNAL);
+    if (why_tasks) *why_tasks = tot[2];
     const size_t need = align_up(tot[0], 256) + tot[1] * 4 + 256;
     if (sl.pin_out_bytes < need) {
         if (sl.pin_out) (void)hipHostFree(sl.pin_out);
@@ -1035,54 +1046,122 @@ int cw_wait(cw_engine* e, int ticket) {
 }
 
 /* After a finished run: did windows stop on a capacity that a larger scratch plan cures (CW_WHY_TASKS: the task, member and arena slots are
-   heuristics of the batch)?  Then the plan grows (x4, up to x64) and the caller runs the batch again. */
-static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st) {
+   heuristics of the batch)?  Then the plan grows (x4, up to x64) and the caller runs the batch again -- if the larger plan is one the engine can
+   actually run: inside the 32-bit offsets (plan_scratch clamps the arena's own scale) and inside the device's free memory.  A scale that is not
+   is refused here, and the run that has finished stands with its overflow statuses (it used to end the batch with CW_E_INVALID or
+   CW_E_NOMEM).  known_any: -1 = look at the last run's WinInfo in scratch (cw_run_device_sync: the caller has just waited for that very run);
+   0 / 1 = the caller knows from its own ticket whether such windows exist (cw_run: scratch may already belong to another thread's batch). */
+static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int known_any, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words) {
     *again = false;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (!e->scratch || e->last_windows == 0 || e->cap_scale >= 64u) return CW_OK;
+    if (!e->scratch || n_windows == 0 || e->cap_scale >= 64u) return CW_OK;
     if (CW_AID_ENV("CW_TASK_CAP") || CW_AID_ENV("CW_MEMBER_CAP")) return CW_OK; /* (test aids that shrink exactly these capacities) */
     CW_HIP(hipSetDevice(e->device));
-    /* copies on the caller's stream, not hipMemcpy: the null stream would wait for every other stream of the device -- the other worker's job */
-    uint32_t* flag = e->host_fb + 8; /* pinned */
-    CW_HIP(hipMemcpyAsync(flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost, st));
-    CW_HIP(hipStreamSynchronize(st));
-    if (!*flag) return CW_OK;
-    std::vector<WinInfo> wi(e->last_windows);
-    CW_HIP(hipMemcpyAsync(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost, st));
-    CW_HIP(hipStreamSynchronize(st));
-    bool any = false; /* (windows stopped for other reasons stay stopped: the loop ends when no window names these capacities, or at x64) */
-    for (const WinInfo& w : wi) any = any || (w.status == CW_WIN_OVERFLOW && w.pad_ == CW_WHY_TASKS);
-    if (any) {
-        e->cap_scale *= 4u; *again = true;
-        fprintf(stderr, "[consent_amd] windows stopped on the batch's task / member / arena capacities: running the batch again with the plan x%u\n", e->cap_scale);
+    bool any = known_any > 0;
+    if (known_any < 0) {
+        if (e->last_windows != n_windows) return CW_OK;
+        /* copies on the caller's stream, not hipMemcpy: the null stream would wait for every other stream of the device -- the other worker's job */
+        uint32_t* flag = e->host_fb + 8; /* pinned */
+        CW_HIP(hipMemcpyAsync(flag, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, any_overflow), 4, hipMemcpyDeviceToHost, st));
+        CW_HIP(hipStreamSynchronize(st));
+        if (!*flag) return CW_OK;
+        std::vector<WinInfo> wi(e->last_windows);
+        CW_HIP(hipMemcpyAsync(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost, st));
+        CW_HIP(hipStreamSynchronize(st));
+        /* (windows stopped for other reasons stay stopped: the loop ends when no window names these capacities, or at x64) */
+        for (const WinInfo& w : wi) any = any || (w.status == CW_WIN_OVERFLOW && w.pad_ == CW_WHY_TASKS);
     }
+    if (!any) return CW_OK;
+    const uint32_t next = e->cap_scale * 4u;
+    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, next);
+    size_t free_b = 0, total_b = 0;
+    const bool mem_known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (!mem_known) (void)hipGetLastError();
+    const size_t margin = (size_t)2 << 30; /* other engines of the device grow too */
+    const bool fits = p.solid_cap <= 0xFFFFFFFFull && p.seg_cap <= 0xFFFFFFFFull && p.arena_cap <= 0xFFFFFFFFull &&
+                      (!mem_known || p.total <= e->scratch_bytes || p.total - e->scratch_bytes + margin <= free_b);
+    if (!fits) {
+        fprintf(stderr, "[consent_amd] windows stopped on the batch's task / member / arena capacities; a plan x%u (%.1f GB) does not fit this device now: keeping the run's result\n",
+                next, (double)p.total / 1e9);
+        return CW_OK;
+    }
+    e->cap_scale = next; *again = true;
+    fprintf(stderr, "[consent_amd] windows stopped on the batch's task / member / arena capacities: running the batch again with the plan x%u\n", e->cap_scale);
     return CW_OK;
+}
+
+/* A grown plan is not forever: after a run at scale > 1 that used less than half of what the next smaller plan offers, the
+   scale goes back a step; scratch that has become three times what the smaller plan needs is given back to the device. */
+static void decay_scale(cw_engine* e, hipStream_t st, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->cap_scale <= 1u || !e->scratch || e->last_windows != n_windows) return;
+    if (hipSetDevice(e->device) != hipSuccess) return;
+    uint32_t* used = e->host_fb + 10; /* pinned: n_tasks, n_members */
+    if (hipMemcpyAsync(used, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
+    const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale / 4u);
+    if ((uint64_t)used[0] * 2u > lower.task_cap || (uint64_t)used[1] * 2u > lower.member_cap) return;
+    e->cap_scale /= 4u;
+    if (e->scratch_bytes > 3 * lower.total + ((size_t)1 << 30)) { /* nothing of this engine is in flight: the caller has just waited for its stream */
+        if (hipFree(e->scratch) != hipSuccess) (void)hipGetLastError();
+        e->scratch = nullptr; e->scratch_bytes = 0;
+    }
 }
 
 /* cw_run_device, then wait for the stream, then -- when windows stopped on the batch's task / member / arena capacities only -- once more
    with a larger plan (cw_private.h; what the native driver and cw_run call: the asynchronous cw_run_device cannot look at its own result) */
 int cw_run_device_sync(cw_engine* e, const cw_batch* batch, const cw_result* res, void* hip_stream) {
+    if (!e || !batch) return CW_E_INVALID;
+    bool grown = false;
+    uint32_t scale_before = 1;
     for (;;) {
         int rc = cw_run_device(e, batch, res, hip_stream);
-        if (rc != CW_OK) return rc;
+        if (rc != CW_OK) {
+            if (grown && (rc == CW_E_INVALID || rc == CW_E_NOMEM)) { /* the larger plan could not be set up after all (memory went to another engine meanwhile):
+                                                                         no kernel of the re-run was launched, the run before it stands, the scale goes back */
+                std::lock_guard<std::mutex> lk(e->mu);
+                e->cap_scale = scale_before;
+                return CW_OK;
+            }
+            return rc;
+        }
         CW_HIP(hipSetDevice(e->device));
-        CW_HIP(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream));
+        hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+        CW_HIP(hipStreamSynchronize(st));
         bool again = false;
-        if ((rc = grow_if_that_helps(e, &again, hip_stream ? (hipStream_t)hip_stream : e->stream)) != CW_OK) return rc;
-        if (!again) return CW_OK;
+        { std::lock_guard<std::mutex> lk(e->mu); scale_before = e->cap_scale; }
+        if ((rc = grow_if_that_helps(e, &again, st, -1, batch->n_windows, batch->n_seqs, batch->n_words)) != CW_OK) return rc;
+        if (!again) {
+            if (!grown) decay_scale(e, st, batch->n_windows, batch->n_seqs, batch->n_words);
+            return CW_OK;
+        }
+        grown = true;
     }
 }
 
 int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
+    bool grown = false;
+    uint32_t scale_before = 1;
+    int first_rc = CW_OK;
     for (;;) {
         int t = -1;
         int rc = cw_submit(e, b, r, &t);
-        if (rc != CW_OK) return rc;
-        const int wrc = cw_wait(e, t);
+        if (rc != CW_OK) {
+            if (grown && (rc == CW_E_INVALID || rc == CW_E_NOMEM)) { std::lock_guard<std::mutex> lk(e->mu); e->cap_scale = scale_before; return first_rc; } /* see cw_run_device_sync */
+            return rc;
+        }
+        uint64_t why_tasks = 0;
+        const int wrc = wait_ticket(e, t, &why_tasks);
         if (wrc != CW_OK && wrc != CW_E_CAPACITY) return wrc;
         bool again = false;
-        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again, e->stream)) != CW_OK) return rc;
+        { std::lock_guard<std::mutex> lk(e->mu); scale_before = e->cap_scale; }
+        /* the decision comes from this ticket's own totals (cw_pack_scan_kernel counts the windows stopped on CW_WHY_TASKS): other threads may have
+           submitted since, and the WinInfo in scratch may be theirs */
+        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again, e->stream, why_tasks ? 1 : 0, b->n_windows, b->n_seqs, b->n_words)) != CW_OK) return rc;
         if (!again) return wrc;
+        grown = true; first_rc = wrc;
     }
 }
 

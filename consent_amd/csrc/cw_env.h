@@ -1,5 +1,5 @@
-/* cw_env.h -- environment switches.  The product library reads nine of them (devices, threads, what to do on a
-   capacity, statistics / timing / profile / task trace on stderr); the test aids (shrunken capacities, dry run, ...) and the experiment knobs
+/* cw_env.h -- environment switches.  The product library reads ten of them (devices, workers and host threads,
+   the PAF block size, what to do on a capacity, statistics / timing / profile / task trace on stderr; tests/test_docs_env.py counts them); the test aids (shrunken capacities, dry run, ...) and the experiment knobs
    (work-groups per CU and tier, routing bounds, opt-in kernels) exist only in a -DCW_TEST_AIDS build of the same sources (consent_amd/aids/,
    built beside the product by consent_amd/_build.py): in the product they are constants, and a stray variable in a user's environment changes
    nothing. */

@@ -27,18 +27,22 @@ struct PackArgs {
     uint32_t* ps;      /* packed solid k-mers    */
     uint64_t* pc_off;  /* [n_windows + 1]        */
     uint64_t* ps_off;  /* [n_windows + 1]        */
-    uint64_t* totals;  /* [0] consensus bytes, [1] solid k-mers */
+    uint64_t* totals;  /* [0] consensus bytes, [1] solid k-mers, [2] windows stopped on the batch's task / member / arena capacities (CW_WHY_TASKS) */
+    const WinInfo* win; /* the batch's per-window records in the engine's scratch (read for [2] only) */
 };
 
 __global__ void __launch_bounds__(1024) cw_pack_scan_kernel(PackArgs a) {
     __shared__ unsigned long long pa[1024], pb[1024];
     __shared__ unsigned long long run[2];
+    __shared__ unsigned int why_tasks;
     const int tid = threadIdx.x;
     if (tid < 2) run[tid] = 0;
+    if (tid == 0) why_tasks = 0;
     __syncthreads();
     for (uint32_t w0 = 0; w0 < a.n_windows; w0 += 1024) {
         const uint32_t w = w0 + tid;
         const bool live = w < a.n_windows && a.win_status[w] != CW_WIN_OVERFLOW;
+        if (w < a.n_windows && !live && a.win[w].status == CW_WIN_OVERFLOW && a.win[w].pad_ == CW_WHY_TASKS) atomicAdd(&why_tasks, 1u);
         const unsigned long long c = live ? a.cons_len[w] : 0, s = (live && a.solid) ? a.solid_len[w] : 0;
         pa[tid] = c; pb[tid] = s;
         __syncthreads();
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(1024) cw_pack_scan_kernel(PackArgs a) {
         if (tid == 0) { run[0] += pa[1023]; run[1] += pb[1023]; }
         __syncthreads();
     }
-    if (tid == 0) { a.pc_off[a.n_windows] = run[0]; a.ps_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; }
+    if (tid == 0) { a.pc_off[a.n_windows] = run[0]; a.ps_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; a.totals[2] = why_tasks; }
 }
 
 __global__ void __launch_bounds__(256) cw_pack_copy_kernel(PackArgs a) {

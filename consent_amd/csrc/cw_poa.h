@@ -118,6 +118,8 @@
 #define CW_RM_LIN(m) (((m) & 4u) != 0u)
 #define CW_RM_X(m) (int)((m) >> 19)
 #define CW_RM_MAX_PRED 2047u
+static_assert(CW_POAB_EC <= 8192 && CW_POAL_EC <= 8192 && CW_POAM2_EC <= 8192 && CW_POAM1_EC <= 8192 && CW_POA_EC <= 8192, "the row word's x field (13 bits) holds a list offset < EC or a DP row <= NC");
+static_assert(CW_POAB_NC <= 8191 && CW_POAL_NC <= 8191, "the row word's x field (13 bits) holds a DP row <= NC");
 #define CW_RM_WORD(base, np, lin, sink, kind, x) ((uint32_t)(base) | ((lin) ? 4u : 0u) | ((sink) ? 8u : 0u) | ((uint32_t)(kind) << 5) | ((uint32_t)(np) << 8) | ((uint32_t)(x) << 19))
 template <typename HT>
 struct PoaMem {
@@ -667,7 +669,8 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     if (CM != 0 && !lin_ && np_ <= 3u && first != 0 && !far_) kind_ = np_;
                     M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, lin_, !M.has_out[node], kind_, np_ == 1u ? first : off);
                 }
-                if (__ballot(r < n && (uint32_t)d > CW_RM_MAX_PRED) != 0ull) return 2; /* more in-edges than the row word counts (cannot happen below 8192 members) */
+                if (__ballot(r < n && (uint32_t)d > CW_RM_MAX_PRED) != 0ull) return 2; /* more in-edges than the row word's 11 bits count: a node needs more than 2047 distinct sources for that
+                                                                                      (members > 2047; tier G then reports rc 2 and the window stops on CW_WHY_POA) */
                 run += cw_lane_value(inc, 63);
             }
             meta_ok = true;

@@ -20,9 +20,22 @@
 /* Global (Needleman-Wunsch) alignment of each segment string against the partial-order graph:   */
 /* segments are cut at shared anchors, so both ends are pinned and a global mode is the natural  */
 /* choice.  Linear gap model.  Scores are spoa's command-line defaults (m=5, n=-4, g=-8).        */
+/* Overridable at build time on BOTH sides (-DCW_POA_MATCH=2 -DCW_POA_MISMATCH=-4 -DCW_POA_GAP=-4 ...): spoa's library defaults differ   */
+/* between its versions, and the version BMEAN bundles is unknown.  Everything in the engine is derived from these three (the recorded-   */
+/* decision fill's scaled constants 4 * (MATCH - GAP), 4 * (MISMATCH - GAP), 4 * GAP included); tests/test_gpu_policy.py builds both      */
+/* sides with another triple.  Bounds: the int16 tiers keep |score| <= 8 * (nodes + columns) inside 15 bits.                              */
+#ifndef CW_POA_MATCH
 #define CW_POA_MATCH      5
+#endif
+#ifndef CW_POA_MISMATCH
 #define CW_POA_MISMATCH (-4)
+#endif
+#ifndef CW_POA_GAP
 #define CW_POA_GAP      (-8)
+#endif
+#if CW_POA_GAP >= 0 || CW_POA_GAP < -8 || CW_POA_MATCH <= 0 || CW_POA_MATCH > 8 || CW_POA_MISMATCH > 0 || CW_POA_MISMATCH < -8 || CW_POA_MATCH <= CW_POA_MISMATCH
+#error "cw_policy.h: CW_POA_MATCH in 1..8, CW_POA_MISMATCH in -8..0, CW_POA_GAP in -8..-1 (linear gap, int16 DP tiers)"
+#endif
 
 /* Traceback preference at a cell (spoa sisd engine order): diagonal through the in-edges in     */
 /* insertion order, then vertical (graph node against a gap) through the in-edges in insertion   */

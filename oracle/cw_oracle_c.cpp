@@ -62,11 +62,11 @@ int cwo_run(const cw_params* p, const cw_batch* b, const cw_result* r, uint64_t*
                 rc = CW_E_CAPACITY;
                 continue;
             }
-            memcpy(r->cons + r->cons_off[w], res.consensus.data(), res.consensus.size());
+            if (!res.consensus.empty()) memcpy(r->cons + r->cons_off[w], res.consensus.data(), res.consensus.size());
             r->cons_len[w] = (uint32_t)res.consensus.size();
             r->win_status[w] = (uint8_t)res.status;
             if (r->solid) {
-                memcpy(r->solid + r->solid_off[w], solid.data(), solid.size() * 4);
+                if (!solid.empty()) memcpy(r->solid + r->solid_off[w], solid.data(), solid.size() * 4); /* (an empty vector's data() may be null: UB for memcpy, found by `make asan`) */
                 r->solid_len[w] = (uint32_t)solid.size();
             }
         }

@@ -136,6 +136,20 @@ def test_two_and_three_engines_write_the_same_fasta_as_one(tmp_path):
     assert '"workers": 2' in err  # counters on stderr, stdout stays pure FASTA
 
 
+def test_eight_logical_devices_write_the_same_fasta_as_one_engine(tmp_path):
+    """What an 8-GPU node runs, on the one GPU of the box: with the test aid CW_VIRTUAL_DEVICES=8 (the -DCW_TEST_AIDS build) the
+    driver sees eight devices -- `-j 8` gives it eight read-set uploads, its own choice of workers per device (here 2 x 8 = 16 engines), the job
+    size and queue of eight devices -- and the FASTA is byte for byte the one-engine FASTA, in PAF order (CONSENT-correction.cpp:77-119)."""
+    fa, paf = make_dataset(tmp_path, 45, n_reads=60)
+    argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 500, "-k", 9, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 8, "-r", fa, "-M", 150, "-p", "x"]
+    one, _ = run_bin("CONSENT-correction", argv, env={"CW_DEVICES": "0"})
+    aids = {"LD_LIBRARY_PATH": os.path.join(ROOT, "consent_amd", "aids"), "CW_VIRTUAL_DEVICES": "8", "CW_WORKERS_PER_DEVICE": "2", "CW_JOB_WINDOWS": "6", "CW_DRIVER_STATS": "1"}
+    eight, err = run_bin("CONSENT-correction", argv, env=aids)
+    assert len(one) > 20000 and eight == one
+    assert '"workers": 16' in err and '"workers_per_device": 2' in err
+    assert all(f'"device": {d},' in err for d in range(8))  # every logical device has a worker in the statistics
+
+
 def test_polishing_a_contig_sharded_over_engines(tmp_path):
     ctg, fa, paf = make_polishing_dataset(tmp_path, 44)
     prm = dict(min_support=1, max_support=20000, window_size=500, mer_size=9, common_kmers=8, min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150)

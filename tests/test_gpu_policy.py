@@ -94,3 +94,22 @@ def test_overlap_alignment_mode_is_implemented_on_both_sides(tmp_path):
     assert digest_default != digest_ov
     mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     assert not mixed
+
+
+@pytest.mark.timeout(1500)
+def test_other_alignment_scores_are_honoured_by_engine_and_oracle(tmp_path):
+    """-DCW_POA_MATCH=2 -DCW_POA_MISMATCH=-4 -DCW_POA_GAP=-4 (cw_policy.h: the three scores are build-time values on both sides since round 5;
+    every derived constant of the engine -- the recorded-decision fill's scaled scores, the packed fills' score pairs, tier Q's -- follows
+    them).  The two sides agree window by window under those scores, the consensus is not the default scores', and mixing the sides disagrees."""
+    from consent_amd import _build
+
+    sc = ["-DCW_POA_MATCH=2", "-DCW_POA_MISMATCH=-4", "-DCW_POA_GAP=-4"]
+    alt_lib = str(tmp_path / "libconsent_amd_sc.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sc, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(sc)])
+    same_default, digest_default = run_child({})
+    same_sc, digest_sc = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_sc
+    assert digest_default != digest_sc
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed
