@@ -526,6 +526,7 @@ def main():
         if prof_whole:  # from the SQ counter passes of the same command with one engine (profiles/latest_*.json, tools/summarize_r03.py)
             out["secondary"]["valu_issue_frac"] = prof_whole.get("valu_issue_frac")
             out["secondary"]["lds_bw_frac"] = prof_whole.get("lds_busy_frac")
+            out["secondary"]["valu_lane_util"] = prof_whole.get("valu_lane_util")  # SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), whole step (pass 3)
             out["secondary"]["counters_source"] = traffic_src
         # parity spot-check of the same windows on the GPU
         got = eng.run(hb.slice(0, n_st))

@@ -133,6 +133,7 @@ struct DevScratch {
     uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
+    uint8_t* q_slab;               /* tier Q (cw_poa_q.h): per resident task CW_POAQ_SLAB_BYTES of kept DP rows */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
     uint32_t s_route_cells;        /* tier S takes a task whose graph is expected to stay below this many nodes (its capacity is CW_POA_NC; a task that outgrows
                                       it is redone in tier L, late).  (Until round 3: a bound on the cells of its LDS matrix, hence the name.) */

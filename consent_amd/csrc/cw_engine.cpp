@@ -27,7 +27,7 @@ namespace {
 static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(4 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840 || CW_M2_CHAIN_TABS || CW_M2_CODES, "tier M2: four work-groups per CU");
-static_assert(CW_POAL_WAVES * CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
+static_assert(CW_POAL_LDS_BYTES <= (CW_POAL_MW > 1 ? 61440 : 40960), "tier L: a work-group fits the hole an M1/M2 work-group leaves (one wave), or a third of a CU (several waves, cw_poa_w.h)");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -47,7 +47,7 @@ size_t big_slab_bytes() {
    CW_WGS_S / _M1 / _M2 / _L override (experiments). */
 struct TierMix { uint32_t s, m1, m2, l; };
 TierMix tier_mix(bool deep) {
-    TierMix m = deep ? TierMix{4, 5, 4, 2} : TierMix{4, 5, 4, 2}; /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
+    TierMix m = deep ? TierMix{4, 5, 4, CW_POAL_MW > 1 ? 1u : 2u} : TierMix{4, 5, 4, CW_POAL_MW > 1 ? 1u : 2u}; /* (tier L, round 5: one four-wave work-group of 56 KB per CU instead of two one-wave ones of 37) */ /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
     auto knob = [](const char* name, uint32_t dflt) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 12 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
     if (m.s > 6) m.s = 6;
@@ -82,7 +82,7 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], qslab, pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap, arena_scale;
@@ -125,6 +125,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     for (int t = 0; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4); /* list 0 = tier Q */
     for (int t = 0; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 0; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
+    put(p.qslab, (size_t)cus * CW_POAQ_WAVES * 4 * CW_POAQ_SLAB_BYTES); /* tier Q: kept rows of every task a CU can hold (32) */
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
@@ -189,13 +190,13 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POAL_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC, CW_POAM2_WAVES, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) != hipSuccess ||
+                            CW_POAL_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
 #ifdef CW_TEST_AIDS
@@ -392,6 +393,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (CW_AID_ENV("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
     sc.use_q = CW_AID_ENV("CW_NO_TIER_Q") ? 0u : 1u;
+    sc.q_slab = base + p.qslab;
     for (int t = 0; t < CW_TIERS; ++t) {
         if (t) { sc.tier_list[t] = (uint32_t*)(base + p.list[t]); sc.over_list[t] = (uint32_t*)(base + p.over[t]); }
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
@@ -408,7 +410,8 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
 #define L_ARGS CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3
     const size_t lds_m1 = CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
     const size_t lds_m2 = CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
-    const size_t lds_l = CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES;
+    const size_t lds_l = CW_POAL_LDS_BYTES;
+    const uint32_t thr_l = 64 * CW_POAL_WAVES * CW_POAL_MW; /* tier L: one task per work-group, its wide rows on CW_POAL_MW waves (cw_poa_w.h) */
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
@@ -442,7 +445,10 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const uint32_t sort_lds = knob_u("CW_SORT_LDS", 16384, 0, CW_SORT_LDS_CLS);
     const uint32_t sort_thr = knob_u("CW_SORT_THREADS", 256, 128, 1024) / 64 * 64;
     const uint32_t q_waves = knob_u("CW_Q_WAVES", 2, 1, CW_POAQ_WAVES);          /* waves per tier-Q work-group (four tasks per wave) */
-    const uint32_t q_per_cu = knob_u("CW_Q_WGS_PER_CU", CW_POAQ_WAVES / q_waves, 1, CW_POAQ_WAVES / q_waves);
+    const uint32_t q_lds_cu = e->prop.sharedMemPerMultiprocessor ? (uint32_t)e->prop.sharedMemPerMultiprocessor : 160u * 1024u;
+    const uint32_t q_fit = q_lds_cu / (uint32_t)(CW_POAQ_TASK_BYTES * 4 * q_waves);   /* work-groups whose LDS a CU holds */
+    const uint32_t q_most = q_fit < CW_POAQ_WAVES / q_waves ? (q_fit ? q_fit : 1u) : CW_POAQ_WAVES / q_waves;
+    const uint32_t q_per_cu = knob_u("CW_Q_WGS_PER_CU", q_most, 1, q_most);
     const uint32_t q_grid = (uint32_t)cus * q_per_cu;
     const uint32_t pass1_wgs = knob_u("CW_PASS1_WGS", 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u, 1, 64u < (uint32_t)cus * 2u ? 64u : (uint32_t)cus * 2u);
     const uint32_t big_cap = p.tier[4].slots / CW_POA_WAVES;
@@ -478,7 +484,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         stage_end(e, st, sid);
         for (int i = 0; i < 2; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
         sid = stage_begin(e, st, "poa_large");
-        cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
+        cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, thr_l, lds_l, st>>>(db, sc);
         stage_end(e, st, sid);
     } else {
     CW_HIP(hipEventRecord(e->ev_fork, st));
@@ -486,7 +492,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     /* tier L also consumes the live overflow queue; only sc.linger_wgs of its work-groups stay for that (far fewer than
        CUs, so they can never keep the producers they wait for off the machine) */
     sid = stage_begin(e, e->side[2], "poa_large");
-    cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, 64 * CW_POAL_WAVES, lds_l, e->side[2]>>>(db, sc);
+    cw_poa_slab_kernel<L_ARGS, 0><<<grid_l, thr_l, lds_l, e->side[2]>>>(db, sc);
     stage_end(e, e->side[2], sid);
     sid = stage_begin(e, e->side[1], "poa_m2");
     cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
@@ -518,7 +524,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
     sid = stage_begin(e, st, "poa_overflow");
-    cw_poa_slab_kernel<L_ARGS, 1><<<pass1_wgs, 64 * CW_POAL_WAVES, lds_l, st>>>(db, sc);
+    cw_poa_slab_kernel<L_ARGS, 1><<<pass1_wgs, thr_l, lds_l, st>>>(db, sc);
     cw_poa_big_kernel<<<big_wgs, 64 * CW_POA_WAVES, 0, st>>>(db, sc);
     stage_end(e, st, sid);
     sid = stage_begin(e, st, "finish");

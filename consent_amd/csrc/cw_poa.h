@@ -86,6 +86,10 @@
 /* LDS per wave of slab tier T (1 = M1, 2 = M2): the ring and the flags only where the recorded-decision fill runs (tier M2 carried their 2.1 KB
    per wave unused until round 4: LDS is what the tiers compete for) */
 #define CW_POA_HOTC_OF_TIER(T) ((T) == 1 || CW_M2_CODES)
+#ifndef CW_M2_DIRS
+#define CW_M2_DIRS 0 /* 1: tier M2 writes tier L's direction words (in its slab, where tier M1 keeps code words) and walks them run by run instead of reading 8x8 tiles of
+                        the matrix back: its traceback costs as many wave-cycles as its fill (15.0 against 16.5 G per depth-150 batch), tier L's a quarter */
+#endif
 #ifndef CW_M2_CHAIN_TABS
 #define CW_M2_CHAIN_TABS 0 /* 1: tier M2 keeps the traceback's chain tables p2 / p4 in LDS (2 KB per wave: a tile's eight rows in three dependent reads instead of
                               seven).  Without them its work-group is 38.6 KB -- the size of M1's, L's and Q's: any four fit a CU -- and the two-engine step 1.8 ms
@@ -121,6 +125,7 @@
 static_assert(CW_POAB_EC <= 8192 && CW_POAL_EC <= 8192 && CW_POAM2_EC <= 8192 && CW_POAM1_EC <= 8192 && CW_POA_EC <= 8192, "the row word's x field (13 bits) holds a list offset < EC or a DP row <= NC");
 static_assert(CW_POAB_NC <= 8191 && CW_POAL_NC <= 8191, "the row word's x field (13 bits) holds a DP row <= NC");
 #define CW_RM_WORD(base, np, lin, sink, kind, x) ((uint32_t)(base) | ((lin) ? 4u : 0u) | ((sink) ? 8u : 0u) | ((uint32_t)(kind) << 5) | ((uint32_t)(np) << 8) | ((uint32_t)(x) << 19))
+struct PoaComm; /* cw_poa_w.h: mailbox and boundary words of a multi-wave tier-L work-group */
 template <typename HT>
 struct PoaMem {
     HT* H;
@@ -164,6 +169,7 @@ struct PoaMem {
     unsigned long long* diag; /* diagnostic build: ten counters of this tier in BatchCounters::prof (rows / linear rows / far loads / predecessor trips of the
                                  unpacked fill, rows / linear / far loads of the packed fill, traceback trips, slow steps, members) */
 #endif
+    PoaComm* comm;      /* cw_poa_w.h: non-NULL in a tier-L work-group of several waves (this is wave 0, the others serve its FILL commands) */
     bool pad64;         /* the matrix is in a slab with 64 cells of slack behind it: rows of <= 64 columns are stored and loaded by all 64 lanes
                            (no execution mask round the store of a row, no mask round a far row's load; see poa_fill) */
 };
@@ -202,7 +208,7 @@ __device__ __forceinline__ PoaMem<HT> poa_carve(uint8_t* base, uint32_t nc, uint
     else { M.nbase = p; p += nc; M.nalc = p; p += nc; M.has_out = p; p += nc; }
     M.sq = p; p += lc + 1;
     M.n_cap = nc; M.e_cap = ec; M.l_cap = lc; M.h_cap = hc; M.d_cap = dc; M.runs = false; M.pad64 = false;
-    M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0; M.lcodes = nullptr; M.lc_cap = 0;
+    M.codes = nullptr; M.ring = nullptr; M.gflag = nullptr; M.c_cap = 0; M.lcodes = nullptr; M.lc_cap = 0; M.comm = nullptr;
 #ifdef CW_DIAG
     M.diag = nullptr;
 #endif
@@ -499,6 +505,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
 }
 
 #include "cw_poa_c.h"
+#include "cw_poa_w.h"
 
 /* One traceback step at a node with several predecessors (or whose step the direction words left open), decided from the cell
  * values in the order of preference of cw_policy.h: diagonal through the in-edges in order, then vertical through them, then
@@ -716,7 +723,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         if constexpr (PK != 0) {
             if (!packed) {
                 if (cols <= 64) { if (pad) poa_fill<HT, 1, PK == 2, true>(M, n, cols, lane, use_dirs); else poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs); }
-                else if constexpr (PK == 2) { /* a very large graph in tier L: one column per lane */
+                else if constexpr (PK == 2 && LCAP > 511) { /* a very large graph in tier L: one column per lane */
                     if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
                     else if (cols <= 256) poa_fill<HT, 4, PK == 2>(M, n, cols, lane, use_dirs);
                     else if (cols <= 512) poa_fill<HT, 8, PK == 2>(M, n, cols, lane, use_dirs);
@@ -724,11 +731,12 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                 }
             }
             else if (cols <= 128) poa_fill_pk<1, PK == 2>(M, n, cols, hs, lane, use_dirs);
+            else if (PK == 2 && CW_POAL_MW > 1 && M.comm != nullptr) { if constexpr (PK == 2 && sizeof(HT) == 2) poa_fill_mw<true>(M, n, cols, hs, lane, use_dirs); } /* tier L: the chunks of the row on the waves of the work-group (cw_poa_w.h) */
             else if constexpr (LCAP > 127) {
                 if (cols <= 256) poa_fill_pk<2, PK == 2>(M, n, cols, hs, lane, use_dirs);
                 else if constexpr (LCAP > 255) {
                     if (cols <= 512) poa_fill_pk<4, PK == 2>(M, n, cols, hs, lane, use_dirs);
-                    else if constexpr (PK == 2) poa_fill_pk<8, PK == 2>(M, n, cols, hs, lane, use_dirs);
+                    else if constexpr (PK == 2 && LCAP > 511) poa_fill_pk<8, PK == 2>(M, n, cols, hs, lane, use_dirs);
                 }
             }
         } else {
@@ -739,7 +747,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             else poa_fill<HT, 16, PK == 2>(M, n, cols, lane, use_dirs);
         }
         POA_PROF(1);
-        if (PK == 2 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
+        if (PK == 2 && LCAP > 511 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
 
         /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
         int bi, bj = L;
@@ -1276,11 +1284,17 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
 /* ---- tiers M1 / M2 / L: graph in LDS, DP matrix in this wave's global slab ------------------------ */
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
+#define CW_POAL_LDS_BYTES (CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES + (CW_POAL_MW > 1 ? CW_POA_COMM_BYTES : 0)) /* tier L's work-group */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES, TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
+__global__ void __launch_bounds__(64 * WAVES * (TIER == 3 ? CW_POAL_MW : 1), TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    /* tier L (round 5, cw_poa_w.h): ONE task per work-group, its wide rows on CW_POAL_MW waves -- wave 0 is "the" wave of the code below, the
+       others (mw_helper) serve its FILL commands and share its LDS arrays */
+    const int mw_wave = (TIER == 3 && CW_POAL_MW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wave = (TIER == 3 && CW_POAL_MW > 1) ? 0 : (int)(threadIdx.x >> 6);
+    PoaComm* const comm = (TIER == 3 && CW_POAL_MW > 1) ? (PoaComm*)(lds + CW_POA_HOT2L_BYTES(NC, EC, LC) * WAVES) : nullptr;
     /* Yielding persistence.  The four tier kernels run side by side and share each CU's LDS; a work-group that loops until its tier's
        list is empty keeps its LDS for the whole stage, so whichever kernel reaches a CU first owns it (measured: tier S held every CU
        for 27 ms of a depth-150 batch while the long tasks of tier L had not started).  Here only the LAST persist_wgs work-groups of
@@ -1288,7 +1302,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
        work-group of ANY tier: the mix on a CU follows the remaining work instead of the launch order.  A wave's slab is therefore
        not tied to its block index: it claims a free one (there are more slabs than waves the hardware can hold at once). */
     uint32_t gw = 0;
-    if (lane == 0) {
+    if (lane == 0 && mw_wave == 0) {
         const uint32_t n_slots = sc.slots[TIER];
         uint32_t s = (uint32_t)(((unsigned long long)(blockIdx.x * WAVES + wave) * 2654435761ull) % n_slots);
         for (;;) {
@@ -1297,7 +1311,9 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
             s = s + 1u == n_slots ? 0u : s + 1u;
         }
         gw = s;
+        if (comm) { comm->slab = s; comm->seq = 0u; comm->cmd = 0u; for (int x = 0; x < CW_POAL_MW; ++x) { comm->done[x] = 0u; comm->ready[x] = 0u; } }
     }
+    if (comm) { __syncthreads(); if (lane == 0) gw = comm->slab; } /* (the one barrier of the kernel: the helpers learn the slab) */
     gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gw);
     const bool yields = PASS == 0 && blockIdx.x + sc.persist_wgs[TIER] < gridDim.x;
     /* the slab is global memory: say so, or every access to the DP matrix is a flat_* instruction (both wait counters, aperture check) */
@@ -1307,7 +1323,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(NC, LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(NC, LC) + CW_POA_DSLAB_BYTES(NC, LC);
     constexpr uint32_t slab = TIER <= 2 ? CW_POA_HOT2T_BYTES(TIER, NC, EC, LC) : CW_POA_HOT2L_BYTES(NC, EC, LC);
-    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), TIER >= 3 ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
+    PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), (TIER >= 3 || (TIER == 2 && CW_M2_DIRS)) ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
                                            true, TIER == 1 || (TIER == 2 && (CW_M2_CHAIN_TABS || CW_M2_CODES)), TIER >= 3 && CW_L_COLD_NODES);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
     if (TIER <= 2 && CW_POA_HOTC_OF_TIER(TIER)) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
@@ -1315,7 +1331,8 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);
         M.codes = (uint32_t*)dslab; M.c_cap = (uint32_t)(CW_POA_DSLAB_BYTES(NC, LC) / 4);
     }
-    M.runs = TIER >= 3; /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
+    M.runs = TIER >= 3 || (TIER == 2 && CW_M2_DIRS); /* tier L: long graphs against short members, long vertical runs (direction words, whole runs per round trip) */
+    M.comm = comm;
 #ifdef CW_DIAG
     M.diag = &sc.ctr->prof[72 + 12 * TIER];
 #endif
@@ -1323,6 +1340,9 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
+    if constexpr (TIER == 3 && CW_POAL_MW > 1) {
+        if (mw_wave > 0) { poa_mw_serve<true>(M, lane, mw_wave); return; } /* until wave 0 posts EXIT */
+    }
 #ifndef CW_M2_PRIO
 #define CW_M2_PRIO 1
 #endif
@@ -1334,7 +1354,7 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         const unsigned long long _t0 = __builtin_readcyclecounter(), _w0 = wall_clock64();
         /* tier M2's rows are 85 % linear (long graphs, short members): there the matrix fill's 37-instruction row beats the recorded
            decisions' 52, and its slower traceback does not make up for it (measured: 35.8 against 38.5 G wave-cycles per batch) */
-        const int rc = poa_run<int16_t, (TIER < 3 ? 1 : 2), (TIER == 1 || (TIER == 2 && CW_M2_CODES) ? 2 : 0), LC>(M, t, b, sc, lane, acc);
+        const int rc = poa_run<int16_t, ((TIER < 3 && !(TIER == 2 && CW_M2_DIRS)) ? 1 : 2), (TIER == 1 || (TIER == 2 && CW_M2_CODES) ? 2 : 0), LC>(M, t, b, sc, lane, acc);
         const unsigned long long _t1 = __builtin_readcyclecounter();
         acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];
         if (lane == 0 && sc.task_dbg) { /* inspection aid (CW_TASK_TRACE): when each task of the slab tiers ran (10 ns units since the tier sort), where, and how it ended */
@@ -1398,6 +1418,11 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         }
     } else if (PASS == 1) {
         /* not used for tiers below L */
+    }
+    if (comm) { /* the helpers leave */
+        if (lane == 0) comm->cmd = CW_MW_CMD_EXIT;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) cww_store(&comm->seq, cww_load(&comm->seq) + 1u);
     }
     poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
     if (lane == 0) __hip_atomic_store(&sc.slot_busy[TIER][gw], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); /* the slab goes back */

@@ -1,31 +1,42 @@
 /*
  * cw_poa_q.h -- tier Q of the partial-order alignment (A4d): FOUR tasks per wavefront, one per 16-lane row.
  *
- * Most POA tasks are tiny: a deep pile is chained densely, so a segment between two anchors is 10-30 bases and its graph a few
- * dozen nodes (depth 150: 305 000 of the 372 000 tasks of a batch, median member length 14).  One wave per task (tier S) leaves
- * three quarters of the lanes of every DP row idle and spends the same instructions on a 14-column row as on a 128-column one.
- * Here a task owns a 16-lane DPP row: two DP columns per lane in packed int16 (members up to 31 bases), a four-step row_shr
- * prefix max (the row_bcast steps of the 64-lane ladder fall away), the same graph arrays as tier S in a quarter-size slab
- * (40 nodes / 120 edges, 4.7 KB per task).  The four tasks of a wave run the same instruction stream under their own
- * predicates -- every "wave-uniform" quantity of cw_poa.h (graph size, row, path position) is a per-lane value that is equal
- * inside a row -- so one instruction advances four alignments.
+ * Most POA tasks are small: a deep pile is chained densely, so a segment between two anchors is 10-30 bases and its graph a few
+ * dozen nodes.  One wave per task (tier S) leaves half to three quarters of the lanes of every DP row idle and spends the same
+ * instructions on a 14-column row as on a 64-column one.  Here a task owns a 16-lane DPP row: two DP columns per lane in packed
+ * int16 (members up to 31 bases), a four-step row_shr prefix max (the row_bcast steps of the 64-lane ladder fall away).  The four
+ * tasks of a wave run the same instruction stream under their own predicates -- every "wave-uniform" quantity of cw_poa.h (graph
+ * size, row, path position) is a per-lane value that is equal inside a row -- so one instruction advances four alignments.
+ *
+ * Round 5: the fill RECORDS THE TRACEBACK'S DECISIONS (what cw_poa_c.h does for the one-task-per-wave tiers, here on packed halves)
+ * and the DP matrix is gone from LDS:
+ *   values     rows are kept as W[i][j] = H[i][j] - j * gap, scaled by 4, the two low bits of every stored value set.  A horizontal
+ *              move costs nothing in that form (the horizontal recurrence is a plain prefix max), and a candidate that came through
+ *              in-edge q of a node carries 3 - min(q, 3) in its low bits: on equal values the earlier in-edge is the larger key.
+ *   decision   a cell is at least every candidate, so a candidate explains it iff it is the largest of its kind and equal to it;
+ *              four bits per cell (in-edge | move << 2; 8 = horizontal), derived with packed 16-bit arithmetic for both columns
+ *              of a lane at once; four rows of a lane's two columns make one 32-bit word in LDS (16 bytes per row and task).
+ *   row store  the last three rows in registers, the last CW_POAQ_RING rows in an LDS ring; the rare row a later row needs from
+ *              further back, and the rows round a node with more than three in-edges, also go to the task's slab in global memory
+ *              (a bit in the row word, set by the rank metadata pass).
+ *   traceback  a walk over code words, no value is looked at: the sixteen lanes look down the diagonal (cell (i - t, j - t) in lane
+ *              t) and a whole run of diagonal moves along a chain of the graph is one step; any other move is one word and one row
+ *              word away.  In-edge 3 means "fourth or later": decided from the kept values, among the in-edges 3.. only.
+ * What that buys: 64 nodes / 192 edges in the LDS that held 40 / 120 with the matrix (tasks of tier S with members of up to 31
+ * bases come here: 43 % of tier S's DP work at depth 150), and a traceback step of one or two LDS round trips instead of seven.
  *
  * Same policy, same arithmetic, same results as poa_run (cw_poa.h; include/cw_policy.h): the tests compare every tier with the
  * oracle.  A task that outgrows a capacity is handed to tier S (which runs after this kernel on the same stream).
+ * -DCW_Q_CODES=0 builds the matrix version of rounds 3-4 (cw_poa_q0.h; tests/test_gpu_variants.py).
  */
 #ifndef CW_POA_Q_H
 #define CW_POA_Q_H
 
 #include "cw_poa.h"
 
-#define CW_POAQ_NC 40
-#define CW_POAQ_EC 120
-#define CW_POAQ_LC 31
-#define CW_POAQ_HS 32 /* row stride of the DP matrix: columns 0..31 */
-#define CW_POAQ_HC ((CW_POAQ_NC + 1) * CW_POAQ_HS)
-#define CW_POAQ_TASK_BYTES ((CW_POAQ_HC * 2 + CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC) + 15) / 16 * 16)
-#define CW_POAQ_WAVES 8 /* 32 tasks per work-group: 150 KB of LDS, one work-group per CU (measured: 5 waves of 64-node slabs 26 ms, 7 x 48 13 ms, 8 x 40 8.7 ms, 10 x 32 5.2 ms for the tasks they take; the step is best here) */
-#define CW_POAQ_ROUTE_NODES 35 /* tasks expected to stay below this many nodes come here */
+#ifndef CW_Q_CODES
+#define CW_Q_CODES 1
+#endif
 
 /* ---- 16-lane row primitives ------------------------------------------------------------------------------------------------ */
 __device__ __forceinline__ unsigned q_ballot(bool p) { return (unsigned)(__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFu; }
@@ -45,53 +56,192 @@ __device__ __forceinline__ unsigned q_scan_max_u32(unsigned v) {
     return v;
 }
 
-/* packed DP fill of one member against the graph: lane gl owns columns 2gl and 2gl + 1 (cf. poa_fill_pk<1>) */
-__device__ __forceinline__ void poaq_fill(const PoaMem<int16_t>& M, const int n, const int cols, const int gl) {
-    const int G = CW_POA_GAP;
-    const int GPK = pk_make(G, G);
-    int* Hw = (int*)M.H;
+#if !CW_Q_CODES
+#include "cw_poa_q0.h"
+#else
+
+#define CW_POAQ_NC 64
+#define CW_POAQ_EC 192
+#define CW_POAQ_LC 31
+#define CW_POAQ_RING 8 /* rows of the LDS ring (a power of two): 64 bytes each */
+#define CW_POAQ_CODE_WORDS ((CW_POAQ_NC + 3) / 4 * 16)
+#define CW_POAQ_GFLAG_WORDS (CW_POAQ_NC / 32 + 2)
+#define CW_POAQ_TASK_BYTES ((CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC) + CW_POAQ_RING * 64 + CW_POAQ_CODE_WORDS * 4 + CW_POAQ_GFLAG_WORDS * 4 + 15) / 16 * 16)
+#define CW_POAQ_SLAB_BYTES ((CW_POAQ_NC + 1) * 64) /* per task, global: kept rows (stride 16 words) */
+#define CW_POAQ_WAVES 8 /* at most: 32 tasks per CU */
+#define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
+
+typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pku_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
+__device__ __forceinline__ int pku_min(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
+__device__ __forceinline__ int pku_shl1(int a) { return __builtin_bit_cast(int, (cw_u2)(__builtin_bit_cast(cw_u2, a) << (cw_u2)(unsigned short)1)); }
+
+struct PoaQx { /* what tier Q keeps beside the graph arrays of PoaMem */
+    uint32_t* ring;   /* LDS: CW_POAQ_RING rows x 16 words */
+    uint32_t* codes;  /* LDS: one word per four rows and lane */
+    uint32_t* gflag;  /* LDS: one bit per rank: the row is also kept in the slab */
+    int* keep;        /* global: kept rows, 16 words each, row i at keep + 16 i */
+};
+
+/* DP fill of one member against the graph, recording the decisions.  Lane gl of the row owns columns 2gl (low half) and 2gl + 1.
+   Returns the DP row of the end cell | its column << 16 (the best sink of the last column, lowest rank on ties; overlap mode: the
+   best cell of a sink's row, lowest rank then lowest column). */
+__device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx& X, const int n, const int cols, const int gl) {
+    typedef __attribute__((address_space(1))) int* gint;
+    const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
+    const int G4PK = pk_make(G4, G4);
+    const int ROW0 = 0x00030003; /* the virtual start row: W = 0 everywhere */
+    const int L = cols - 1;
     const int j0 = 2 * gl, j1 = j0 + 1;
-    const int jg = pk_make(j0 * G, j1 * G);
-    int rc0 = jg, rc1 = jg, rc2 = jg; /* the last three rows, rc0 = the previous one */
-    const int amask = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
     const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
-    const int qpk = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0);
+    const int qpk = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* bit b of a half: the column's base is b */
+    const int xs_pk = pk_make(gl == 0 ? CW_NEG16 : XS4, XS4);                 /* column 0 has no diagonal */
+    const cw_s2 ms_pk = (cw_s2)(short)(MS4 - XS4);
+    gint keep = (gint)X.keep;
+    int rc0 = ROW0, rc1 = ROW0, rc2 = ROW0; /* rows i-1, i-2, i-3 */
+    int bs0 = (int)0x80000000, bi0 = 0, bs1 = (int)0x80000000, bi1 = 0; /* best sink cell of this lane's even / odd column */
+    int bc0 = 0, bc1 = 0;                                              /* (overlap mode: their H values decide; kept per column) */
+    uint32_t acc = 0u;
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const uint32_t meta = M.rmeta[r];
-        const int pr0 = (int)M.rpred0[r];
-        const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-        const int srow = pk_score(qpk, base);
-        int v = CW_NEGPK;
-        for (int q = 0; q < np; ++q) {
-            const int prow = (np == 1) ? pr0 : (int)M.plist[off + q];
-            const int dist = i - prow;
-            int up;
-            if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
-            else up = (j0 < cols) ? Hw[(prow * CW_POAQ_HS + j0) >> 1] : CW_NEGPK;
-            const int sh = CW_DPP(CW_NEGPK, up, 0x111, 0xF);            /* lane l-1's pair inside the row; column 0 has no left neighbour */
-            const int dg = __builtin_amdgcn_alignbit(up, sh, 16);       /* (col 2l-1, col 2l) of the row above */
-            v = pk_max(v, pk_max(pk_add(dg, srow), pk_add(up, GPK)));
+        const int np = CW_RM_NP(meta), x = CW_RM_X(meta);
+        const int t_ = (int)(((unsigned)qpk >> (meta & 3u)) & 0x00010001u);
+        const int srow = __builtin_bit_cast(int, (cw_s2)(__builtin_bit_cast(cw_s2, t_) * ms_pk + __builtin_bit_cast(cw_s2, xs_pk)));
+        int dm, vm;
+        if (CW_RM_LIN(meta)) { /* one in-edge, from the row before */
+            const int sh = CW_DPP(0, rc0, 0x111, 0xF);
+            dm = __builtin_amdgcn_alignbit(rc0, sh, 16); vm = rc0;
+        } else {
+            dm = CW_NEGPK; vm = CW_NEGPK;
+            for (int q = 0; q < np; ++q) {
+                const int prow = np == 1 ? x : (int)M.plist[x + q];
+                const int dist = i - prow;
+                int up;
+                if (prow == 0) up = ROW0;
+                else if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
+                else if (dist <= CW_POAQ_RING) up = (int)X.ring[(prow & (CW_POAQ_RING - 1)) * 16 + gl];
+                else up = keep[prow * 16 + gl];
+                const int qq = q < 3 ? q : 3;
+                up = pk_sub(up, pk_make(qq, qq));
+                const int sh = CW_DPP(0, up, 0x111, 0xF);                 /* lane gl - 1's pair; lane 0: nothing (its column 0 takes no diagonal) */
+                dm = pk_max(dm, __builtin_amdgcn_alignbit(up, sh, 16)); /* (col 2gl - 1, col 2gl) of the predecessor row */
+                vm = pk_max(vm, up);
+            }
         }
-        if (CW_POA_OV && gl == 0) v = (int)((unsigned)v & 0xFFFF0000u); /* overlap mode (cw_policy.h): column 0 -- this lane's even half -- is free */
-        int w = pk_sub(v, jg);
-        w = (w & amask) | (CW_NEGPK & ~amask);
-        w = pk_max(w, (w << 16) | 0x8AD0);                              /* odd column sees the even one of its lane */
-        const unsigned inc = q_scan_max_u32(((unsigned)w >> 16) ^ 0x8000u);
-        const unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x111, 0xF);
+        const int kD = pk_add(dm, srow), kV = pk_add(vm, G4PK);
+        int v = pk_max(kD, kV);
+        if (CW_POA_OV && gl == 0) v = (int)(((unsigned)v & 0xFFFF0000u) | 3u); /* overlap mode (cw_policy.h): column 0 is free */
+        int w = pk_max(v, (v << 16) | (CW_NEG16 & 0xFFFF));                   /* the odd column sees the even one of its lane */
+        const unsigned inc = q_scan_max_u32(((unsigned)w >> 16) ^ 0x8000u);   /* the lanes' running maxima as biased unsigned numbers */
+        const unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x111, 0xF);        /* exclusive; 0 = nothing to the left */
         w = pk_max(w, pk_splat_lo((int)(ex ^ 0x8000u)));
-        const int nv = pk_add(w, jg);
+        const int nv = w | 0x00030003;
+        /* the codes of both columns: in-edge q (candidate ^ cell, the cell's low bits being 3) for a diagonal move, 4 + q for a vertical one, 8 for a horizontal one */
+        const int tD = kD ^ nv, tV = kV ^ nv;
+        const int fD = pku_max(tD, pku_shl1(tD & (int)0xFFFCFFFC));                    /* q if the upper bits agree, >= 8 otherwise */
+        const int fV = pk_add(pku_min(pku_max(tV, pku_shl1(tV & (int)0xFFFCFFFC)), 0x00080008), 0x00040004);
+        const int code = pku_min(pku_min(fD, fV), 0x00080008);
+        acc |= (uint32_t)code << ((r & 3) * 4);
+        if ((r & 3) == 3) { X.codes[(r >> 2) * 16 + gl] = acc; acc = 0u; }
+        X.ring[(i & (CW_POAQ_RING - 1)) * 16 + gl] = (uint32_t)nv;
+        if (meta & 24u) {
+            if (meta & 16u) keep[i * 16 + gl] = nv;
+            if (CW_RM_SINK(meta)) {
+                if (CW_POA_OV) { /* H form: columns of one row are compared */
+                    const int h0 = ((int)(short)(nv & 0xFFFF) >> 2) + j0 * CW_POA_GAP, h1 = (nv >> 18) + j1 * CW_POA_GAP;
+                    if (j0 >= 1 && j0 <= L && h0 > bs0) { bs0 = h0; bi0 = i; }
+                    if (j1 <= L && h1 > bs1) { bs1 = h1; bi1 = i; }
+                } else {
+                    const int h0 = (int)(short)(nv & 0xFFFF), h1 = nv >> 16;
+                    if (h0 > bs0) { bs0 = h0; bi0 = i; } /* ranks ascend: the lowest rank keeps a tie */
+                    if (h1 > bs1) { bs1 = h1; bi1 = i; }
+                }
+            }
+        }
         rc2 = rc1; rc1 = rc0; rc0 = nv;
-        if (j0 < cols) Hw[(i * CW_POAQ_HS + j0) >> 1] = nv;
     }
+    if (n & 3) X.codes[((n - 1) >> 2) * 16 + gl] = acc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the kept rows are read by other lanes in the traceback */
+    (void)bc0; (void)bc1;
+    int bi, bj = L;
+    if (CW_POA_OV) { /* the best over the row's lanes: value, then lowest rank, then lowest column */
+        int bs = bs0, br = bi0, bc = j0;
+        if (bs1 > bs || (bs1 == bs && bi1 < br)) { bs = bs1; br = bi1; bc = j1; }
+        if (bs == (int)0x80000000) br = 0x7FFFFFFF;
+        for (int o = 8; o > 0; o >>= 1) {
+            const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o), oc = __shfl_xor(bc, o);
+            if (os > bs || (os == bs && (orr < br || (orr == br && oc < bc)))) { bs = os; br = orr; bc = oc; }
+        }
+        bi = br; bj = bc;
+    } else {
+        bi = q_bcast((L & 1) ? bi1 : bi0, L >> 1);
+    }
+    return bi | (bj << 16);
+}
+
+/* Follows the recorded codes from (bi, bj) towards the virtual start; writes seqrank[j] = rank aligned to sequence position j (diagonal
+   moves).  Stops in column 0: what is left of the path there is vertical and aligns nothing.  Returns false when the walk does not
+   end (cannot happen; reported as an internal error). */
+__device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const PoaQx& X, const int n, const int bi, const int bj, const int gl) {
+    typedef __attribute__((address_space(1))) const int* gcint;
+    const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
+    gcint keep = (gcint)X.keep;
+    int i = bi, j = bj, trips = 0;
+    while (i > 0 && j > 0) {
+        if (++trips > n + 40) return false;
+        /* lane t looks at cell (i - t, j - t): a run of diagonal moves through first in-edges that lead to the rank before */
+        const int ri = i - gl, cj = j - gl;
+        bool ok = false;
+        int nib = 15;
+        uint32_t meta = 0u;
+        if (ri >= 1 && cj >= 1) {
+            const uint32_t cw = X.codes[((ri - 1) >> 2) * 16 + (cj >> 1)];
+            nib = (int)((cw >> (((cj & 1) << 4) + ((ri - 1) & 3) * 4)) & 15u);
+            meta = M.rmeta[ri - 1];
+            ok = nib == 0 && (int)M.rpred0[ri - 1] == ri - 1;
+        }
+        const unsigned okb = q_ballot(ok);
+        const int run = __ffs((int)(~okb & 0x1FFFFu)) - 1; /* leading lanes that continue the run (0 .. 16) */
+        if (run > 0) {
+            if (gl < run) M.seqrank[cj - 1] = (uint16_t)(ri - 1);
+            i -= run; j -= run;
+            continue;
+        }
+        /* one step, decided by lane 0's cell */
+        const int nib0 = q_bcast(nib, 0);
+        const uint32_t meta0 = (uint32_t)q_bcast((int)meta, 0);
+        if (nib0 == 8) { j--; continue; }
+        const int mv = nib0 >> 2;
+        int q = nib0 & 3;
+        const int np = CW_RM_NP(meta0), off = CW_RM_X(meta0);
+        if (q == 3) { /* fourth in-edge or later: the first of them whose candidate equals the cell (the values of these rows are kept) */
+            const int base = (int)(meta0 & 3u);
+            const int cjv = mv == 0 ? j - 1 : j;
+            const int hw = keep[i * 16 + (j >> 1)];
+            const int h = (j & 1) ? (hw >> 16) : (int)(short)(hw & 0xFFFF);
+            const int add = mv == 0 ? (((int)M.sq[j - 1] == base) ? MS4 : XS4) : G4;
+            q = -1;
+            for (int t = 3; t < np && q < 0; ++t) {
+                const int pr = (int)M.plist[off + t];
+                const int pw = pr == 0 ? 0x00030003 : keep[pr * 16 + (cjv >> 1)];
+                const int pv = (cjv & 1) ? (pw >> 16) : (int)(short)(pw & 0xFFFF);
+                if (h == pv + add) q = t; /* both values carry the low bits 3 */
+            }
+            if (q < 0) return false;
+        }
+        const int pr = np == 1 ? off : (int)M.plist[off + q];
+        if (mv == 0) { if (gl == 0) M.seqrank[j - 1] = (uint16_t)(i - 1); j--; }
+        i = pr;
+    }
+    return true;
 }
 
 /* Returns 1 = done, 2 = a capacity of this tier was exceeded, 3 = output capacity exceeded / internal.  Every value below is
    per lane and equal inside the 16-lane row; `gl` = lane inside the row. */
-__device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
+__device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
     unsigned long long _pt = __builtin_readcyclecounter();
 #define POAQ_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
-    const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH, HS = CW_POAQ_HS;
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
     bool meta_ok = false;
     const unsigned lt_mask = (1u << gl) - 1u;
@@ -120,11 +270,12 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
             continue;
         }
         const int cols = L + 1;
-        if ((uint32_t)((n + 1) * HS) > M.h_cap) return 2;
 
-        /* ---- per-rank metadata ---- */
+        /* ---- per-rank metadata: the row words (CW_RM_WORD), predecessor lists, which rows the fill keeps in the slab ---- */
         if (!meta_ok) {
             int run = 0;
+            for (int w = gl; w < CW_POAQ_GFLAG_WORDS; w += 16) X.gflag[w] = 0u;
+            cw_wave_sync();
             for (int r0 = 0; r0 < n; r0 += 16) {
                 const int r = r0 + gl;
                 const int node = r < n ? M.r2n[r] : 0;
@@ -137,93 +288,32 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                         const int pr = M.n2r[M.efrom[e]] + 1;
                         if (q == off) first = pr;
                         M.plist[q++] = (uint16_t)pr;
+                        if (r + 1 - pr > CW_POAQ_RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
+                            __hip_atomic_fetch_or((cwc_l32)X.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
+                    if (d > 3) __hip_atomic_fetch_or((cwc_l32)X.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     M.rpred0[r] = (uint16_t)first;
-                    M.rmeta[r] = (uint32_t)M.nbase[node] | ((uint32_t)(d ? d : 1) << 2) | ((uint32_t)off << 16);
+                    const uint32_t np_ = (uint32_t)(d ? d : 1);
+                    M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, np_ == 1u && first == r, !M.has_out[node], 0u, np_ == 1u ? first : off);
                 }
                 run += q_bcast(inc, 15);
             }
             meta_ok = true;
             cw_wave_sync();
+            for (int r = gl; r < n; r += 16) if ((X.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
+            cw_wave_sync();
         }
         POAQ_PROF(0);
 
-        /* ---- DP fill ---- */
-        for (int j = gl; j < cols; j += 16) M.H[j] = (int16_t)(j * G);
+        /* ---- DP fill (records the decisions), end cell ---- */
         for (int j = gl; j < L; j += 16) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
-        poaq_fill(M, n, cols, gl);
+        const int be = poaq_fill_c(M, X, n, cols, gl);
         cw_wave_sync();
         POAQ_PROF(1);
 
-        /* ---- end cell: best sink in the last column, lowest rank on ties ---- */
-        int bi, bj = L;
-        if (CW_POA_OV) { /* overlap mode: the best cell of a sink's row, columns 1..L; lowest rank, then lowest column on ties */
-            int bs = CW_NEG * 2, br = 0x7FFFFFFF, bc = L;
-            for (int r = gl; r < n; r += 16) {
-                if (M.has_out[M.r2n[r]]) continue;
-                for (int j = 1; j <= L; ++j) {
-                    const int h = M.H[(r + 1) * HS + j];
-                    if (h > bs) { bs = h; br = r; bc = j; }
-                }
-            }
-            for (int o = 8; o > 0; o >>= 1) {
-                const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o), oc = __shfl_xor(bc, o);
-                if (os > bs || (os == bs && orr < br)) { bs = os; br = orr; bc = oc; }
-            }
-            bi = br + 1; bj = bc;
-        } else {
-            int bs = CW_NEG * 2, br = 0x7FFFFFFF;
-            for (int r = gl; r < n; r += 16) {
-                if (M.has_out[M.r2n[r]]) continue;
-                const int h = M.H[(r + 1) * HS + L];
-                if (h > bs) { bs = h; br = r; } /* ranks ascend within a lane */
-            }
-            for (int o = 8; o > 0; o >>= 1) {
-                const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o);
-                if (os > bs || (os == bs && orr < br)) { bs = os; br = orr; }
-            }
-            bi = br + 1;
-        }
-
-        /* ---- traceback: every lane of the row walks the same path (diagonal through the in-edges in order, then vertical through them,
-           then horizontal); the three candidate cells of a single-predecessor node are requested together ---- */
-        {
-            int i = bi, j = bj;
-            while (i > 0 && (!CW_POA_OV || j > 0)) { /* (overlap mode: the walk stops in column 0) */
-                const uint32_t meta = M.rmeta[i - 1];
-                const int pr0 = (int)M.rpred0[i - 1];
-                const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
-                const int h = M.H[i * HS + j];
-                const int sx = (j != 0 && (int)M.sq[j - 1] == base) ? MS : XS;
-                const int hh = j != 0 ? (int)M.H[i * HS + j - 1] : CW_NEG * 2;
-                int pi = i, pj = j;
-                bool found = false;
-                if (np == 1) {
-                    const int hv = (int)M.H[pr0 * HS + j];
-                    const int hd = j != 0 ? (int)M.H[pr0 * HS + j - 1] : CW_NEG * 2;
-                    if (j != 0 && h == hd + sx) { pi = pr0; pj = j - 1; found = true; }
-                    else if (h == hv + G) { pi = pr0; found = true; }
-                } else {
-                    if (j != 0) {
-                        for (int q = 0; q < np && !found; ++q) {
-                            const int pr = (int)M.plist[off + q];
-                            if (h == (int)M.H[pr * HS + j - 1] + sx) { pi = pr; pj = j - 1; found = true; }
-                        }
-                    }
-                    for (int q = 0; q < np && !found; ++q) {
-                        const int pr = (int)M.plist[off + q];
-                        if (h == (int)M.H[pr * HS + j] + G) { pi = pr; found = true; }
-                    }
-                }
-                if (!found) {
-                    if (j != 0 && h == hh + G) { pj = j - 1; found = true; }
-                    else return 3;
-                }
-                if (pj != j && pi != i && gl == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
-                i = pi; j = pj;
-            }
-        }
+        /* ---- traceback over the code words ---- */
+        if (!poaq_trace_c(M, X, n, be & 0xFFFF, be >> 16, gl)) return 3;
         cw_wave_sync();
         POAQ_PROF(2);
 
@@ -427,7 +517,15 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int gl = threadIdx.x & 15;
     const uint32_t grp = threadIdx.x >> 4; /* 0 .. 4 * waves - 1 */
-    const PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)grp * CW_POAQ_TASK_BYTES, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC, CW_POAQ_HC, 0);
+    uint8_t* mine = lds + (size_t)grp * CW_POAQ_TASK_BYTES;
+    const PoaMem<int16_t> M = poa_carve<int16_t>(mine, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC, 0, 0);
+    PoaQx X;
+    {
+        uint8_t* extra = mine + CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC);
+        X.ring = (uint32_t*)extra; X.codes = X.ring + CW_POAQ_RING * 16; X.gflag = X.codes + CW_POAQ_CODE_WORDS;
+        typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
+        X.keep = (int*)(cw_gptr)(sc.q_slab + (size_t)(blockIdx.x * (blockDim.x >> 4) + grp) * CW_POAQ_SLAB_BYTES);
+    }
     const uint32_t* list = sc.tier_list[0];
     const uint32_t n_work = min(sc.ctr->n_tier[0], sc.list_cap);
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
@@ -439,7 +537,7 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         if (t.n_members == 0) continue; /* a neutral entry (cw_chain.h "cap_ok") */
-        const int rc = poaq_run(M, t, b, sc, gl, acc);
+        const int rc = poaq_run(M, X, t, b, sc, gl, acc);
         if (gl == 0) poa_hand_over(sc, t, ti, rc, 0); /* rc 2: redone in tier S, whose kernel follows this one on the stream */
         cw_wave_sync();
     }
@@ -448,4 +546,5 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
     if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[28 + q], acc[q]);
 }
 
+#endif /* CW_Q_CODES */
 #endif

@@ -4,6 +4,9 @@
   -DCW_POA_CODES=0  tiers S / M1 on the matrix path (fill writes the DP matrix, the traceback reads tiles of it back) instead of the
                     recorded-decision path of cw_poa_c.h,
   -DCW_M2_CODES=1   tier M2 on the recorded-decision path too,
+  -DCW_POAL_MW=4    one tier-L task on the four waves of a work-group, the chunks of a wide packed row pipelined by rows (cw_poa_w.h: built in round 5,
+                    measured no faster -- tier L's rows are narrow -- and off by default),
+  -DCW_Q_CODES=0    tier Q with the DP matrix in LDS and a walk over its values (rounds 3-4, cw_poa_q0.h) instead of recorded decisions,
 each compared with the oracle on piles of several depths (all tiers)."""
 import os
 import subprocess
@@ -13,7 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"]}
+VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "lwaves": ["-DCW_POAL_MW=4"]}
 
 CHILD = r"""
 import os, sys
@@ -32,6 +35,31 @@ for depth, n, msa, wlen in ((150, 32, 150, 500), (30, 96, 20, 500), (60, 32, 150
     exp, _ = oracle_lib.oracle_run(prm, hb, threads=os.cpu_count() or 1)
     for w in range(n):
         same = same and got.consensus(w) == exp.consensus(w) and int(got.status[w]) == int(exp.status[w])
+# few anchors -> segments of hundreds of bases: the wide packed rows of tiers M2 / L (what -DCW_POAL_MW=4 spreads over waves)
+import random
+rng = random.Random(5)
+def mutate(s, rate):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < rate * 0.3:
+            continue
+        if x < rate * 0.6:
+            out.append(rng.choice("ACGT"))
+        out.append(rng.choice("ACGT") if x < rate else c)
+    return "".join(out)
+piles = []
+for depth, ln, rate in ((8, 900, 0.2), (14, 700, 0.22), (24, 600, 0.2), (40, 520, 0.18)):
+    truth = "".join(rng.choice("ACGT") for _ in range(ln))
+    piles.append([mutate(truth, rate) for _ in range(depth)])
+prm = ca.Params(9, 4, 8, 2, 150)
+hb = ca.pack_piles(piles)
+eng = ca.Engine(prm)
+got = eng.run(hb)
+eng.close()
+exp, _ = oracle_lib.oracle_run(prm, hb, threads=os.cpu_count() or 1)
+for w in range(len(piles)):
+    same = same and got.consensus(w) == exp.consensus(w) and int(got.status[w]) == int(exp.status[w])
 print("RESULT", int(same))
 """
 

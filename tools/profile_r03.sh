@@ -10,7 +10,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-BASE="python bench.py --steps 5 --warmup 2 --cpu-sample 0 --pcie-steps 0 --workload $WL"
+BASE="python bench.py --steps 5 --warmup 2 --cpu-sample 0 --pcie-steps 0 --driver-leg 0 --workload $WL"
 if [ "$WHAT" != pmc ]; then
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_e1" -o trace -- $BASE --engines 1 > "$OUT/bench_trace_e1.log" 2>&1
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_e2" -o trace -- $BASE --engines 2 > "$OUT/bench_trace_e2.log" 2>&1
@@ -22,6 +22,9 @@ if [ "$WHAT" != trace ]; then
       -d "$OUT/pmc_sq1" -o sq1 -- $BASE --engines 1 > "$OUT/bench_sq1.log" 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace \
       -d "$OUT/pmc_sq2" -o sq2 -- $BASE --engines 1 > "$OUT/bench_sq2.log" 2>&1
+  # round 5: how full the lanes of the VALU instructions are -- thread-cycles against instruction-cycles
+  timeout 600 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --kernel-trace \
+      -d "$OUT/pmc_sq3" -o sq3 -- $BASE --engines 1 > "$OUT/bench_sq3.log" 2>&1
 fi
 find "$OUT" -name "*.db" | head
 tail -2 "$OUT"/bench_*.log

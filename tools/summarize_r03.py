@@ -151,6 +151,23 @@ def main():
             lines.append("")
             lines.append(f"# whole step ({ms:.2f} ms, one engine, {CLOCK_GHZ} GHz assumed): VALU issue {summary['whole_step']['valu_issue_frac']:.3f} of 1024 SIMDs x 1 wave-instruction / 4 cycles;"
                          f" LDS array busy {summary['whole_step']['lds_busy_frac']:.3f} of 256 CUs")
+    sq3 = per_kernel(os.path.join(src, "pmc_sq3", "sq3_results.db"))
+    if sq3:
+        lines.append("")
+        lines.append("# rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --kernel-trace (pass 3, own pass, --engines 1); per launch, averaged")
+        lines.append("# lane utilisation of the VALU instructions = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): 1.0 = every lane of every VALU instruction active")
+        lines.append(f"{'kernel':58s} {'THREAD_CYC_VALU':>16s} {'ACTIVE_INST_VALU':>16s} {'INSTS_VALU':>16s} {'lane util':>10s}")
+        t_thr = t_act = 0.0
+        for name in sorted(sq3, key=lambda n: -sq3[n].get("SQ_WAVE_CYCLES", 0)):
+            v = sq3[name]
+            thr, act = v.get("SQ_THREAD_CYCLES_VALU", 0.0), v.get("SQ_ACTIVE_INST_VALU", 0.0)
+            util = thr / (64.0 * act) if act else float("nan")
+            t_thr += thr; t_act += act
+            summary["kernels"].setdefault(name, {}).setdefault("sq_derived", {})["valu_lane_util"] = util
+            lines.append(f"{short(name)[:58]:58s} {thr:16.4g} {act:16.4g} {v.get('SQ_INSTS_VALU', float('nan')):16.4g} {util:10.3f}")
+        if t_act:
+            summary.setdefault("whole_step", {})["valu_lane_util"] = t_thr / (64.0 * t_act)
+            lines.append(f"# whole step: lane utilisation {t_thr / (64.0 * t_act):.3f}")
     os.makedirs("profiles", exist_ok=True)
     open(os.path.join("profiles", f"{tag}.txt"), "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(os.path.join("profiles", f"{tag}.json"), "w"), indent=1)
