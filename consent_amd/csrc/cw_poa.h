@@ -1448,8 +1448,15 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t l
     uint32_t c;
     if (tier == 0) { /* tier Q: the four tasks of a wave advance in lock step, so neighbours in the list should be alike: longest members first,
                         then by how many there are */
+#ifdef CW_Q_SORT_R4 /* rounds 3-4: longest member first, three steps of eight members */
         const uint32_t nm = n_members >> 3;
         return (CW_SORT_CLASSES - 1) - ((max_len < 32u ? max_len : 31u) * 4u + (nm < 3u ? nm : 3u));
+#else
+        /* round 5: a wave's four tasks end when its longest one does, and a task's time is members x rows x ...: since tier Q also takes the deep piles'
+           tasks (up to maxMSA members), the member count comes first -- eight classes, roughly geometric -- then the longest member in steps of two */
+        const uint32_t mc = n_members < 4u ? 0u : n_members < 8u ? 1u : n_members < 12u ? 2u : n_members < 16u ? 3u : n_members < 24u ? 4u : n_members < 32u ? 5u : n_members < 64u ? 6u : 7u;
+        return (CW_SORT_CLASSES - 1) - (mc * 16u + ((max_len < 32u ? max_len : 31u) >> 1));
+#endif
     }
     if (tier == 1 || tier == 5) { /* tier H: the two tasks of a wave advance in lock step, so neighbours in the list should be alike as well */
         c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;

@@ -22,8 +22,11 @@
  *   traceback  a walk over code words, no value is looked at: the sixteen lanes look down the diagonal (cell (i - t, j - t) in lane
  *              t) and a whole run of diagonal moves along a chain of the graph is one step; any other move is one word and one row
  *              word away.  In-edge 3 means "fourth or later": decided from the kept values, among the in-edges 3.. only.
- * What that buys: 64 nodes / 192 edges in the LDS that held 40 / 120 with the matrix (tasks of tier S with members of up to 31
- * bases come here: 43 % of tier S's DP work at depth 150), and a traceback step of one or two LDS round trips instead of seven.
+ *   bytes      64 nodes, 184 edges, 32 columns: every node id, rank, edge id and DP row of this tier fits a byte, and the graph arrays are
+ *              byte arrays (PoaQ; the one-task-per-wave tiers keep 16-bit ids).  A task is 3.3 KB of LDS where the matrix version took 4.7 KB
+ *              for 40 nodes: twelve waves per CU instead of eight -- and the tier is bound by the latency its resident waves can hide.
+ * What that buys: 64 nodes / 184 edges (tasks of tier S with members of up to 31 bases come here: 43 % of tier S's DP work at depth
+ * 150), half again as many tasks resident, and a traceback step of one or two LDS round trips instead of seven.
  *
  * Same policy, same arithmetic, same results as poa_run (cw_poa.h; include/cw_policy.h): the tests compare every tier with the
  * oracle.  A task that outgrows a capacity is handed to tier S (which runs after this kernel on the same stream).
@@ -61,32 +64,106 @@ __device__ __forceinline__ unsigned q_scan_max_u32(unsigned v) {
 #else
 
 #define CW_POAQ_NC 64
-#define CW_POAQ_EC 192
+#define CW_POAQ_EC 184 /* (with 64 nodes and the ring: 3392 bytes a task, 40 704 a three-wave work-group -- four of them are a CU's 160 KB to the byte) */
 #define CW_POAQ_LC 31
+#define CW_NONE8 0xFFu
+static_assert(CW_POAQ_NC < 255 && CW_POAQ_EC < 255 && CW_POAQ_LC < 255, "tier Q keeps node ids, DP rows, edge ids and sequence positions in bytes");
 #define CW_POAQ_RING 8 /* rows of the LDS ring (a power of two): 64 bytes each */
 #define CW_POAQ_CODE_WORDS ((CW_POAQ_NC + 3) / 4 * 16)
 #define CW_POAQ_GFLAG_WORDS (CW_POAQ_NC / 32 + 2)
-#define CW_POAQ_TASK_BYTES ((CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC) + CW_POAQ_RING * 64 + CW_POAQ_CODE_WORDS * 4 + CW_POAQ_GFLAG_WORDS * 4 + 15) / 16 * 16)
+/* graph arrays of a task (PoaQ, poaq_carve): the row words, then bytes */
+#define CW_POAQ_GRAPH_BYTES ((4 * CW_POAQ_NC + (3 + (CW_CONS_HEAVIEST_BUNDLE ? 1 : 0)) * CW_POAQ_EC + 14 * CW_POAQ_NC + 4 * (CW_POAQ_LC + 1) + 15) / 16 * 16)
+#define CW_POAQ_TASK_BYTES ((CW_POAQ_GRAPH_BYTES + CW_POAQ_RING * 64 + CW_POAQ_CODE_WORDS * 4 + CW_POAQ_GFLAG_WORDS * 4 + 15) / 16 * 16)
 #define CW_POAQ_SLAB_BYTES ((CW_POAQ_NC + 1) * 64) /* per task, global: kept rows (stride 16 words) */
-#define CW_POAQ_WAVES 8 /* at most: 32 tasks per CU */
+#define CW_POAQ_WAVES 12 /* at most: 48 tasks per CU */
 #define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
+static_assert(CW_POAQ_CODE_WORDS >= CW_POAQ_NC + 1, "the merge's rank histogram borrows the code words");
 
 typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int pku_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
 __device__ __forceinline__ int pku_min(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
 __device__ __forceinline__ int pku_shl1(int a) { return __builtin_bit_cast(int, (cw_u2)(__builtin_bit_cast(cw_u2, a) << (cw_u2)(unsigned short)1)); }
 
-struct PoaQx { /* what tier Q keeps beside the graph arrays of PoaMem */
-    uint32_t* ring;   /* LDS: CW_POAQ_RING rows x 16 words */
-    uint32_t* codes;  /* LDS: one word per four rows and lane */
-    uint32_t* gflag;  /* LDS: one bit per rank: the row is also kept in the slab */
+struct PoaQ { /* one task's arrays: LDS, except `keep` */
+    uint32_t* rmeta;  /* rank -> the row word (CW_RM_WORD) */
+    uint8_t* plist;   /* predecessor DP rows in in-edge order (CSR) */
+    uint8_t* efrom;   /* edge -> source node */
+    uint8_t* enext;   /* edge -> next in-edge of the same target, CW_NONE8 at the end */
+    uint8_t* ew;      /* edge -> sequences whose path uses it (heaviest-bundle policy only, else NULL) */
+    uint8_t* rpred0;  /* rank -> DP row of its first predecessor (0 = virtual start) */
+    uint8_t* ncov;    /* node -> sequences through it (a task of more than 255 members goes to tier S) */
+    uint8_t* nal;     /* node -> 3 aligned node ids */
+    uint8_t* in_head; /* node -> first in-edge, CW_NONE8 if none */
+    uint8_t* in_tail;
+    uint8_t* indeg;
+    uint8_t* r2n;     /* rank -> node */
+    uint8_t* n2r;
+    uint8_t* rtmp;
+    uint8_t* nbase;
+    uint8_t* nalc;
+    uint8_t* has_out;
+    uint8_t* seqrank; /* sequence position -> rank of the node it is aligned to, CW_NONE8 for an insertion */
+    uint8_t* pcur;
+    uint8_t* pat;
+    uint8_t* sq;      /* current member, base codes */
+    uint32_t* ring;   /* CW_POAQ_RING rows x 16 words */
+    uint32_t* codes;  /* one word per four rows and lane; between a traceback and the next fill: the merge's rank histogram */
+    uint32_t* gflag;  /* one bit per rank: the row is also kept in the slab */
     int* keep;        /* global: kept rows, 16 words each, row i at keep + 16 i */
 };
+__device__ __forceinline__ PoaQ poaq_carve(uint8_t* p) {
+    PoaQ M;
+    const uint32_t nc = CW_POAQ_NC, ec = CW_POAQ_EC, lc1 = CW_POAQ_LC + 1;
+    uint8_t* const base = p;
+    M.rmeta = (uint32_t*)p; p += 4 * nc;
+    M.plist = p; p += ec; M.efrom = p; p += ec; M.enext = p; p += ec;
+    M.ew = nullptr;
+    if (CW_CONS_HEAVIEST_BUNDLE) { M.ew = p; p += ec; }
+    M.rpred0 = p; p += nc; M.ncov = p; p += nc; M.nal = p; p += 3 * nc; M.in_head = p; p += nc; M.in_tail = p; p += nc; M.indeg = p; p += nc;
+    M.r2n = p; p += nc; M.n2r = p; p += nc; M.rtmp = p; p += nc; M.nbase = p; p += nc; M.nalc = p; p += nc; M.has_out = p; p += nc;
+    M.seqrank = p; p += lc1; M.pcur = p; p += lc1; M.pat = p; p += lc1; M.sq = p; p += lc1;
+    uint8_t* extra = base + CW_POAQ_GRAPH_BYTES;
+    M.ring = (uint32_t*)extra; M.codes = M.ring + CW_POAQ_RING * 16; M.gflag = M.codes + CW_POAQ_CODE_WORDS;
+    M.keep = nullptr;
+    return M;
+}
+/* (poaq_carve uses 4 NC + (3 | 4) EC + 14 NC + 4 (LC + 1) bytes of CW_POAQ_GRAPH_BYTES) */
+
+#if CW_CONS_HEAVIEST_BUNDLE
+/* cw_policy.h CW_POA_CONSENSUS_HEAVIEST_BUNDLE on one lane (cf. poa_consensus_hb): scores by node in the row words, the chosen source in rpred0 */
+__device__ __forceinline__ uint32_t poaq_consensus_hb(const PoaQ& M, const int n, const PoaTask& t, const DevScratch& sc) {
+    uint32_t* score = M.rmeta;
+    uint8_t* pred = M.rpred0;
+    int end = -1;
+    uint32_t end_score = 0;
+    for (int r = 0; r < n; ++r) {
+        const int v = M.r2n[r];
+        int p = -1;
+        uint32_t wb = 0, ps = 0;
+        for (uint32_t e = M.in_head[v]; e != CW_NONE8; e = M.enext[e]) {
+            const int u = M.efrom[e];
+            const uint32_t w = M.ew[e], su = score[u];
+            if (p < 0 || wb < w || (wb == w && ps <= su)) { wb = w; p = u; ps = su; }
+        }
+        const uint32_t s_ = p < 0 ? 0u : wb + ps;
+        score[v] = s_;
+        pred[v] = p < 0 ? (uint8_t)CW_NONE8 : (uint8_t)p;
+        if (!M.has_out[v] && (end < 0 || end_score < s_)) { end = v; end_score = s_; }
+    }
+    uint32_t len = 0;
+    for (int v = end; v >= 0; v = pred[v] == CW_NONE8 ? -1 : (int)pred[v]) ++len;
+    if (len <= t.out_cap) {
+        uint32_t k = len;
+        for (int v = end; v >= 0; v = pred[v] == CW_NONE8 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = "ACGT"[M.nbase[v]];
+    }
+    return len;
+}
+#endif
 
 /* DP fill of one member against the graph, recording the decisions.  Lane gl of the row owns columns 2gl (low half) and 2gl + 1.
    Returns the DP row of the end cell | its column << 16 (the best sink of the last column, lowest rank on ties; overlap mode: the
    best cell of a sink's row, lowest rank then lowest column). */
-__device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx& X, const int n, const int cols, const int gl) {
+__device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int cols, const int gl) {
     typedef __attribute__((address_space(1))) int* gint;
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     const int G4PK = pk_make(G4, G4);
@@ -97,7 +174,7 @@ __device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx
     const int qpk = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* bit b of a half: the column's base is b */
     const int xs_pk = pk_make(gl == 0 ? CW_NEG16 : XS4, XS4);                 /* column 0 has no diagonal */
     const cw_s2 ms_pk = (cw_s2)(short)(MS4 - XS4);
-    gint keep = (gint)X.keep;
+    gint keep = (gint)M.keep;
     int rc0 = ROW0, rc1 = ROW0, rc2 = ROW0; /* rows i-1, i-2, i-3 */
     int bs0 = (int)0x80000000, bi0 = 0, bs1 = (int)0x80000000, bi1 = 0; /* best sink cell of this lane's even / odd column */
     int bc0 = 0, bc1 = 0;                                              /* (overlap mode: their H values decide; kept per column) */
@@ -120,7 +197,7 @@ __device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx
                 int up;
                 if (prow == 0) up = ROW0;
                 else if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
-                else if (dist <= CW_POAQ_RING) up = (int)X.ring[(prow & (CW_POAQ_RING - 1)) * 16 + gl];
+                else if (dist <= CW_POAQ_RING) up = (int)M.ring[(prow & (CW_POAQ_RING - 1)) * 16 + gl];
                 else up = keep[prow * 16 + gl];
                 const int qq = q < 3 ? q : 3;
                 up = pk_sub(up, pk_make(qq, qq));
@@ -143,8 +220,8 @@ __device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx
         const int fV = pk_add(pku_min(pku_max(tV, pku_shl1(tV & (int)0xFFFCFFFC)), 0x00080008), 0x00040004);
         const int code = pku_min(pku_min(fD, fV), 0x00080008);
         acc |= (uint32_t)code << ((r & 3) * 4);
-        if ((r & 3) == 3) { X.codes[(r >> 2) * 16 + gl] = acc; acc = 0u; }
-        X.ring[(i & (CW_POAQ_RING - 1)) * 16 + gl] = (uint32_t)nv;
+        if ((r & 3) == 3) { M.codes[(r >> 2) * 16 + gl] = acc; acc = 0u; }
+        M.ring[(i & (CW_POAQ_RING - 1)) * 16 + gl] = (uint32_t)nv;
         if (meta & 24u) {
             if (meta & 16u) keep[i * 16 + gl] = nv;
             if (CW_RM_SINK(meta)) {
@@ -161,7 +238,7 @@ __device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx
         }
         rc2 = rc1; rc1 = rc0; rc0 = nv;
     }
-    if (n & 3) X.codes[((n - 1) >> 2) * 16 + gl] = acc;
+    if (n & 3) M.codes[((n - 1) >> 2) * 16 + gl] = acc;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the kept rows are read by other lanes in the traceback */
     (void)bc0; (void)bc1;
     int bi, bj = L;
@@ -183,10 +260,10 @@ __device__ __forceinline__ int poaq_fill_c(const PoaMem<int16_t>& M, const PoaQx
 /* Follows the recorded codes from (bi, bj) towards the virtual start; writes seqrank[j] = rank aligned to sequence position j (diagonal
    moves).  Stops in column 0: what is left of the path there is vertical and aligns nothing.  Returns false when the walk does not
    end (cannot happen; reported as an internal error). */
-__device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const PoaQx& X, const int n, const int bi, const int bj, const int gl) {
+__device__ __forceinline__ bool poaq_trace_c(const PoaQ& M, const int n, const int bi, const int bj, const int gl) {
     typedef __attribute__((address_space(1))) const int* gcint;
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
-    gcint keep = (gcint)X.keep;
+    gcint keep = (gcint)M.keep;
     int i = bi, j = bj, trips = 0;
     while (i > 0 && j > 0) {
         if (++trips > n + 40) return false;
@@ -196,7 +273,7 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const Poa
         int nib = 15;
         uint32_t meta = 0u;
         if (ri >= 1 && cj >= 1) {
-            const uint32_t cw = X.codes[((ri - 1) >> 2) * 16 + (cj >> 1)];
+            const uint32_t cw = M.codes[((ri - 1) >> 2) * 16 + (cj >> 1)];
             nib = (int)((cw >> (((cj & 1) << 4) + ((ri - 1) & 3) * 4)) & 15u);
             meta = M.rmeta[ri - 1];
             ok = nib == 0 && (int)M.rpred0[ri - 1] == ri - 1;
@@ -204,7 +281,7 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const Poa
         const unsigned okb = q_ballot(ok);
         const int run = __ffs((int)(~okb & 0x1FFFFu)) - 1; /* leading lanes that continue the run (0 .. 16) */
         if (run > 0) {
-            if (gl < run) M.seqrank[cj - 1] = (uint16_t)(ri - 1);
+            if (gl < run) M.seqrank[cj - 1] = (uint8_t)(ri - 1);
             i -= run; j -= run;
             continue;
         }
@@ -231,7 +308,7 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const Poa
             if (q < 0) return false;
         }
         const int pr = np == 1 ? off : (int)M.plist[off + q];
-        if (mv == 0) { if (gl == 0) M.seqrank[j - 1] = (uint16_t)(i - 1); j--; }
+        if (mv == 0) { if (gl == 0) M.seqrank[j - 1] = (uint8_t)(i - 1); j--; }
         i = pr;
     }
     return true;
@@ -239,17 +316,18 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaMem<int16_t>& M, const Poa
 
 /* Returns 1 = done, 2 = a capacity of this tier was exceeded, 3 = output capacity exceeded / internal.  Every value below is
    per lane and equal inside the 16-lane row; `gl` = lane inside the row. */
-__device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
+__device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
     unsigned long long _pt = __builtin_readcyclecounter();
 #define POAQ_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
     bool meta_ok = false;
     const unsigned lt_mask = (1u << gl) - 1u;
 
+    if (t.n_members > 255u) return 2; /* coverage counts and edge weights are bytes here */
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
         const int L = (int)pm.len;
-        if ((uint32_t)L > M.l_cap) return 2;
+        if ((uint32_t)L > (uint32_t)CW_POAQ_LC) return 2;
         {
             const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
             for (int j = gl; j < L; j += 16) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
@@ -257,13 +335,13 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
         cw_wave_sync();
         nseq++;
         if (n == 0) { /* first member: a chain */
-            if ((uint32_t)L > M.n_cap || (uint32_t)L > M.e_cap) return 2;
+            if ((uint32_t)L > (uint32_t)CW_POAQ_NC || (uint32_t)L > (uint32_t)CW_POAQ_EC) return 2;
             for (int j = gl; j < L; j += 16) {
                 M.nbase[j] = M.sq[j]; M.ncov[j] = 1; M.nalc[j] = 0;
-                M.in_head[j] = j ? (uint16_t)(j - 1) : CW_NONE16; M.in_tail[j] = M.in_head[j];
+                M.in_head[j] = j ? (uint8_t)(j - 1) : CW_NONE8; M.in_tail[j] = M.in_head[j];
                 M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
-                M.r2n[j] = (uint16_t)j; M.n2r[j] = (uint16_t)j;
-                if (j) { M.efrom[j - 1] = (uint16_t)(j - 1); M.enext[j - 1] = CW_NONE16; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
+                M.r2n[j] = (uint8_t)j; M.n2r[j] = (uint8_t)j;
+                if (j) { M.efrom[j - 1] = (uint8_t)(j - 1); M.enext[j - 1] = CW_NONE8; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
             }
             n = L; ne = L - 1; tpl_nodes = L; meta_ok = false;
             cw_wave_sync();
@@ -274,7 +352,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
         /* ---- per-rank metadata: the row words (CW_RM_WORD), predecessor lists, which rows the fill keeps in the slab ---- */
         if (!meta_ok) {
             int run = 0;
-            for (int w = gl; w < CW_POAQ_GFLAG_WORDS; w += 16) X.gflag[w] = 0u;
+            for (int w = gl; w < CW_POAQ_GFLAG_WORDS; w += 16) M.gflag[w] = 0u;
             cw_wave_sync();
             for (int r0 = 0; r0 < n; r0 += 16) {
                 const int r = r0 + gl;
@@ -284,15 +362,15 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
                 const int off = run + inc - d;
                 if (r < n) {
                     int q = off, first = 0;
-                    for (uint32_t e = M.in_head[node]; e != CW_NONE16; e = M.enext[e]) {
+                    for (uint32_t e = M.in_head[node]; e != CW_NONE8; e = M.enext[e]) {
                         const int pr = M.n2r[M.efrom[e]] + 1;
                         if (q == off) first = pr;
-                        M.plist[q++] = (uint16_t)pr;
+                        M.plist[q++] = (uint8_t)pr;
                         if (r + 1 - pr > CW_POAQ_RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
-                            __hip_atomic_fetch_or((cwc_l32)X.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
-                    if (d > 3) __hip_atomic_fetch_or((cwc_l32)X.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    M.rpred0[r] = (uint16_t)first;
+                    if (d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    M.rpred0[r] = (uint8_t)first;
                     const uint32_t np_ = (uint32_t)(d ? d : 1);
                     M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, np_ == 1u && first == r, !M.has_out[node], 0u, np_ == 1u ? first : off);
                 }
@@ -300,20 +378,20 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
             }
             meta_ok = true;
             cw_wave_sync();
-            for (int r = gl; r < n; r += 16) if ((X.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
+            for (int r = gl; r < n; r += 16) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
             cw_wave_sync();
         }
         POAQ_PROF(0);
 
         /* ---- DP fill (records the decisions), end cell ---- */
-        for (int j = gl; j < L; j += 16) M.seqrank[j] = CW_NONE16;
+        for (int j = gl; j < L; j += 16) M.seqrank[j] = CW_NONE8;
         cw_wave_sync();
-        const int be = poaq_fill_c(M, X, n, cols, gl);
+        const int be = poaq_fill_c(M, n, cols, gl);
         cw_wave_sync();
         POAQ_PROF(1);
 
         /* ---- traceback over the code words ---- */
-        if (!poaq_trace_c(M, X, n, be & 0xFFFF, be >> 16, gl)) return 3;
+        if (!poaq_trace_c(M, n, be & 0xFFFF, be >> 16, gl)) return 3;
         cw_wave_sync();
         POAQ_PROF(2);
 
@@ -325,16 +403,16 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
             for (int c = chunks - 1; c >= 0; --c) {
                 const int j = c * 16 + gl;
                 const bool act = j < L;
-                const uint32_t rk = act ? M.seqrank[j] : CW_NONE16;
-                const unsigned has = q_ballot(act && rk != CW_NONE16);
+                const uint32_t rk = act ? M.seqrank[j] : CW_NONE8;
+                const unsigned has = q_ballot(act && rk != CW_NONE8);
                 const unsigned later = has & ~(lt_mask | (1u << gl));
                 const int later_rank = (int)(uint32_t)q_bcast((int)rk, later ? (__ffs((int)later) - 1) : 0);
                 const int qr = later ? later_rank : next_rank;
                 const int first_rank = (int)(uint32_t)q_bcast((int)rk, has ? (__ffs((int)has) - 1) : 0);
-                uint32_t cur = CW_NONE16, at = CW_NONE16;
+                uint32_t cur = CW_NONE8, at = CW_NONE8;
                 if (act) {
                     const int bcode = M.sq[j];
-                    if (rk != CW_NONE16) {
+                    if (rk != CW_NONE8) {
                         const int pn = M.r2n[rk];
                         if (M.nbase[pn] == bcode) cur = (uint32_t)pn;
                         else {
@@ -345,7 +423,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
                                 if (M.nbase[v] == bcode) cur = (uint32_t)v;
                                 last = max(last, (int)M.n2r[v]);
                             }
-                            if (cur == CW_NONE16) at = (uint32_t)(last + 1);
+                            if (cur == CW_NONE8) at = (uint32_t)(last + 1);
                         }
                     } else if (qr < 0) {
                         at = (uint32_t)n_old;
@@ -355,8 +433,8 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
                         for (int a = 0; a < M.nalc[q]; ++a) first = min(first, (int)M.n2r[M.nal[q * 3 + a]]);
                         at = (uint32_t)first;
                     }
-                    M.pcur[j] = (uint16_t)cur;
-                    M.pat[j] = (uint16_t)at;
+                    M.pcur[j] = (uint8_t)cur;
+                    M.pat[j] = (uint8_t)at;
                 }
                 if (has) next_rank = first_rank;
             }
@@ -365,42 +443,42 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
             for (int c = 0; c < chunks; ++c) {
                 const int j = c * 16 + gl;
                 const bool act = j < L;
-                const bool fresh = act && M.pcur[j] == CW_NONE16;
+                const bool fresh = act && M.pcur[j] == CW_NONE8;
                 const unsigned fb = q_ballot(fresh);
                 if (fresh) {
                     const int cur = n_old + fresh_total + __popc(fb & lt_mask);
-                    if ((uint32_t)cur < M.n_cap) {
-                        M.pcur[j] = (uint16_t)cur;
+                    if ((uint32_t)cur < (uint32_t)CW_POAQ_NC) {
+                        M.pcur[j] = (uint8_t)cur;
                         M.nbase[cur] = M.sq[j]; M.ncov[cur] = 1; M.nalc[cur] = 0;
-                        M.in_head[cur] = CW_NONE16; M.in_tail[cur] = CW_NONE16; M.indeg[cur] = 0; M.has_out[cur] = 0;
+                        M.in_head[cur] = CW_NONE8; M.in_tail[cur] = CW_NONE8; M.indeg[cur] = 0; M.has_out[cur] = 0;
                         const uint32_t rk = M.seqrank[j];
-                        if (rk != CW_NONE16) {
+                        if (rk != CW_NONE8) {
                             const int pn = M.r2n[rk];
                             const int ac = M.nalc[pn];
                             for (int a = 0; a < ac; ++a) {
                                 const int v = M.nal[pn * 3 + a];
-                                M.nal[cur * 3 + a] = (uint16_t)v;
-                                M.nal[v * 3 + M.nalc[v]] = (uint16_t)cur; M.nalc[v] = (uint8_t)(M.nalc[v] + 1);
+                                M.nal[cur * 3 + a] = (uint8_t)v;
+                                M.nal[v * 3 + M.nalc[v]] = (uint8_t)cur; M.nalc[v] = (uint8_t)(M.nalc[v] + 1);
                             }
-                            M.nal[cur * 3 + ac] = (uint16_t)pn; M.nalc[cur] = (uint8_t)(ac + 1);
-                            M.nal[pn * 3 + ac] = (uint16_t)cur; M.nalc[pn] = (uint8_t)(ac + 1);
+                            M.nal[cur * 3 + ac] = (uint8_t)pn; M.nalc[cur] = (uint8_t)(ac + 1);
+                            M.nal[pn * 3 + ac] = (uint8_t)cur; M.nalc[pn] = (uint8_t)(ac + 1);
                         }
                     }
                 } else if (act) {
                     const int cur = M.pcur[j];
-                    M.ncov[cur] = (uint16_t)(M.ncov[cur] + 1);
+                    M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1);
                 }
                 fresh_total += __popc(fb);
             }
-            if ((uint32_t)(n_old + fresh_total) > M.n_cap) return 2;
+            if ((uint32_t)(n_old + fresh_total) > (uint32_t)CW_POAQ_NC) return 2;
             cw_wave_sync();
             if (fresh_total > 0) {
-                uint32_t* hist = (uint32_t*)M.plist; /* n_old + 1 counters (EC * 2 bytes >= 4 * (NC + 1)) */
+                uint32_t* hist = M.codes; /* n_old + 1 counters: the code words are dead between the traceback and the next fill */
                 for (int r = gl; r <= n_old; r += 16) hist[r] = 0;
                 cw_wave_sync();
                 for (int c = 0; c < chunks; ++c) {
                     const int j = c * 16 + gl;
-                    if (j < L && M.pat[j] != CW_NONE16) atomicAdd(&hist[M.pat[j]], 1u);
+                    if (j < L && M.pat[j] != CW_NONE8) atomicAdd(&hist[M.pat[j]], 1u);
                 }
                 cw_wave_sync();
                 int run = 0;
@@ -411,18 +489,18 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
                     if (r < n_old) {
                         const int nr = r + run + inc;
                         const int v = M.r2n[r];
-                        M.rtmp[nr] = (uint16_t)v;
-                        M.n2r[v] = (uint16_t)nr;
+                        M.rtmp[nr] = (uint8_t)v;
+                        M.n2r[v] = (uint8_t)nr;
                     }
                     run += q_bcast(inc, 15);
                 }
                 for (int c = 0; c < chunks; ++c) {
                     const int j = c * 16 + gl;
-                    if (j < L && M.pat[j] != CW_NONE16) {
+                    if (j < L && M.pat[j] != CW_NONE8) {
                         const int cur = M.pcur[j];
                         const int nr = (int)M.pat[j] + (cur - n_old);
-                        M.rtmp[nr] = (uint16_t)cur;
-                        M.n2r[cur] = (uint16_t)nr;
+                        M.rtmp[nr] = (uint8_t)cur;
+                        M.n2r[cur] = (uint8_t)nr;
                     }
                 }
                 cw_wave_sync();
@@ -439,20 +517,20 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
                 if (act) {
                     head = M.pcur[j - 1]; cur = M.pcur[j];
                     add = true;
-                    for (uint32_t e = M.in_head[cur]; e != CW_NONE16; e = M.enext[e])
-                        if (M.efrom[e] == (uint16_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint16_t)(M.ew[e] + 1); break; }
+                    for (uint32_t e = M.in_head[cur]; e != CW_NONE8; e = M.enext[e])
+                        if (M.efrom[e] == (uint8_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint8_t)(M.ew[e] + 1); break; }
                 }
                 const unsigned ab = q_ballot(add);
                 const int total = __popc(ab);
-                if ((uint32_t)(ne + total) > M.e_cap) return 2;
+                if ((uint32_t)(ne + total) > (uint32_t)CW_POAQ_EC) return 2;
                 if (add) {
                     const int e = ne + __popc(ab & lt_mask);
-                    M.efrom[e] = (uint16_t)head; M.enext[e] = CW_NONE16;
+                    M.efrom[e] = (uint8_t)head; M.enext[e] = CW_NONE8;
                     if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = 1;
                     const uint32_t tl = M.in_tail[cur];
-                    if (tl == CW_NONE16) M.in_head[cur] = (uint16_t)e; else M.enext[tl] = (uint16_t)e;
-                    M.in_tail[cur] = (uint16_t)e;
-                    M.indeg[cur] = (uint16_t)(M.indeg[cur] + 1);
+                    if (tl == CW_NONE8) M.in_head[cur] = (uint8_t)e; else M.enext[tl] = (uint8_t)e;
+                    M.in_tail[cur] = (uint8_t)e;
+                    M.indeg[cur] = (uint8_t)(M.indeg[cur] + 1);
                     M.has_out[head] = 1;
                 }
                 if (total) { ne += total; meta_ok = false; }
@@ -466,7 +544,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaQx& X, const PoaTask&
     uint32_t out_len = 0;
 #if CW_CONS_HEAVIEST_BUNDLE
     cw_wave_sync();
-    if (gl == 0) out_len = poa_consensus_hb(M, n, t, sc);
+    if (gl == 0) out_len = poaq_consensus_hb(M, n, t, sc);
     out_len = (uint32_t)__shfl((int)out_len, (int)(threadIdx.x & 48u));
 #else
     for (int r0 = 0; r0 < n; r0 += 16) {
@@ -517,14 +595,10 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int gl = threadIdx.x & 15;
     const uint32_t grp = threadIdx.x >> 4; /* 0 .. 4 * waves - 1 */
-    uint8_t* mine = lds + (size_t)grp * CW_POAQ_TASK_BYTES;
-    const PoaMem<int16_t> M = poa_carve<int16_t>(mine, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC, 0, 0);
-    PoaQx X;
+    PoaQ M = poaq_carve(lds + (size_t)grp * CW_POAQ_TASK_BYTES);
     {
-        uint8_t* extra = mine + CW_POA_GRAPH_BYTES(CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_LC);
-        X.ring = (uint32_t*)extra; X.codes = X.ring + CW_POAQ_RING * 16; X.gflag = X.codes + CW_POAQ_CODE_WORDS;
         typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
-        X.keep = (int*)(cw_gptr)(sc.q_slab + (size_t)(blockIdx.x * (blockDim.x >> 4) + grp) * CW_POAQ_SLAB_BYTES);
+        M.keep = (int*)(cw_gptr)(sc.q_slab + (size_t)(blockIdx.x * (blockDim.x >> 4) + grp) * CW_POAQ_SLAB_BYTES);
     }
     const uint32_t* list = sc.tier_list[0];
     const uint32_t n_work = min(sc.ctr->n_tier[0], sc.list_cap);
@@ -537,7 +611,7 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         if (t.n_members == 0) continue; /* a neutral entry (cw_chain.h "cap_ok") */
-        const int rc = poaq_run(M, X, t, b, sc, gl, acc);
+        const int rc = poaq_run(M, t, b, sc, gl, acc);
         if (gl == 0) poa_hand_over(sc, t, ti, rc, 0); /* rc 2: redone in tier S, whose kernel follows this one on the stream */
         cw_wave_sync();
     }

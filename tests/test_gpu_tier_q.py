@@ -5,7 +5,7 @@ through the shared stretches, the region between them is a POA task whose member
 on inside that region is chosen to reach the parts of the kernel the synthetic PacBio piles seldom do:
   * nodes with more than three in-edges (in-edge ordinal 3 = "fourth or later": decided from kept DP rows),
   * predecessors further back than the LDS ring of rows reaches (long insertions and deletions: kept rows read back from the slab),
-  * graphs that outgrow the tier's 64 nodes or 192 edges (handed to tier S and redone there),
+  * graphs that outgrow the tier's 64 nodes or 184 edges (handed to tier S and redone there),
   * tasks of very different sizes side by side in one wave (the four rows of a wave advance in lock step).
 Bit-exact: consensus bytes, status, solid set."""
 import random
