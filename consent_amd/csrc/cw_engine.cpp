@@ -444,7 +444,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
        step time is unchanged. */
     const uint32_t sort_lds = knob_u("CW_SORT_LDS", 16384, 0, CW_SORT_LDS_CLS);
     const uint32_t sort_thr = knob_u("CW_SORT_THREADS", 256, 128, 1024) / 64 * 64;
-    const uint32_t q_waves = knob_u("CW_Q_WAVES", CW_POAQ_WAVES % 3 == 0 ? 3 : 2, 1, CW_POAQ_WAVES); /* waves per tier-Q work-group (four tasks per wave; round 5: three-wave work-groups of 40 KB, four per CU) */
+    const uint32_t q_waves = knob_u("CW_Q_WAVES", CW_POAQ_WAVES % 3 == 0 ? 3 : CW_POAQ_WAVES % 2 == 0 ? 2 : 1, 1, CW_POAQ_WAVES); /* waves per tier-Q work-group (four tasks per wave; round 5: three-wave work-groups of 40 KB, four per CU) */
     const uint32_t q_lds_cu = e->prop.sharedMemPerMultiprocessor ? (uint32_t)e->prop.sharedMemPerMultiprocessor : 160u * 1024u;
     const uint32_t q_fit = q_lds_cu / (((uint32_t)(CW_POAQ_TASK_BYTES * 4 * q_waves) + 1023u) / 1024u * 1024u);   /* work-groups whose LDS a CU holds (allocation granule: at most 1 KB) */
     const uint32_t q_most = q_fit < CW_POAQ_WAVES / q_waves ? (q_fit ? q_fit : 1u) : CW_POAQ_WAVES / q_waves;

@@ -20,6 +20,7 @@
 
 #include "cw_device.h"
 
+typedef __attribute__((address_space(3))) uint32_t* cw_l32w;
 typedef __attribute__((address_space(3))) const uint32_t* cw_l32; /* a pile's words staged in LDS ... */
 typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or where the batch has them */
 #define CW_IDX_THREADS 1024
@@ -32,6 +33,9 @@ typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or wher
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 #ifndef CW_IDX_BYTES
+#ifndef CW_IDX_BYTES_RTN
+#define CW_IDX_BYTES_RTN 0 /* 1: the byte counters of phase A with returning adds, as round 4 had them */
+#endif
 #define CW_IDX_BYTES 1 /* phase A counts in byte counters first (two halves of the key space for k = 9); 0 = the nibble table only */
 #endif
 #ifndef CW_IDX_BYTES_MIN_N
@@ -453,14 +457,32 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (tid < 8) flags[tid] = 0;
             for (uint32_t h = 0; h < n_half; ++h) {
                 for (uint32_t i = tid; i < bwords; i += CW_IDX_THREADS) tab[i] = 0;
+                if (tid == 1 || tid == 2) flags[tid] = 0;
                 __syncthreads();
                 if (h == 0) CW_PROF(sc.ctr, 55, tid == 0);
+#if CW_IDX_BYTES_RTN /* rounds 4: a returning add, the old byte looked at */
                 CW_IDX_PASS_BLOCKR({
                     if (n_half > 1u && (key >> 17) != h) continue;
                     const uint32_t kk = key & (bkeys - 1u), sh8 = (kk & 3u) * 8u;
                     const uint32_t old = atomicAdd(&tab[kk >> 2], 1u << sh8);
                     if (((old >> sh8) & 255u) >= 200u) flags[0] = 1; /* (a byte cannot carry into its neighbour unseen: the add that takes it from 255 to 0 returns 255) */
                 })
+#else
+                /* Round 5: fire-and-forget adds.  Nobody waits for an add to come back, so the pass runs at the rate the LDS takes the adds instead of
+                   at the latency of a returning atomic per k-mer and thread; whether a byte overflowed is decided AFTER the pass, exactly: a word holds
+                   the sum of its four counters x 256^b, so as long as no counter passes 255 the bytes ARE the counts, and every overflow lowers the sum
+                   of all bytes of the table by 255 (a carry into the next byte) or 256 (out of the word) against the number of adds made.  The export
+                   scan reads every word anyway and adds the bytes up (v_sad_u8); a table whose byte sum is not the number of k-mers counted sends the
+                   window to the nibble path below, as a counter at 200 did. */
+                uint32_t my_adds = 0;
+                CW_IDX_PASS_BLOCKR({
+                    if (n_half > 1u && (key >> 17) != h) continue;
+                    const uint32_t kk = key & (bkeys - 1u), sh8 = (kk & 3u) * 8u;
+                    (void)__hip_atomic_fetch_add((cw_l32w)(tab + (kk >> 2)), 1u << sh8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++my_adds;
+                })
+                { const uint32_t ws_ = (uint32_t)cw_wave_sum((int)my_adds); if (lane == 0) atomicAdd(&flags[1], ws_); }
+#endif
                 __syncthreads();
                 CW_PROF(sc.ctr, 0, tid == 0);
                 if (flags[0]) { ok8 = false; break; }
@@ -472,15 +494,20 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     const uint32_t c = (((v & 0x7F7F7F7Fu) + addt) | v) & 0x80808080u;
                     return ((c >> 7) | (c >> 14) | (c >> 21) | (c >> 28)) & 0xFu;
                 };
-                uint32_t m[8];
+                uint32_t m[8], bsum = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     m[i] = 0u;
                     if ((uint32_t)i < BNI) {
                         const uint4 v4 = *(const uint4*)&tab[(qbase + (uint32_t)i * 64u) * 4u];
                         m[i] = cmask8(v4.x) | (cmask8(v4.y) << 4) | (cmask8(v4.z) << 8) | (cmask8(v4.w) << 12);
+                        bsum = __builtin_amdgcn_sad_u8(v4.x, 0u, bsum); bsum = __builtin_amdgcn_sad_u8(v4.y, 0u, bsum);
+                        bsum = __builtin_amdgcn_sad_u8(v4.z, 0u, bsum); bsum = __builtin_amdgcn_sad_u8(v4.w, 0u, bsum);
                     }
                 }
+#if !CW_IDX_BYTES_RTN
+                { const uint32_t ws_ = (uint32_t)cw_wave_sum((int)bsum); if (lane == 0) atomicAdd(&flags[2], ws_); } /* complete after the barriers of the scan below */
+#endif
                 CW_PROF(sc.ctr, 56, tid == 0);
                 uint32_t offs[8], wtot = 0;
 #pragma unroll
@@ -493,6 +520,9 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 uint32_t total;
                 uint32_t woff = cw_block_exscan(lane == 0 ? wtot : 0u, scan_tmp, &total);
                 woff = (uint32_t)cw_lane_value((int)woff, 0);
+#if !CW_IDX_BYTES_RTN
+                if (flags[1] != flags[2]) { ok8 = false; break; } /* a counter passed 255: the bytes are not the counts */
+#endif
                 fits8 = written + total <= w_solid_cap;
                 if (!fits8) break;
 #pragma unroll

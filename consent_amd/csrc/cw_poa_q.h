@@ -63,20 +63,33 @@ __device__ __forceinline__ unsigned q_scan_max_u32(unsigned v) {
 #include "cw_poa_q0.h"
 #else
 
+#ifndef CW_POAQ_NC
 #define CW_POAQ_NC 64
-#define CW_POAQ_EC 184 /* (with 64 nodes and the ring: 3392 bytes a task, 40 704 a three-wave work-group -- four of them are a CU's 160 KB to the byte) */
+#endif
+#ifndef CW_POAQ_EC
+#define CW_POAQ_EC 184
+#endif
+/* CW_POAQ_EC 184: ( (with 64 nodes and the ring: 3392 bytes a task, 40 704 a three-wave work-group -- four of them are a CU's 160 KB to the byte) */
 #define CW_POAQ_LC 31
 #define CW_NONE8 0xFFu
 static_assert(CW_POAQ_NC < 255 && CW_POAQ_EC < 255 && CW_POAQ_LC < 255, "tier Q keeps node ids, DP rows, edge ids and sequence positions in bytes");
-#define CW_POAQ_RING 8 /* rows of the LDS ring (a power of two): 64 bytes each */
+#ifndef CW_POAQ_RING
+#define CW_POAQ_RING 8
+#endif
+/* CW_POAQ_RING: rows of the LDS ring (a power of two): 64 bytes each */
 #define CW_POAQ_CODE_WORDS ((CW_POAQ_NC + 3) / 4 * 16)
 #define CW_POAQ_GFLAG_WORDS (CW_POAQ_NC / 32 + 2)
 /* graph arrays of a task (PoaQ, poaq_carve): the row words, then bytes */
 #define CW_POAQ_GRAPH_BYTES ((4 * CW_POAQ_NC + (3 + (CW_CONS_HEAVIEST_BUNDLE ? 1 : 0)) * CW_POAQ_EC + 14 * CW_POAQ_NC + 4 * (CW_POAQ_LC + 1) + 15) / 16 * 16)
 #define CW_POAQ_TASK_BYTES ((CW_POAQ_GRAPH_BYTES + CW_POAQ_RING * 64 + CW_POAQ_CODE_WORDS * 4 + CW_POAQ_GFLAG_WORDS * 4 + 15) / 16 * 16)
 #define CW_POAQ_SLAB_BYTES ((CW_POAQ_NC + 1) * 64) /* per task, global: kept rows (stride 16 words) */
+#ifndef CW_POAQ_WAVES
 #define CW_POAQ_WAVES 12 /* at most: 48 tasks per CU */
-#define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
+#endif
+#ifndef CW_POAQ_ROUTE_NODES
+#define CW_POAQ_ROUTE_NODES 60
+#endif
+/* CW_POAQ_ROUTE_NODES:  tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
 static_assert(CW_POAQ_CODE_WORDS >= CW_POAQ_NC + 1, "the merge's rank histogram borrows the code words");
 
 typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));

@@ -146,6 +146,35 @@ def test_high_identity_deep_piles_use_the_global_anchor_matrix(engines):
     assert all(int(x) == ca.WIN_CONSENSUS for x in got.status[:3])
 
 
+@pytest.mark.parametrize("occ", [254, 255, 256, 257, 300, 511, 512, 513, 1030])
+def test_byte_counters_hand_over_exactly_at_256_occurrences(engines, occ):
+    """Phase A of the index kernel counts k-mers in byte counters with fire-and-forget adds (round 5) and decides afterwards whether a counter
+    overflowed: the bytes of the table must add up to the number of k-mers counted.  A marker 9-mer occurs `occ` times in the pile (two or
+    more copies in some sequences): up to 255 the bytes are the counts, from 256 on the window takes the nibble path -- the solid set and the
+    consensus are the oracle's on both sides of the edge, and when two keys of one table word overflow together."""
+    rng = random.Random(occ)
+    marker, marker2 = "ACGTTGCAA", "ACGTTGCAC"  # neighbours in the key space: the same 32-bit word of the byte table
+    truth = rand_seq(rng, 420)
+    depth = 130
+    per = [occ // depth + (1 if s < occ % depth else 0) for s in range(depth)]
+    pile = []
+    for s in range(depth):
+        seq = mutate(rng, truth, 0.1)
+        cuts = sorted(rng.sample(range(20, len(seq) - 20), per[s])) if per[s] else []
+        out, last = [], 0
+        for c in cuts:
+            out.append(seq[last:c])
+            out.append(marker if occ != 1030 or rng.random() < 0.5 else marker2)
+            last = c
+        out.append(seq[last:])
+        pile.append("".join(out))
+    prm = (9, 4, 8, 2, 150)
+    hb = ca.pack_piles([pile, [mutate(rng, truth, 0.1) for _ in range(40)]])
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb, threads=4)
+    assert_same(got, exp, 2, f"{occ} occurrences")
+
+
 def test_out_of_order_anchors_in_most_of_a_deep_pile(engines):
     """Round 2's chain scoring: sequences with an out-of-order anchor stay in the presence bits except at those anchors, whose pairs come
     from correction rows.  Here two unique stretches of the window are exchanged in most sequences (150 dirty sequences: masks of three
