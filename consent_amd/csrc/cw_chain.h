@@ -21,7 +21,6 @@
 #include "cw_index.h"
 #include "cw_poa.h" /* tier capacities for the routing rule */
 #include "cw_poa_q.h"
-#include "cw_poa_h.h"
 
 #define CW_CH_WAVES 4
 #ifndef CW_CH_SLAB
@@ -363,8 +362,8 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                        (a task that outgrows tier S is redone in tier L, the scarcest one) */
                     const uint32_t est_s = (e_mx * (15u + e_n / 5u) + 9u) / 10u;
                     /* tier Q (four tasks per wave, cw_poa_q.h): members of at most 31 bases and a graph that should stay small */
-                    /* tier H (two tasks per wave, cw_poa_h.h): members of 32 .. 63 bases, graph expected to stay inside 128 nodes */
-                    const bool fits_h = sc.use_h != 0u && e_mx <= (uint32_t)CW_POAH_LC && e_mx >= sc.h_min_len && est <= (uint32_t)CW_POAH_ROUTE_NODES;
+                    /* tier H (two tasks per wave, cw_poa_q.h): members of up to 63 bases, graph expected (depth-aware) to stay inside its 128 nodes */
+                    const bool fits_h = sc.use_h != 0u && e_mx <= (uint32_t)CW_POAH_LC && e_mx >= sc.h_min_len && est_s <= (uint32_t)CW_POAH_ROUTE_NODES;
                     const bool fits_s = est_s <= sc.s_route_cells && e_mx <= (uint32_t)CW_POA_LC; /* s_route_cells: a node count since round 4 */
                     const uint32_t tier = !poa ? 0xFFu
                                           : (sc.use_q && e_mx <= (uint32_t)CW_POAQ_LC && est_s <= (uint32_t)CW_POAQ_ROUTE_NODES) ? 4u

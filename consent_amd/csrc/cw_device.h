@@ -74,7 +74,7 @@ struct PoaMember {
 };
 
 #define CW_TIERS 6 /* POA memory tiers: 0 = S (LDS), 1 = M1, 2 = M2, 3 = L (graph in LDS, matrix in a slab), 4 = G (all global), 5 = H (two tasks per wave,
-                      cw_poa_h.h); list 0 is tier Q's (four tasks per wave, cw_poa_q.h) */
+                      cw_poa_q.h); list 0 is tier Q's (four tasks per wave, cw_poa_q.h) */
 #define CW_PROF_SLOTS 128
 
 /* Batch-wide counters (one struct in scratch, zeroed before every run). */
@@ -93,6 +93,8 @@ struct BatchCounters {
     uint32_t next_chain;          /* work-stealing cursor of the chain kernel */
     unsigned long long prof[CW_PROF_SLOTS]; /* cycle totals per phase (0-32; tier H: 64-68), longest single task per POA tier (36-40), see cw_debug_profile; 72 + 12 t ..: row / trip
                                                counts of tier t in a -DCW_DIAG build (cw_poa.h PoaMem::diag) */
+    uint32_t n_fin_retry;         /* windows the finish kernel's first pass handed to its second (cw_finish.h) */
+    uint32_t next_fin_retry;
 };
 
 struct DevBatch {
@@ -130,15 +132,17 @@ struct DevScratch {
     uint64_t ablock_units;         /* capacity in 16-byte units */
     unsigned long long* ex_fallback; /* index kernel: per-work-group exact table of saturated keys for very deep piles (CW_EXG_SLOTS each) */
     uint4* task_dbg;               /* NULL unless CW_TASK_TRACE is set: per task (start, duration) in 1024-cycle units, tier|rc|pass, wave */
+    uint32_t* fin_retry;           /* finish kernel: windows whose strings outgrew the first pass (n_windows entries) */
     uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */
     uint8_t* q_slab;               /* tier Q (cw_poa_q.h): per resident task CW_POAQ_SLAB_BYTES of kept DP rows */
+    uint8_t* h_slab;               /* tier H: per resident task CW_POAH_SLAB_BYTES of kept DP rows and code words */
     uint32_t use_q;                /* route small tasks to tier Q (cw_poa_q.h); 0 = tier S takes them (CW_NO_TIER_Q) */
     uint32_t s_route_cells;        /* tier S takes a task whose graph is expected to stay below this many nodes (its capacity is CW_POA_NC; a task that outgrows
                                       it is redone in tier L, late).  (Until round 3: a bound on the cells of its LDS matrix, hence the name.) */
     uint32_t m1_route_depth;       /* tier M1 is chosen with the depth-aware graph estimate too (deep piles of ~100-base members outgrow its 256 nodes) */
-    uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1; 2 = also what tier S would take (CW_TIER_H) */
+    uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1 or further; 2 (default) = also what tier S would take (CW_TIER_H) */
     uint32_t h_min_len;            /* shortest "longest member" tier H takes (CW_H_MIN_LEN, default CW_POAH_MIN_LEN) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */

@@ -9,7 +9,6 @@
 #include "cw_chain.h"
 #include "cw_poa.h"
 #include "cw_poa_q.h"
-#include "cw_poa_h.h"
 #include "cw_finish.h"
 #include "cw_extract.h"
 #include "cw_stitch.h"
@@ -78,11 +77,11 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
     t[3] = {(l_wgs * 3u / 2u + 8u) * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
     const uint64_t bs = (uint64_t)n_windows / 16u + 8u;
     t[4] = {bs < big_slots ? (uint32_t)bs / 4u * 4u : big_slots, big_slab_bytes()};
-    t[5] = {CW_AID_ENV("CW_TIER_H") ? (uint32_t)cus * 6 * 2 * CW_POAH_WAVES : 8u, CW_POAH_SLAB_BYTES}; /* tier H (opt-in): a slab per 32-lane half, at most five work-groups of four halves per CU */
+    t[5] = {8u, 64u}; /* (tier H's slabs go by resident task, not by claim: ScratchPlan::hslab) */
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], qslab, pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], qslab, hslab, finretry, pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap, arena_scale;
@@ -125,7 +124,8 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     for (int t = 0; t < CW_TIERS; ++t) put(p.list[t], (size_t)p.task_cap * 4); /* list 0 = tier Q */
     for (int t = 0; t < CW_TIERS; ++t) put(p.over[t], (size_t)p.task_cap * 4);
     for (int t = 0; t < CW_TIERS; ++t) put(p.slab[t], (size_t)p.tier[t].slots * p.tier[t].slab_bytes);
-    put(p.qslab, (size_t)cus * CW_POAQ_WAVES * 4 * CW_POAQ_SLAB_BYTES); /* tier Q: kept rows of every task a CU can hold (32) */
+    put(p.qslab, (size_t)cus * CW_POAQ_WAVES * 4 * CW_POAQ_SLAB_BYTES); /* tier Q: kept rows of every task a CU can hold */
+    put(p.hslab, (size_t)cus * CW_POAH_WAVES * 2 * CW_POAH_SLAB_BYTES); /* tier H: kept rows and code words */
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
@@ -138,6 +138,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.exg, idx_wgs * CW_EXG_SLOTS * 8);
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
     put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
+    put(p.finretry, (size_t)n_windows * 4);
     p.total = o;
     return p;
 }
@@ -182,8 +183,8 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
-#ifdef CW_TEST_AIDS
-        hipFuncSetAttribute((const void*)cw_poa_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES) != hipSuccess ||
+#if CW_Q_CODES
+        hipFuncSetAttribute((const void*)cw_poa_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAH_TASK_BYTES * 2 * 6) != hipSuccess ||
 #endif
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES) != hipSuccess ||
@@ -197,7 +198,8 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POAL_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB_BIG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB_OF(CW_FIN_CB_BIG)) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
 #ifdef CW_TEST_AIDS
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
@@ -351,6 +353,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     e->last_tasks_off = p.tasks; e->last_tdbg_off = p.tdbg; e->last_task_cap = p.task_cap;
     if (sc.task_dbg) CW_HIP(hipMemsetAsync(sc.task_dbg, 0, (size_t)p.task_cap * 16, st));
     sc.fin_vis = (uint32_t*)(base + p.finvis); sc.fin_vis_words = CW_FIN_VIS_GLB_WORDS;
+    sc.fin_retry = (uint32_t*)(base + p.finretry);
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = CW_AID_ENV("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     /* grids of the four concurrent tier kernels: `yield` work-groups that run one chunk of tasks and end, then `persist` ones that loop
@@ -368,10 +371,12 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.persist_wgs[4] = 0;
     const uint32_t wgs_s = yield_wgs[0] + sc.persist_wgs[0], wgs_m1 = yield_wgs[1] + sc.persist_wgs[1], wgs_m2 = yield_wgs[2] + sc.persist_wgs[2],
                    wgs_l = yield_wgs[3] + sc.persist_wgs[3];
-    /* Tier H (two tasks per wave, cw_poa_h.h) is built, bit-identical to the oracle (tests/test_gpu_parity.py::test_tier_h_two_tasks_per_wave)
-       and OFF unless CW_TIER_H=1 (takes what would go to tier M1) or 2 (also what tier S would take): measured at depth 150 it costs 2.4 M
-       wave-cycles per task where tier M1 spends 3.1 M on the same tasks, but with its 8 waves per CU beside the other tiers the step is
-       slower (111 ms against 93 with one engine) -- DESIGN.md "Round 3".  Persistent work-groups of four halves, 29 KB of LDS each. */
+    /* Tier H (two tasks per wave on 32-lane halves, cw_poa_q.h; round 5: tier Q's code instantiated for members of up to 63 bases and graphs of up
+       to 128 nodes -- byte-sized graph arrays, recorded decisions, code words in the task's slab; it replaces round 3's opt-in kernel).  Bit-identical
+       (tests/test_gpu_tier_q.py, test_gpu_parity.py) and OFF: measured on one box at depth 150 it takes tier S's 41.7 k tasks in 27.4 ms where tier
+       S needs 28.4 -- 64 G wave-cycles against 69 -- and with its 18 waves per CU the other tiers slow down (M2 30.8 -> 36.7, L 41 -> 44 ms): step
+       61-63 ms against 55-58; depth 30: 23.6 against 22.7.  Four tasks per wave (tier Q) beat tier S's scalar-controlled row loop six to one in
+       machine time; two per wave do not: a per-lane row loop is ~100 instructions, tier S's 45.  CW_TIER_H=1|2 (test-aid build) turns it on. */
     /* Routing margins against late hand-overs.  A task that outgrows tier S or M1 is redone in tier L, whose work-groups only turn to the
        hand-over queue once their own list is empty: measured on a depth-150 batch (tools/task_trace.py), the ~150 tasks of 24-45 members
        x 27-31 bases that the depth-aware estimate put just inside tier S's 2048 cells, and the ~45 tasks of 52-64 members x 90-120 bases
@@ -383,17 +388,25 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (const char* env = CW_AID_ENV("CW_S_ROUTE_NODES")) { const int v = atoi(env); if (v >= 8 && v <= CW_POA_NC) sc.s_route_cells = (uint32_t)v; }
     sc.m1_route_depth = 1u;
     if (const char* env = CW_AID_ENV("CW_M1_ROUTE_DEPTH")) sc.m1_route_depth = (uint32_t)atoi(env);
-    sc.use_h = 0; sc.h_min_len = CW_POAH_MIN_LEN;
-    if (const char* env = CW_AID_ENV("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2) sc.use_h = (uint32_t)v; }
+    sc.use_h = 0u; sc.h_min_len = CW_POAH_MIN_LEN;
+    if (const char* env = CW_AID_ENV("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2 && CW_Q_CODES) sc.use_h = (uint32_t)v; }
     if (const char* env = CW_AID_ENV("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
     uint32_t wgs_h = 0;
-    if (sc.use_h) { uint32_t per_cu = 4; if (const char* env = CW_AID_ENV("CW_WGS_H")) { const int v = atoi(env); if (v >= 1 && v <= 5) per_cu = (uint32_t)v; } wgs_h = (uint32_t)cus * per_cu; }
+    const uint32_t h_waves = 3; /* waves per tier-H work-group (two tasks per wave) */
+    if (sc.use_h) {
+        const uint32_t lds_cu = e->prop.sharedMemPerMultiprocessor ? (uint32_t)e->prop.sharedMemPerMultiprocessor : 160u * 1024u;
+        const uint32_t fit = lds_cu / (((uint32_t)(CW_POAH_TASK_BYTES * 2 * h_waves) + 1023u) / 1024u * 1024u);
+        uint32_t per_cu = fit < CW_POAH_WAVES / h_waves ? (fit ? fit : 1u) : CW_POAH_WAVES / h_waves;
+        if (const char* env = CW_AID_ENV("CW_WGS_H")) { const int v = atoi(env); if (v >= 1 && (uint32_t)v <= per_cu) per_cu = (uint32_t)v; }
+        wgs_h = (uint32_t)cus * per_cu;
+    }
     sc.persist_wgs[5] = wgs_h;
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2 + wgs_h;
     if (CW_AID_ENV("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
     sc.use_q = CW_AID_ENV("CW_NO_TIER_Q") ? 0u : 1u;
     sc.q_slab = base + p.qslab;
+    sc.h_slab = base + p.hslab;
     for (int t = 0; t < CW_TIERS; ++t) {
         if (t) { sc.tier_list[t] = (uint32_t*)(base + p.list[t]); sc.over_list[t] = (uint32_t*)(base + p.over[t]); }
         sc.slab[t] = base + p.slab[t]; sc.slab_bytes[t] = p.tier[t].slab_bytes; sc.slots[t] = p.tier[t].slots;
@@ -464,18 +477,18 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         sid = stage_begin(e, st, "poa_q");
         cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, st>>>(db, sc);
         stage_end(e, st, sid);
+#if CW_Q_CODES
+        if (wgs_h) {
+            sid = stage_begin(e, st, "poa_h");
+            cw_poa_h_kernel<<<wgs_h, 64 * h_waves, CW_POAH_TASK_BYTES * 2 * h_waves, st>>>(db, sc);
+            stage_end(e, st, sid);
+        }
+#endif
         CW_HIP(hipEventRecord(e->ev_fork, st));
         for (int i = 0; i < 2; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
         sid = stage_begin(e, e->side[1], "poa_m2");
         cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
         stage_end(e, e->side[1], sid);
-#ifdef CW_TEST_AIDS
-        if (wgs_h) {
-            sid = stage_begin(e, e->side[0], "poa_h");
-            cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
-            stage_end(e, e->side[0], sid);
-        }
-#endif
         sid = stage_begin(e, e->side[0], "poa_m1");
         cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
         stage_end(e, e->side[0], sid);
@@ -497,13 +510,6 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, e->side[1], "poa_m2");
     cw_poa_slab_kernel<M2_ARGS, 0><<<wgs_m2, 64 * CW_POAM2_WAVES, lds_m2, e->side[1]>>>(db, sc);
     stage_end(e, e->side[1], sid);
-#ifdef CW_TEST_AIDS
-    if (wgs_h) { /* tier H shares tier M1's stream (a stream of its own would be a fifth hardware queue per engine): H first, then what is left for M1 */
-        sid = stage_begin(e, e->side[0], "poa_h");
-        cw_poa_h_kernel<<<wgs_h, 64 * CW_POAH_WAVES, CW_POAH_TASK_LDS * 2 * CW_POAH_WAVES, e->side[0]>>>(db, sc);
-        stage_end(e, e->side[0], sid);
-    }
-#endif
     sid = stage_begin(e, e->side[0], "poa_m1");
     cw_poa_slab_kernel<M1_ARGS, 0><<<wgs_m1, 64 * CW_POAM1_WAVES, lds_m1, e->side[0]>>>(db, sc);
     stage_end(e, e->side[0], sid);
@@ -514,8 +520,15 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     hipStream_t ms = e->stream;
     if (ms != st) CW_HIP(hipStreamWaitEvent(ms, e->ev_fork, 0));
     sid = stage_begin(e, ms, "poa_q");
-    cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, ms>>>(db, sc); /* four tasks per wave, one work-group per CU */
+    cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, ms>>>(db, sc); /* four tasks per wave */
     stage_end(e, ms, sid);
+#if CW_Q_CODES
+    if (wgs_h) { /* two tasks per wave; hands what outgrows it to tier L's live queue, as tier S does */
+        sid = stage_begin(e, ms, "poa_h");
+        cw_poa_h_kernel<<<wgs_h, 64 * h_waves, CW_POAH_TASK_BYTES * 2 * h_waves, ms>>>(db, sc);
+        stage_end(e, ms, sid);
+    }
+#endif
     sid = stage_begin(e, ms, "poa");
     cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, ms>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, ms, sid);
@@ -531,7 +544,10 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     {
         uint32_t grid = (batch->n_windows + CW_FIN_WAVES - 1) / CW_FIN_WAVES;
         if (grid > (uint32_t)cus * 2) grid = (uint32_t)cus * 2;
-        cw_finish_kernel<<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
+        cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false><<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
+        /* second pass: the windows whose strings outgrew the first pass's buffers (normally none: the kernel reads one counter and ends) */
+        const uint32_t grid2 = batch->n_windows < 64u ? batch->n_windows : 64u;
+        cw_finish_kernel<CW_FIN_CB_BIG, 1, true><<<grid2, 64, CW_FIN_SLAB_OF(CW_FIN_CB_BIG), st>>>(db, sc, e->prm, fo);
     }
     stage_end(e, st, sid);
     /* feedback for the next batch's linger_wgs (pinned destination: asynchronous) */
@@ -568,7 +584,7 @@ int cw_poll(cw_engine* e) {
     int bulk = 0, done = 0;
     for (int i = 0; i < e->n_stages; ++i) {
         const char* n = e->stage_name[i];
-        if (strcmp(n, "poa") && strcmp(n, "poa_m1") && strcmp(n, "poa_m2")) continue;
+        if (strcmp(n, "poa") && strcmp(n, "poa_m1") && strcmp(n, "poa_m2") && strcmp(n, "poa_h")) continue;
         ++bulk;
         q = hipEventQuery(e->ev1[i]);
         if (q == hipSuccess) ++done;

@@ -16,7 +16,9 @@
 #include "cw_device.h"
 
 #define CW_FIN_WAVES 4
-#define CW_FIN_CB 3072        /* string capacity per buffer              */
+#define CW_FIN_CB 3072        /* string capacity per buffer, first pass                                    */
+#define CW_FIN_CB_BIG 32768   /* ... of the second pass (round 5): windows whose consensus or polish outgrew the first are done again, one wave per
+                                 work-group with 107 KB of LDS -- k < 8 (chance anchors: consensuses of several templates), heaviest-bundle policy */
 #ifndef CW_FIN_VIS_WORDS
 #define CW_FIN_VIS_WORDS 1024 /* visited bitmap in LDS: up to 32768 solid k-mers */
 #endif
@@ -27,7 +29,8 @@
    solid keys instead of 1024 (a depth-150 pile has ~2500, so its lookups are binary searches in global memory; round 4 tried) makes the
    work-group 124 KB, one per CU, and the kernel 1.75x as long at depth 30 and 1.15x at depth 150; a third work-group per CU (smaller buffers) changed nothing */
 #define CW_FIN_K16_MAX ((CW_FIN_VIS_WORDS + CW_FIN_SKEYS) * 32 / 17 / 64 * 64) /* compact table: n / 32 bitmap words + n / 2 words of 16-bit keys in the bitmap's and the key table's space (3840) */
-#define CW_FIN_SLAB (3 * CW_FIN_CB + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256 + 4 * CW_FIN_SKEYS + 16)
+#define CW_FIN_SLAB_OF(CB) (3 * (CB) + 4 * CW_FIN_VIS_WORDS + CW_FIN_FRAMES * 48 + 256 + 4 * CW_FIN_SKEYS + 16)
+#define CW_FIN_SLAB CW_FIN_SLAB_OF(CW_FIN_CB)
 
 struct FinOut {
     char* cons;
@@ -204,6 +207,7 @@ struct FinLds {
     uint32_t* f_dist;
     uint32_t* f_key;
     uint32_t* tmp;   /* 64 words            */
+    uint32_t cb;     /* capacity of s / alt / path (CW_FIN_CB, or CW_FIN_CB_BIG in the second pass) */
 };
 
 __device__ __forceinline__ uint32_t fin_vis_get(const FinLds& M, uint32_t w) { return M.vis_glb ? ((fin_g32)M.vis)[w] : ((fin_l32)M.vis)[w]; }
@@ -236,14 +240,14 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                 const bool seen = (fin_vis_get(M, ci >> 5) >> (ci & 31)) & 1u;
                 found = (ck == dst);
                 if (!found && !seen) {
-                    if (plen + 2 > CW_FIN_CB) return -1;
+                    if (plen + 2 > M.cb) return -1;
                     if (lane == 0) { fin_vis_or(M, ci >> 5, 1u << (ci & 31)); M.path[plen] = "ACGT"[ck & 3u]; }
                     plen++; dist++;
                     cw_wave_sync();
                     n = fin_neighbours(c, ck, 0, nbk, nbi, lane);
                     it = 0;
                 } else if (found) {
-                    if (plen + 2 > CW_FIN_CB) return -1;
+                    if (plen + 2 > M.cb) return -1;
                     if (lane == 0) M.path[plen] = "ACGT"[ck & 3u];
                     plen++;
                 } else {
@@ -263,7 +267,7 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                 const bool seen = (fin_vis_get(M, ci >> 5) >> (ci & 31)) & 1u;
                 found = (ck == dst);
                 if (!found && !seen) {
-                    if (depth + 1 >= CW_FIN_FRAMES || plen + 2 > CW_FIN_CB) return -1;
+                    if (depth + 1 >= CW_FIN_FRAMES || plen + 2 > M.cb) return -1;
                     branches++;
                     if (lane == 0) {
                         fin_vis_or(M, ci >> 5, 1u << (ci & 31));
@@ -278,7 +282,7 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                     descended = true;
                     break;
                 } else if (found) {
-                    if (plen + 2 > CW_FIN_CB) return -1;
+                    if (plen + 2 > M.cb) return -1;
                     if (lane == 0) M.path[plen] = "ACGT"[ck & 3u];
                     plen++;
                 } else {
@@ -428,7 +432,7 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
                 if (bal) { bpos = p0 + (uint32_t)(__ffsll((long long)bal) - 1); break; }
             }
             const uint32_t new_len = len - rl + (uint32_t)region_len;
-            if (new_len > CW_FIN_CB) return -1;
+            if (new_len > M.cb) return -1;
             for (uint32_t q = lane; q < new_len; q += 64) {
                 uint8_t ch;
                 if (q < bpos) ch = M.s[q];
@@ -464,14 +468,17 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
     return (int)len;
 }
 
-__global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b, DevScratch sc, cw_params prm, FinOut out) {
+/* CB: string capacity; WAVES: waves per work-group; RETRY: the second pass over the windows the first pass could not hold (sc.fin_retry) */
+template <int CB, int WAVES, bool RETRY>
+__global__ void __launch_bounds__(64 * WAVES) cw_finish_kernel(DevBatch b, DevScratch sc, cw_params prm, FinOut out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* slab = lds + (size_t)wave * CW_FIN_SLAB;
+    uint8_t* slab = lds + (size_t)wave * CW_FIN_SLAB_OF(CB);
     FinLds M;
-    uint8_t* buf0 = slab; uint8_t* buf1 = slab + CW_FIN_CB;
-    M.path = slab + 2 * CW_FIN_CB;
-    uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CW_FIN_CB);
+    M.cb = CB;
+    uint8_t* buf0 = slab; uint8_t* buf1 = slab + CB;
+    M.path = slab + 2 * CB;
+    uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CB);
     M.vis = vis_lds; M.vis_glb = false;
     uint32_t* skey_lds = vis_lds + CW_FIN_VIS_WORDS; /* CW_FIN_SKEYS + 4 words, right behind the bitmap: the compact table runs through both */
     M.f_nbk = skey_lds + CW_FIN_SKEYS + 4;
@@ -481,11 +488,13 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
     M.f_key = M.f_dist + CW_FIN_FRAMES;
     M.tmp = M.f_key + CW_FIN_FRAMES; /* 64 words */
 
+    const uint32_t n_retry = RETRY ? min(sc.ctr->n_fin_retry, b.n_windows) : 0u;
     for (;;) {
         uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(&sc.ctr->next_finish, 1u);
+        if (lane == 0) w = atomicAdd(RETRY ? &sc.ctr->next_fin_retry : &sc.ctr->next_finish, 1u);
         w = (uint32_t)__shfl((int)w, 0);
-        if (w >= b.n_windows) break;
+        if (RETRY) { if (w >= n_retry) break; w = sc.fin_retry[w]; }
+        else if (w >= b.n_windows) break;
         const WinInfo wi = sc.win[w];
         const uint32_t s0 = b.win_first_seq[w];
         const uint64_t o_beg = out.cons_off[w], o_cap = out.cons_off[w + 1] - o_beg;
@@ -514,7 +523,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                 for (int o = 1; o < 64; o <<= 1) { uint32_t x = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += x; }
                 const uint32_t off = total + inc - sl;
                 const uint32_t tot = total + (uint32_t)__shfl((int)inc, 63);
-                if (tot > CW_FIN_CB) { bad = true; break; }
+                if (tot > (uint32_t)CB) { bad = true; break; }
                 if (sl) {
                     const uint8_t* src = sc.arena + sc.seg_off[wi.seg_base + g];
                     for (uint32_t q = 0; q < sl; ++q) M.s[off + q] = src[q];
@@ -525,7 +534,7 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
             /* the visited bitmap of link(): in LDS for up to 32768 solid k-mers (every correction pile); the piles of assembly polishing are
                as deep as the coverage and can hold more: then this wave's slot in global memory */
             const bool vis_glb = wi.n_solid > 32u * CW_FIN_VIS_WORDS;
-            M.vis = vis_glb ? sc.fin_vis + (size_t)(blockIdx.x * CW_FIN_WAVES + wave) * sc.fin_vis_words : vis_lds; M.vis_glb = vis_glb;
+            M.vis = vis_glb ? sc.fin_vis + (size_t)(blockIdx.x * WAVES + wave) * sc.fin_vis_words : vis_lds; M.vis_glb = vis_glb;
             if (bad || wi.n_solid > 32u * sc.fin_vis_words) { status = CW_WIN_OVERFLOW; why = bad ? CW_WHY_FIN_LEN : CW_WHY_FIN_SOLID; }
             else {
                 len = (int)total;
@@ -587,6 +596,12 @@ __global__ void __launch_bounds__(64 * CW_FIN_WAVES) cw_finish_kernel(DevBatch b
                     else for (uint32_t q = lane; q < (uint32_t)len; q += 64) out.cons[o_beg + q] = (char)M.s[q];
                 }
             }
+        }
+        if (!RETRY && status == CW_WIN_OVERFLOW && (why == CW_WHY_FIN_LEN || why == CW_WHY_FIN_POLISH)) {
+            /* the strings outgrew this pass's buffers: the window goes on the list of the second pass (CW_FIN_CB_BIG), which writes its result */
+            if (lane == 0) { const uint32_t at = atomicAdd(&sc.ctr->n_fin_retry, 1u); if (at < b.n_windows) sc.fin_retry[at] = w; }
+            cw_wave_sync();
+            continue;
         }
         /* solid set for the caller */
         uint32_t n_sol = 0;

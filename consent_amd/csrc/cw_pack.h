@@ -98,8 +98,10 @@ __global__ void __launch_bounds__(256) cw_plan_need_kernel(PlanArgs a) {
     if (lane == 0) {
         /* three templates + 256, and never less than the finish kernel's own string capacity (CW_FIN_CB 3072): the slot is then not what stops a
            window whose consensus comes out several times its template (short k, spurious anchors) */
-        const unsigned long long c3 = s1 > s0 ? 3ull * a.seq_len[s0] + 256ull : 256ull;
-        a.cons_off[w] = c3 < 3072ull ? 3072ull : c3;
+        /* (k < 8: chance anchors make consensuses of several templates -- the finish kernel's second pass holds them, the slot has to as well) */
+        const unsigned long long c3 = s1 > s0 ? (a.k < 8u ? 12ull : 3ull) * a.seq_len[s0] + 256ull : 256ull;
+        const unsigned long long floor_ = a.k < 8u ? 32768ull : 3072ull; /* CW_FIN_CB_BIG / CW_FIN_CB */
+        a.cons_off[w] = c3 < floor_ ? floor_ : c3;
         a.solid_off[w] = nk / a.solid + 16ull;
     }
 }

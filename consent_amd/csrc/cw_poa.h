@@ -1458,7 +1458,11 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t l
         return (CW_SORT_CLASSES - 1) - (mc * 16u + ((max_len < 32u ? max_len : 31u) >> 1));
 #endif
     }
-    if (tier == 1 || tier == 5) { /* tier H: the two tasks of a wave advance in lock step, so neighbours in the list should be alike as well */
+    if (tier == 5) { /* tier H (cw_poa_q.h): as tier Q, the longest member in steps of four */
+        const uint32_t mc = n_members < 4u ? 0u : n_members < 8u ? 1u : n_members < 12u ? 2u : n_members < 16u ? 3u : n_members < 24u ? 4u : n_members < 32u ? 5u : n_members < 64u ? 6u : 7u;
+        return (CW_SORT_CLASSES - 1) - (mc * 16u + ((max_len < 64u ? max_len : 63u) >> 2));
+    }
+    if (tier == 1) {
         c = ((max_len * (15u + n_members / 5u) + 9u) / 10u) >> 2;
     } else {
         /* fitted on the task timeline of a depth-150 batch (tools/task_trace.py, CW_FIT): tier L time ~ members^1.76 x mean length^0.84 x

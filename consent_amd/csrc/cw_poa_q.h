@@ -63,48 +63,101 @@ __device__ __forceinline__ unsigned q_scan_max_u32(unsigned v) {
 #include "cw_poa_q0.h"
 #else
 
-#ifndef CW_POAQ_NC
-#define CW_POAQ_NC 64
-#endif
-#ifndef CW_POAQ_EC
-#define CW_POAQ_EC 184
-#endif
-/* CW_POAQ_EC 184: ( (with 64 nodes and the ring: 3392 bytes a task, 40 704 a three-wave work-group -- four of them are a CU's 160 KB to the byte) */
-#define CW_POAQ_LC 31
 #define CW_NONE8 0xFFu
-static_assert(CW_POAQ_NC < 255 && CW_POAQ_EC < 255 && CW_POAQ_LC < 255, "tier Q keeps node ids, DP rows, edge ids and sequence positions in bytes");
-#ifndef CW_POAQ_RING
-#define CW_POAQ_RING 8
-#endif
-/* CW_POAQ_RING: rows of the LDS ring (a power of two): 64 bytes each */
-#define CW_POAQ_CODE_WORDS ((CW_POAQ_NC + 3) / 4 * 16)
-#define CW_POAQ_GFLAG_WORDS (CW_POAQ_NC / 32 + 2)
-/* graph arrays of a task (PoaQ, poaq_carve): the row words, then bytes */
-#define CW_POAQ_GRAPH_BYTES ((4 * CW_POAQ_NC + (3 + (CW_CONS_HEAVIEST_BUNDLE ? 1 : 0)) * CW_POAQ_EC + 14 * CW_POAQ_NC + 4 * (CW_POAQ_LC + 1) + 15) / 16 * 16)
-#define CW_POAQ_TASK_BYTES ((CW_POAQ_GRAPH_BYTES + CW_POAQ_RING * 64 + CW_POAQ_CODE_WORDS * 4 + CW_POAQ_GFLAG_WORDS * 4 + 15) / 16 * 16)
-#define CW_POAQ_SLAB_BYTES ((CW_POAQ_NC + 1) * 64) /* per task, global: kept rows (stride 16 words) */
-#ifndef CW_POAQ_WAVES
-#define CW_POAQ_WAVES 12 /* at most: 48 tasks per CU */
-#endif
-#ifndef CW_POAQ_ROUTE_NODES
-#define CW_POAQ_ROUTE_NODES 60
-#endif
-/* CW_POAQ_ROUTE_NODES:  tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
-static_assert(CW_POAQ_CODE_WORDS >= CW_POAQ_NC + 1, "the merge's rank histogram borrows the code words");
-
 typedef unsigned short cw_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int pku_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
 __device__ __forceinline__ int pku_min(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(cw_u2, a), __builtin_bit_cast(cw_u2, b))); }
 __device__ __forceinline__ int pku_shl1(int a) { return __builtin_bit_cast(int, (cw_u2)(__builtin_bit_cast(cw_u2, a) << (cw_u2)(unsigned short)1)); }
 
-struct PoaQ { /* one task's arrays: LDS, except `keep` */
+/* One shape of the several-tasks-per-wave tiers: a task owns GW lanes (16: tier Q, four tasks per wave; 32: tier H, two), two DP columns per lane.
+   CG: the code words live in the task's global slab instead of LDS (tier H: 4 KB per task would halve the waves a CU holds). */
+template <int GW_, int NC_, int EC_, int RING_, bool CG_>
+struct PoaQT {
+    static constexpr int GW = GW_, NC = NC_, EC = EC_, RING = RING_, LC = 2 * GW_ - 1;
+    static constexpr bool CG = CG_;
+    static constexpr int CODE_WORDS = (NC_ + 3) / 4 * GW_;
+    static constexpr int GFLAG_WORDS = NC_ / 32 + 2;
+    static constexpr int GRAPH_BYTES = (4 * NC_ + (3 + (CW_CONS_HEAVIEST_BUNDLE ? 1 : 0)) * EC_ + 14 * NC_ + 4 * (LC + 1) + 15) / 16 * 16; /* row words, then bytes (poaq_carve) */
+    static constexpr int TASK_BYTES = (GRAPH_BYTES + RING_ * GW_ * 4 + (CG_ ? 0 : CODE_WORDS * 4) + GFLAG_WORDS * 4 + 15) / 16 * 16;
+    static constexpr int KEEP_WORDS = (NC_ + 1) * GW_;                          /* kept rows, GW words each */
+    static constexpr int SLAB_BYTES = (KEEP_WORDS + (CG_ ? CODE_WORDS : 0)) * 4; /* per task, global */
+    static_assert(NC_ < 255 && EC_ < 255 && LC < 255, "these tiers keep node ids, DP rows, edge ids and sequence positions in bytes");
+    static_assert((CG_ ? RING_ * GW_ : CODE_WORDS) >= NC_ + 1, "the merge's rank histogram borrows the code words (or, when they are global, the row ring)");
+    static_assert((RING_ & (RING_ - 1)) == 0 && RING_ >= 4, "the ring is a power of two and reaches beyond the three rows kept in registers");
+};
+
+#ifndef CW_POAQ_NC
+#define CW_POAQ_NC 64
+#endif
+#ifndef CW_POAQ_EC
+#define CW_POAQ_EC 184 /* (with 64 nodes and the ring: 3392 bytes a task, 40 704 a three-wave work-group -- four of them are a CU's 160 KB to the byte) */
+#endif
+#ifndef CW_POAQ_RING
+#define CW_POAQ_RING 8 /* rows of the LDS ring: a predecessor further back comes from the task's slab */
+#endif
+typedef PoaQT<16, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_RING, false> PoaQ16;
+#define CW_POAQ_LC 31
+#define CW_POAQ_TASK_BYTES (PoaQ16::TASK_BYTES)
+#define CW_POAQ_SLAB_BYTES (PoaQ16::SLAB_BYTES)
+#ifndef CW_POAQ_WAVES
+#define CW_POAQ_WAVES (CW_CONS_HEAVIEST_BUNDLE ? 10 : 12) /* at most, per CU: 48 tasks (40 with the edge weights of the heaviest-bundle policy: 3576 bytes a task) */
+#endif
+static_assert(PoaQ16::TASK_BYTES * 4 * CW_POAQ_WAVES <= 163840, "tier Q: CW_POAQ_WAVES waves of four tasks fit a CU's LDS");
+#ifndef CW_POAQ_ROUTE_NODES
+#define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
+#endif
+
+/* tier H (round 5; replaces the opt-in kernel of round 3): two tasks per wave on 32-lane halves, members of up to 63 bases, 128 nodes */
+#ifndef CW_POAH_NC
+#define CW_POAH_NC 128
+#endif
+#ifndef CW_POAH_EC
+#define CW_POAH_EC 250
+#endif
+typedef PoaQT<32, CW_POAH_NC, CW_POAH_EC, 8, true> PoaQ32;
+#define CW_POAH_LC 63
+#define CW_POAH_TASK_BYTES (PoaQ32::TASK_BYTES)
+#define CW_POAH_SLAB_BYTES (PoaQ32::SLAB_BYTES)
+#ifndef CW_POAH_WAVES
+#define CW_POAH_WAVES 18 /* at most, per CU: 36 tasks */
+#endif
+#ifndef CW_POAH_ROUTE_NODES
+#define CW_POAH_ROUTE_NODES 112 /* (the depth-aware estimate of cw_chain.h) */
+#endif
+#define CW_POAH_MIN_LEN 1
+
+/* ---- GW-lane group primitives ----------------------------------------------------------------------------------------------- */
+template <class T> __device__ __forceinline__ unsigned g_ballot(bool p) {
+    if constexpr (T::GW == 16) return (unsigned)(__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFu;
+    else return (unsigned)(__ballot(p) >> (threadIdx.x & 32u));
+}
+template <class T> __device__ __forceinline__ int g_bcast(int v, int src) { return __shfl(v, (int)(threadIdx.x & (unsigned)(64 - T::GW)) + src); }
+template <class T> __device__ __forceinline__ int g_scan_add(int v) {
+    v += CW_DPP(0, v, 0x111, 0xF); v += CW_DPP(0, v, 0x112, 0xF); v += CW_DPP(0, v, 0x114, 0xF); v += CW_DPP(0, v, 0x118, 0xF);
+    if constexpr (T::GW == 32) v += CW_DPP(0, v, 0x142, 0xA); /* lane 15 of the group's first row into its second row */
+    return v;
+}
+template <class T> __device__ __forceinline__ unsigned g_scan_max_u32(unsigned v) {
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x111, 0xF)); v = max(v, (unsigned)CW_DPP(0, (int)v, 0x112, 0xF));
+    v = max(v, (unsigned)CW_DPP(0, (int)v, 0x114, 0xF)); v = max(v, (unsigned)CW_DPP(0, (int)v, 0x118, 0xF));
+    if constexpr (T::GW == 32) v = max(v, (unsigned)CW_DPP(0, (int)v, 0x142, 0xA));
+    return v;
+}
+/* lane gl receives v of lane gl - 1 of its group; lane 0 of the group receives 0 */
+template <class T> __device__ __forceinline__ int g_shr1(int v, int gl) {
+    if constexpr (T::GW == 16) return CW_DPP(0, v, 0x111, 0xF);
+    else { const int s_ = CW_DPP(0, v, 0x138, 0xF); return gl == 0 ? 0 : s_; } /* (wave_shr:1 would hand lane 32 the other task's last lane) */
+}
+
+template <class T>
+struct PoaQ { /* one task's arrays: LDS, except `keep` (and `codes` when T::CG) */
     uint32_t* rmeta;  /* rank -> the row word (CW_RM_WORD) */
     uint8_t* plist;   /* predecessor DP rows in in-edge order (CSR) */
     uint8_t* efrom;   /* edge -> source node */
     uint8_t* enext;   /* edge -> next in-edge of the same target, CW_NONE8 at the end */
     uint8_t* ew;      /* edge -> sequences whose path uses it (heaviest-bundle policy only, else NULL) */
     uint8_t* rpred0;  /* rank -> DP row of its first predecessor (0 = virtual start) */
-    uint8_t* ncov;    /* node -> sequences through it (a task of more than 255 members goes to tier S) */
+    uint8_t* ncov;    /* node -> sequences through it (a task of more than 255 members goes to the next tier) */
     uint8_t* nal;     /* node -> 3 aligned node ids */
     uint8_t* in_head; /* node -> first in-edge, CW_NONE8 if none */
     uint8_t* in_tail;
@@ -119,14 +172,16 @@ struct PoaQ { /* one task's arrays: LDS, except `keep` */
     uint8_t* pcur;
     uint8_t* pat;
     uint8_t* sq;      /* current member, base codes */
-    uint32_t* ring;   /* CW_POAQ_RING rows x 16 words */
-    uint32_t* codes;  /* one word per four rows and lane; between a traceback and the next fill: the merge's rank histogram */
+    uint32_t* ring;   /* T::RING rows x GW words */
+    uint32_t* codes;  /* one word per four rows and lane (LDS, or global when T::CG) */
+    uint32_t* hist;   /* the merge's rank histogram: borrows the code words, or the ring */
     uint32_t* gflag;  /* one bit per rank: the row is also kept in the slab */
-    int* keep;        /* global: kept rows, 16 words each, row i at keep + 16 i */
+    int* keep;        /* global: kept rows, GW words each, row i at keep + GW i */
 };
-__device__ __forceinline__ PoaQ poaq_carve(uint8_t* p) {
-    PoaQ M;
-    const uint32_t nc = CW_POAQ_NC, ec = CW_POAQ_EC, lc1 = CW_POAQ_LC + 1;
+template <class T>
+__device__ __forceinline__ PoaQ<T> poaq_carve(uint8_t* p, uint8_t* slab) {
+    PoaQ<T> M;
+    const uint32_t nc = T::NC, ec = T::EC, lc1 = T::LC + 1;
     uint8_t* const base = p;
     M.rmeta = (uint32_t*)p; p += 4 * nc;
     M.plist = p; p += ec; M.efrom = p; p += ec; M.enext = p; p += ec;
@@ -135,16 +190,26 @@ __device__ __forceinline__ PoaQ poaq_carve(uint8_t* p) {
     M.rpred0 = p; p += nc; M.ncov = p; p += nc; M.nal = p; p += 3 * nc; M.in_head = p; p += nc; M.in_tail = p; p += nc; M.indeg = p; p += nc;
     M.r2n = p; p += nc; M.n2r = p; p += nc; M.rtmp = p; p += nc; M.nbase = p; p += nc; M.nalc = p; p += nc; M.has_out = p; p += nc;
     M.seqrank = p; p += lc1; M.pcur = p; p += lc1; M.pat = p; p += lc1; M.sq = p; p += lc1;
-    uint8_t* extra = base + CW_POAQ_GRAPH_BYTES;
-    M.ring = (uint32_t*)extra; M.codes = M.ring + CW_POAQ_RING * 16; M.gflag = M.codes + CW_POAQ_CODE_WORDS;
-    M.keep = nullptr;
+    uint32_t* extra = (uint32_t*)(base + T::GRAPH_BYTES);
+    M.ring = extra; extra += T::RING * T::GW;
+    M.keep = (int*)slab;
+    if constexpr (T::CG) { M.codes = (uint32_t*)slab + T::KEEP_WORDS; M.hist = M.ring; }
+    else { M.codes = extra; extra += T::CODE_WORDS; M.hist = M.codes; }
+    M.gflag = extra;
     return M;
 }
-/* (poaq_carve uses 4 NC + (3 | 4) EC + 14 NC + 4 (LC + 1) bytes of CW_POAQ_GRAPH_BYTES) */
+typedef __attribute__((address_space(1))) uint32_t* cwq_g32;
+template <class T> __device__ __forceinline__ void poaq_code_store(const PoaQ<T>& M, int idx, uint32_t v) {
+    if constexpr (T::CG) ((cwq_g32)M.codes)[idx] = v; else ((cwc_l32)M.codes)[idx] = v;
+}
+template <class T> __device__ __forceinline__ uint32_t poaq_code_load(const PoaQ<T>& M, int idx) {
+    if constexpr (T::CG) return ((cwq_g32)M.codes)[idx]; else return ((cwc_l32)M.codes)[idx];
+}
 
 #if CW_CONS_HEAVIEST_BUNDLE
 /* cw_policy.h CW_POA_CONSENSUS_HEAVIEST_BUNDLE on one lane (cf. poa_consensus_hb): scores by node in the row words, the chosen source in rpred0 */
-__device__ __forceinline__ uint32_t poaq_consensus_hb(const PoaQ& M, const int n, const PoaTask& t, const DevScratch& sc) {
+template <class T>
+__device__ __forceinline__ uint32_t poaq_consensus_hb(const PoaQ<T>& M, const int n, const PoaTask& t, const DevScratch& sc) {
     uint32_t* score = M.rmeta;
     uint8_t* pred = M.rpred0;
     int end = -1;
@@ -173,11 +238,13 @@ __device__ __forceinline__ uint32_t poaq_consensus_hb(const PoaQ& M, const int n
 }
 #endif
 
-/* DP fill of one member against the graph, recording the decisions.  Lane gl of the row owns columns 2gl (low half) and 2gl + 1.
+/* DP fill of one member against the graph, recording the decisions.  Lane gl of the group owns columns 2gl (low half) and 2gl + 1.
    Returns the DP row of the end cell | its column << 16 (the best sink of the last column, lowest rank on ties; overlap mode: the
    best cell of a sink's row, lowest rank then lowest column). */
-__device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int cols, const int gl) {
+template <class T>
+__device__ __forceinline__ int poaq_fill_c(const PoaQ<T>& M, const int n, const int cols, const int gl) {
     typedef __attribute__((address_space(1))) int* gint;
+    constexpr int GW = T::GW;
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     const int G4PK = pk_make(G4, G4);
     const int ROW0 = 0x00030003; /* the virtual start row: W = 0 everywhere */
@@ -190,7 +257,6 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
     gint keep = (gint)M.keep;
     int rc0 = ROW0, rc1 = ROW0, rc2 = ROW0; /* rows i-1, i-2, i-3 */
     int bs0 = (int)0x80000000, bi0 = 0, bs1 = (int)0x80000000, bi1 = 0; /* best sink cell of this lane's even / odd column */
-    int bc0 = 0, bc1 = 0;                                              /* (overlap mode: their H values decide; kept per column) */
     uint32_t acc = 0u;
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
@@ -200,8 +266,7 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
         const int srow = __builtin_bit_cast(int, (cw_s2)(__builtin_bit_cast(cw_s2, t_) * ms_pk + __builtin_bit_cast(cw_s2, xs_pk)));
         int dm, vm;
         if (CW_RM_LIN(meta)) { /* one in-edge, from the row before */
-            const int sh = CW_DPP(0, rc0, 0x111, 0xF);
-            dm = __builtin_amdgcn_alignbit(rc0, sh, 16); vm = rc0;
+            dm = __builtin_amdgcn_alignbit(rc0, g_shr1<T>(rc0, gl), 16); vm = rc0;
         } else {
             dm = CW_NEGPK; vm = CW_NEGPK;
             for (int q = 0; q < np; ++q) {
@@ -210,12 +275,11 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
                 int up;
                 if (prow == 0) up = ROW0;
                 else if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
-                else if (dist <= CW_POAQ_RING) up = (int)M.ring[(prow & (CW_POAQ_RING - 1)) * 16 + gl];
-                else up = keep[prow * 16 + gl];
+                else if (dist <= T::RING) up = (int)M.ring[(prow & (T::RING - 1)) * GW + gl];
+                else up = keep[prow * GW + gl];
                 const int qq = q < 3 ? q : 3;
                 up = pk_sub(up, pk_make(qq, qq));
-                const int sh = CW_DPP(0, up, 0x111, 0xF);                 /* lane gl - 1's pair; lane 0: nothing (its column 0 takes no diagonal) */
-                dm = pk_max(dm, __builtin_amdgcn_alignbit(up, sh, 16)); /* (col 2gl - 1, col 2gl) of the predecessor row */
+                dm = pk_max(dm, __builtin_amdgcn_alignbit(up, g_shr1<T>(up, gl), 16)); /* (col 2gl - 1, col 2gl) of the predecessor row; group lane 0: nothing (column 0 takes no diagonal) */
                 vm = pk_max(vm, up);
             }
         }
@@ -223,8 +287,8 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
         int v = pk_max(kD, kV);
         if (CW_POA_OV && gl == 0) v = (int)(((unsigned)v & 0xFFFF0000u) | 3u); /* overlap mode (cw_policy.h): column 0 is free */
         int w = pk_max(v, (v << 16) | (CW_NEG16 & 0xFFFF));                   /* the odd column sees the even one of its lane */
-        const unsigned inc = q_scan_max_u32(((unsigned)w >> 16) ^ 0x8000u);   /* the lanes' running maxima as biased unsigned numbers */
-        const unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x111, 0xF);        /* exclusive; 0 = nothing to the left */
+        const unsigned inc = g_scan_max_u32<T>(((unsigned)w >> 16) ^ 0x8000u); /* the lanes' running maxima as biased unsigned numbers */
+        const unsigned ex = (unsigned)g_shr1<T>((int)inc, gl);                 /* exclusive; 0 = nothing to the left */
         w = pk_max(w, pk_splat_lo((int)(ex ^ 0x8000u)));
         const int nv = w | 0x00030003;
         /* the codes of both columns: in-edge q (candidate ^ cell, the cell's low bits being 3) for a diagonal move, 4 + q for a vertical one, 8 for a horizontal one */
@@ -233,10 +297,10 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
         const int fV = pk_add(pku_min(pku_max(tV, pku_shl1(tV & (int)0xFFFCFFFC)), 0x00080008), 0x00040004);
         const int code = pku_min(pku_min(fD, fV), 0x00080008);
         acc |= (uint32_t)code << ((r & 3) * 4);
-        if ((r & 3) == 3) { M.codes[(r >> 2) * 16 + gl] = acc; acc = 0u; }
-        M.ring[(i & (CW_POAQ_RING - 1)) * 16 + gl] = (uint32_t)nv;
+        if ((r & 3) == 3) { poaq_code_store<T>(M, (r >> 2) * GW + gl, acc); acc = 0u; }
+        M.ring[(i & (T::RING - 1)) * GW + gl] = (uint32_t)nv;
         if (meta & 24u) {
-            if (meta & 16u) keep[i * 16 + gl] = nv;
+            if (meta & 16u) keep[i * GW + gl] = nv;
             if (CW_RM_SINK(meta)) {
                 if (CW_POA_OV) { /* H form: columns of one row are compared */
                     const int h0 = ((int)(short)(nv & 0xFFFF) >> 2) + j0 * CW_POA_GAP, h1 = (nv >> 18) + j1 * CW_POA_GAP;
@@ -251,21 +315,20 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
         }
         rc2 = rc1; rc1 = rc0; rc0 = nv;
     }
-    if (n & 3) M.codes[((n - 1) >> 2) * 16 + gl] = acc;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the kept rows are read by other lanes in the traceback */
-    (void)bc0; (void)bc1;
+    if (n & 3) poaq_code_store<T>(M, ((n - 1) >> 2) * GW + gl, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the kept rows (and global code words) are read by other lanes in the traceback */
     int bi, bj = L;
-    if (CW_POA_OV) { /* the best over the row's lanes: value, then lowest rank, then lowest column */
+    if (CW_POA_OV) { /* the best over the group's lanes: value, then lowest rank, then lowest column */
         int bs = bs0, br = bi0, bc = j0;
         if (bs1 > bs || (bs1 == bs && bi1 < br)) { bs = bs1; br = bi1; bc = j1; }
         if (bs == (int)0x80000000) br = 0x7FFFFFFF;
-        for (int o = 8; o > 0; o >>= 1) {
+        for (int o = GW / 2; o > 0; o >>= 1) {
             const int os = __shfl_xor(bs, o), orr = __shfl_xor(br, o), oc = __shfl_xor(bc, o);
             if (os > bs || (os == bs && (orr < br || (orr == br && oc < bc)))) { bs = os; br = orr; bc = oc; }
         }
         bi = br; bj = bc;
     } else {
-        bi = q_bcast((L & 1) ? bi1 : bi0, L >> 1);
+        bi = g_bcast<T>((L & 1) ? bi1 : bi0, L >> 1);
     }
     return bi | (bj << 16);
 }
@@ -273,34 +336,36 @@ __device__ __forceinline__ int poaq_fill_c(const PoaQ& M, const int n, const int
 /* Follows the recorded codes from (bi, bj) towards the virtual start; writes seqrank[j] = rank aligned to sequence position j (diagonal
    moves).  Stops in column 0: what is left of the path there is vertical and aligns nothing.  Returns false when the walk does not
    end (cannot happen; reported as an internal error). */
-__device__ __forceinline__ bool poaq_trace_c(const PoaQ& M, const int n, const int bi, const int bj, const int gl) {
+template <class T>
+__device__ __forceinline__ bool poaq_trace_c(const PoaQ<T>& M, const int n, const int bi, const int bj, const int gl) {
     typedef __attribute__((address_space(1))) const int* gcint;
+    constexpr int GW = T::GW;
     const int G4 = 4 * CW_POA_GAP, MS4 = 4 * (CW_POA_MATCH - CW_POA_GAP), XS4 = 4 * (CW_POA_MISMATCH - CW_POA_GAP);
     gcint keep = (gcint)M.keep;
     int i = bi, j = bj, trips = 0;
     while (i > 0 && j > 0) {
-        if (++trips > n + 40) return false;
+        if (++trips > n + 2 * GW + 8) return false;
         /* lane t looks at cell (i - t, j - t): a run of diagonal moves through first in-edges that lead to the rank before */
         const int ri = i - gl, cj = j - gl;
         bool ok = false;
         int nib = 15;
         uint32_t meta = 0u;
         if (ri >= 1 && cj >= 1) {
-            const uint32_t cw = M.codes[((ri - 1) >> 2) * 16 + (cj >> 1)];
+            const uint32_t cw = poaq_code_load<T>(M, ((ri - 1) >> 2) * GW + (cj >> 1));
             nib = (int)((cw >> (((cj & 1) << 4) + ((ri - 1) & 3) * 4)) & 15u);
             meta = M.rmeta[ri - 1];
             ok = nib == 0 && (int)M.rpred0[ri - 1] == ri - 1;
         }
-        const unsigned okb = q_ballot(ok);
-        const int run = __ffs((int)(~okb & 0x1FFFFu)) - 1; /* leading lanes that continue the run (0 .. 16) */
+        const unsigned okb = g_ballot<T>(ok);
+        const int run = __ffsll((long long)~(unsigned long long)okb) - 1; /* leading lanes that continue the run (0 .. GW) */
         if (run > 0) {
             if (gl < run) M.seqrank[cj - 1] = (uint8_t)(ri - 1);
             i -= run; j -= run;
             continue;
         }
-        /* one step, decided by lane 0's cell */
-        const int nib0 = q_bcast(nib, 0);
-        const uint32_t meta0 = (uint32_t)q_bcast((int)meta, 0);
+        /* one step, decided by the group's lane 0 */
+        const int nib0 = g_bcast<T>(nib, 0);
+        const uint32_t meta0 = (uint32_t)g_bcast<T>((int)meta, 0);
         if (nib0 == 8) { j--; continue; }
         const int mv = nib0 >> 2;
         int q = nib0 & 3;
@@ -308,13 +373,13 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaQ& M, const int n, const i
         if (q == 3) { /* fourth in-edge or later: the first of them whose candidate equals the cell (the values of these rows are kept) */
             const int base = (int)(meta0 & 3u);
             const int cjv = mv == 0 ? j - 1 : j;
-            const int hw = keep[i * 16 + (j >> 1)];
+            const int hw = keep[i * GW + (j >> 1)];
             const int h = (j & 1) ? (hw >> 16) : (int)(short)(hw & 0xFFFF);
             const int add = mv == 0 ? (((int)M.sq[j - 1] == base) ? MS4 : XS4) : G4;
             q = -1;
             for (int t = 3; t < np && q < 0; ++t) {
                 const int pr = (int)M.plist[off + t];
-                const int pw = pr == 0 ? 0x00030003 : keep[pr * 16 + (cjv >> 1)];
+                const int pw = pr == 0 ? 0x00030003 : keep[pr * GW + (cjv >> 1)];
                 const int pv = (cjv & 1) ? (pw >> 16) : (int)(short)(pw & 0xFFFF);
                 if (h == pv + add) q = t; /* both values carry the low bits 3 */
             }
@@ -327,11 +392,11 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaQ& M, const int n, const i
     return true;
 }
 
-/* Returns 1 = done, 2 = a capacity of this tier was exceeded, 3 = output capacity exceeded / internal.  Every value below is
-   per lane and equal inside the 16-lane row; `gl` = lane inside the row. */
-__device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
+template <class T>
+__device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
     unsigned long long _pt = __builtin_readcyclecounter();
 #define POAQ_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
+    constexpr int GW = T::GW;
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
     bool meta_ok = false;
     const unsigned lt_mask = (1u << gl) - 1u;
@@ -340,16 +405,16 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
         const int L = (int)pm.len;
-        if ((uint32_t)L > (uint32_t)CW_POAQ_LC) return 2;
+        if ((uint32_t)L > (uint32_t)T::LC) return 2;
         {
             const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
-            for (int j = gl; j < L; j += 16) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
+            for (int j = gl; j < L; j += GW) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
         }
         cw_wave_sync();
         nseq++;
         if (n == 0) { /* first member: a chain */
-            if ((uint32_t)L > (uint32_t)CW_POAQ_NC || (uint32_t)L > (uint32_t)CW_POAQ_EC) return 2;
-            for (int j = gl; j < L; j += 16) {
+            if ((uint32_t)L > (uint32_t)T::NC || (uint32_t)L > (uint32_t)T::EC) return 2;
+            for (int j = gl; j < L; j += GW) {
                 M.nbase[j] = M.sq[j]; M.ncov[j] = 1; M.nalc[j] = 0;
                 M.in_head[j] = j ? (uint8_t)(j - 1) : CW_NONE8; M.in_tail[j] = M.in_head[j];
                 M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
@@ -365,13 +430,13 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
         /* ---- per-rank metadata: the row words (CW_RM_WORD), predecessor lists, which rows the fill keeps in the slab ---- */
         if (!meta_ok) {
             int run = 0;
-            for (int w = gl; w < CW_POAQ_GFLAG_WORDS; w += 16) M.gflag[w] = 0u;
+            for (int w = gl; w < T::GFLAG_WORDS; w += GW) M.gflag[w] = 0u;
             cw_wave_sync();
-            for (int r0 = 0; r0 < n; r0 += 16) {
+            for (int r0 = 0; r0 < n; r0 += GW) {
                 const int r = r0 + gl;
                 const int node = r < n ? M.r2n[r] : 0;
                 const int d = r < n ? M.indeg[node] : 0;
-                const int inc = q_scan_add(d);
+                const int inc = g_scan_add<T>(d);
                 const int off = run + inc - d;
                 if (r < n) {
                     int q = off, first = 0;
@@ -379,7 +444,7 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                         const int pr = M.n2r[M.efrom[e]] + 1;
                         if (q == off) first = pr;
                         M.plist[q++] = (uint8_t)pr;
-                        if (r + 1 - pr > CW_POAQ_RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
+                        if (r + 1 - pr > T::RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
                             __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                     if (d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -387,41 +452,41 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                     const uint32_t np_ = (uint32_t)(d ? d : 1);
                     M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, np_ == 1u && first == r, !M.has_out[node], 0u, np_ == 1u ? first : off);
                 }
-                run += q_bcast(inc, 15);
+                run += g_bcast<T>(inc, GW - 1);
             }
             meta_ok = true;
             cw_wave_sync();
-            for (int r = gl; r < n; r += 16) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
+            for (int r = gl; r < n; r += GW) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
             cw_wave_sync();
         }
         POAQ_PROF(0);
 
         /* ---- DP fill (records the decisions), end cell ---- */
-        for (int j = gl; j < L; j += 16) M.seqrank[j] = CW_NONE8;
+        for (int j = gl; j < L; j += GW) M.seqrank[j] = CW_NONE8;
         cw_wave_sync();
-        const int be = poaq_fill_c(M, n, cols, gl);
+        const int be = poaq_fill_c<T>(M, n, cols, gl);
         cw_wave_sync();
         POAQ_PROF(1);
 
         /* ---- traceback over the code words ---- */
-        if (!poaq_trace_c(M, n, be & 0xFFFF, be >> 16, gl)) return 3;
+        if (!poaq_trace_c<T>(M, n, be & 0xFFFF, be >> 16, gl)) return 3;
         cw_wave_sync();
         POAQ_PROF(2);
 
         /* ---- merge the path into the graph: one lane per sequence position, 16 at a time (cf. poa_run) ---- */
         {
             const int n_old = n;
-            const int chunks = (L + 15) >> 4;
+            const int chunks = (L + GW - 1) / GW;
             int next_rank = -1;
             for (int c = chunks - 1; c >= 0; --c) {
-                const int j = c * 16 + gl;
+                const int j = c * GW + gl;
                 const bool act = j < L;
                 const uint32_t rk = act ? M.seqrank[j] : CW_NONE8;
-                const unsigned has = q_ballot(act && rk != CW_NONE8);
+                const unsigned has = g_ballot<T>(act && rk != CW_NONE8);
                 const unsigned later = has & ~(lt_mask | (1u << gl));
-                const int later_rank = (int)(uint32_t)q_bcast((int)rk, later ? (__ffs((int)later) - 1) : 0);
+                const int later_rank = (int)(uint32_t)g_bcast<T>((int)rk, later ? (__ffs((int)later) - 1) : 0);
                 const int qr = later ? later_rank : next_rank;
-                const int first_rank = (int)(uint32_t)q_bcast((int)rk, has ? (__ffs((int)has) - 1) : 0);
+                const int first_rank = (int)(uint32_t)g_bcast<T>((int)rk, has ? (__ffs((int)has) - 1) : 0);
                 uint32_t cur = CW_NONE8, at = CW_NONE8;
                 if (act) {
                     const int bcode = M.sq[j];
@@ -454,13 +519,13 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
             cw_wave_sync();
             int fresh_total = 0;
             for (int c = 0; c < chunks; ++c) {
-                const int j = c * 16 + gl;
+                const int j = c * GW + gl;
                 const bool act = j < L;
                 const bool fresh = act && M.pcur[j] == CW_NONE8;
-                const unsigned fb = q_ballot(fresh);
+                const unsigned fb = g_ballot<T>(fresh);
                 if (fresh) {
                     const int cur = n_old + fresh_total + __popc(fb & lt_mask);
-                    if ((uint32_t)cur < (uint32_t)CW_POAQ_NC) {
+                    if ((uint32_t)cur < (uint32_t)T::NC) {
                         M.pcur[j] = (uint8_t)cur;
                         M.nbase[cur] = M.sq[j]; M.ncov[cur] = 1; M.nalc[cur] = 0;
                         M.in_head[cur] = CW_NONE8; M.in_tail[cur] = CW_NONE8; M.indeg[cur] = 0; M.has_out[cur] = 0;
@@ -483,32 +548,32 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                 }
                 fresh_total += __popc(fb);
             }
-            if ((uint32_t)(n_old + fresh_total) > (uint32_t)CW_POAQ_NC) return 2;
+            if ((uint32_t)(n_old + fresh_total) > (uint32_t)T::NC) return 2;
             cw_wave_sync();
             if (fresh_total > 0) {
-                uint32_t* hist = M.codes; /* n_old + 1 counters: the code words are dead between the traceback and the next fill */
-                for (int r = gl; r <= n_old; r += 16) hist[r] = 0;
+                uint32_t* hist = M.hist; /* n_old + 1 counters: the code words (or the row ring) are dead between the traceback and the next fill */
+                for (int r = gl; r <= n_old; r += GW) hist[r] = 0;
                 cw_wave_sync();
                 for (int c = 0; c < chunks; ++c) {
-                    const int j = c * 16 + gl;
+                    const int j = c * GW + gl;
                     if (j < L && M.pat[j] != CW_NONE8) atomicAdd(&hist[M.pat[j]], 1u);
                 }
                 cw_wave_sync();
                 int run = 0;
-                for (int r0 = 0; r0 < n_old; r0 += 16) {
+                for (int r0 = 0; r0 < n_old; r0 += GW) {
                     const int r = r0 + gl;
                     const int hcount = r < n_old ? (int)hist[r] : 0;
-                    const int inc = q_scan_add(hcount);
+                    const int inc = g_scan_add<T>(hcount);
                     if (r < n_old) {
                         const int nr = r + run + inc;
                         const int v = M.r2n[r];
                         M.rtmp[nr] = (uint8_t)v;
                         M.n2r[v] = (uint8_t)nr;
                     }
-                    run += q_bcast(inc, 15);
+                    run += g_bcast<T>(inc, GW - 1);
                 }
                 for (int c = 0; c < chunks; ++c) {
-                    const int j = c * 16 + gl;
+                    const int j = c * GW + gl;
                     if (j < L && M.pat[j] != CW_NONE8) {
                         const int cur = M.pcur[j];
                         const int nr = (int)M.pat[j] + (cur - n_old);
@@ -518,12 +583,12 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                 }
                 cw_wave_sync();
                 n = n_old + fresh_total;
-                for (int r = gl; r < n; r += 16) M.r2n[r] = M.rtmp[r];
+                for (int r = gl; r < n; r += GW) M.r2n[r] = M.rtmp[r];
                 meta_ok = false;
                 cw_wave_sync();
             }
             for (int c = 0; c < chunks; ++c) {
-                const int j = c * 16 + gl;
+                const int j = c * GW + gl;
                 const bool act = j < L && j > 0;
                 int head = 0, cur = 0;
                 bool add = false;
@@ -533,9 +598,9 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                     for (uint32_t e = M.in_head[cur]; e != CW_NONE8; e = M.enext[e])
                         if (M.efrom[e] == (uint8_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint8_t)(M.ew[e] + 1); break; }
                 }
-                const unsigned ab = q_ballot(add);
+                const unsigned ab = g_ballot<T>(add);
                 const int total = __popc(ab);
-                if ((uint32_t)(ne + total) > (uint32_t)CW_POAQ_EC) return 2;
+                if ((uint32_t)(ne + total) > (uint32_t)T::EC) return 2;
                 if (add) {
                     const int e = ne + __popc(ab & lt_mask);
                     M.efrom[e] = (uint8_t)head; M.enext[e] = CW_NONE8;
@@ -557,10 +622,10 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
     uint32_t out_len = 0;
 #if CW_CONS_HEAVIEST_BUNDLE
     cw_wave_sync();
-    if (gl == 0) out_len = poaq_consensus_hb(M, n, t, sc);
-    out_len = (uint32_t)__shfl((int)out_len, (int)(threadIdx.x & 48u));
+    if (gl == 0) out_len = poaq_consensus_hb<T>(M, n, t, sc);
+    out_len = (uint32_t)g_bcast<T>((int)out_len, 0);
 #else
-    for (int r0 = 0; r0 < n; r0 += 16) {
+    for (int r0 = 0; r0 < n; r0 += GW) {
         const int r = r0 + gl;
         int emit = -1;
         if (r < n) {
@@ -590,7 +655,7 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
                 }
             }
         }
-        const unsigned bal = q_ballot(emit >= 0);
+        const unsigned bal = g_ballot<T>(emit >= 0);
         const uint32_t idx = out_len + (uint32_t)__popc(bal & lt_mask);
         if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
         out_len += (uint32_t)__popc(bal);
@@ -603,34 +668,42 @@ __device__ int poaq_run(const PoaQ& M, const PoaTask& t, const DevBatch& b, cons
     return 1;
 }
 
-/* ---- tier Q: four tasks per wave ------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b, DevScratch sc) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int gl = threadIdx.x & 15;
-    const uint32_t grp = threadIdx.x >> 4; /* 0 .. 4 * waves - 1 */
-    PoaQ M = poaq_carve(lds + (size_t)grp * CW_POAQ_TASK_BYTES);
-    {
-        typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
-        M.keep = (int*)(cw_gptr)(sc.q_slab + (size_t)(blockIdx.x * (blockDim.x >> 4) + grp) * CW_POAQ_SLAB_BYTES);
-    }
-    const uint32_t* list = sc.tier_list[0];
-    const uint32_t n_work = min(sc.ctr->n_tier[0], sc.list_cap);
+/* ---- tier Q (four tasks per wave) and tier H (two): one kernel body ------------------------------------------------------------------ */
+template <class T, int TIER_LIST, int NEXT_TIER, int PROF_BASE, bool PRODUCER>
+__device__ __forceinline__ void poaq_kernel_body(const DevBatch& b, const DevScratch& sc, uint8_t* lds, uint8_t* slab_base) {
+    const int gl = threadIdx.x & (T::GW - 1);
+    const uint32_t grp = threadIdx.x / T::GW; /* 0 .. (64 / GW) * waves - 1 */
+    typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
+    const PoaQ<T> M = poaq_carve<T>(lds + (size_t)grp * T::TASK_BYTES, (uint8_t*)(cw_gptr)(slab_base + (size_t)(blockIdx.x * (blockDim.x / T::GW) + grp) * T::SLAB_BYTES));
+    const uint32_t* list = sc.tier_list[TIER_LIST];
+    const uint32_t n_work = min(sc.ctr->n_tier[TIER_LIST], sc.list_cap);
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
     for (;;) {
         uint32_t mi = 0;
-        if (gl == 0) mi = atomicAdd(&sc.ctr->next_tier[0], 1u);
-        mi = (uint32_t)q_bcast((int)mi, 0);
+        if (gl == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER_LIST], 1u);
+        mi = (uint32_t)g_bcast<T>((int)mi, 0);
         if (mi >= n_work) break;
         const uint32_t ti = list[mi];
         const PoaTask t = sc.tasks[ti];
         if (t.n_members == 0) continue; /* a neutral entry (cw_chain.h "cap_ok") */
-        const int rc = poaq_run(M, t, b, sc, gl, acc);
-        if (gl == 0) poa_hand_over(sc, t, ti, rc, 0); /* rc 2: redone in tier S, whose kernel follows this one on the stream */
+        const int rc = poaq_run<T>(M, t, b, sc, gl, acc);
+        if (gl == 0) poa_hand_over(sc, t, ti, rc, NEXT_TIER);
         cw_wave_sync();
     }
-    /* per-phase cycles as the first row of every wave saw them (the four rows of a wave share one instruction stream): slots of tier G,
-       which never runs beside tier Q in practice, offset by 28 */
-    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[28 + q], acc[q]);
+    /* per-phase cycles as the first group of every wave saw them (the groups of a wave share one instruction stream) */
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[PROF_BASE + q], acc[q]);
+    if (PRODUCER) poa_producer_done(sc);
+}
+
+/* tier Q: a task that outgrows it (rc 2) is redone in tier S, whose kernel follows on the stream (hand-over list 0) */
+__global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b, DevScratch sc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    poaq_kernel_body<PoaQ16, 0, 0, 28, false>(b, sc, lds, sc.q_slab);
+}
+/* tier H: members of up to 63 bases, graphs of up to 128 nodes; a task that outgrows it goes to tier L's live queue, like tier S's */
+__global__ void __launch_bounds__(64 * 6, 5) cw_poa_h_kernel(DevBatch b, DevScratch sc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    poaq_kernel_body<PoaQ32, 5, 3, 64, true>(b, sc, lds, sc.h_slab);
 }
 
 #endif /* CW_Q_CODES */

@@ -14,6 +14,13 @@
 #define CW_POAQ_WAVES 8 /* 32 tasks per work-group: 150 KB of LDS, one work-group per CU (measured: 5 waves of 64-node slabs 26 ms, 7 x 48 13 ms, 8 x 40 8.7 ms, 10 x 32 5.2 ms for the tasks they take; the step is best here) */
 #define CW_POAQ_ROUTE_NODES 35 /* tasks expected to stay below this many nodes come here */
 #define CW_POAQ_SLAB_BYTES 64 /* (no slab in this variant) */
+/* (no tier H in this variant: cw_poa_q.h) */
+#define CW_POAH_LC 63
+#define CW_POAH_ROUTE_NODES 112
+#define CW_POAH_MIN_LEN 1
+#define CW_POAH_TASK_BYTES 64
+#define CW_POAH_SLAB_BYTES 64
+#define CW_POAH_WAVES 1
 
 /* packed DP fill of one member against the graph: lane gl owns columns 2gl and 2gl + 1 (cf. poa_fill_pk<1>) */
 __device__ __forceinline__ void poaq_fill(const PoaMem<int16_t>& M, const int n, const int cols, const int gl) {

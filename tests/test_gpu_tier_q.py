@@ -1,4 +1,4 @@
-"""GPU: tier Q (four POA tasks per wave, cw_poa_q.h) on the recorded-decision path of round 5, against the oracle.
+"""GPU: tiers Q and H (four / two POA tasks per wave, cw_poa_q.h) on the recorded-decision path of round 5, against the oracle.
 
 The piles are built so that every window has ONE variable region between two stretches every sequence shares: the anchor chain runs
 through the shared stretches, the region between them is a POA task whose members are at most 31 bases long -- tier Q's -- and what goes
@@ -31,7 +31,7 @@ def assert_same(got, exp, n, what=""):
         assert np.array_equal(got.solid_kmers(w), exp.solid_kmers(w)), f"{what} window {w}: solid set differs"
 
 
-def region_pile(rng, depth, mid_len, kind):
+def region_pile(rng, depth, mid_len, kind, cap=22):
     """left (shared) + a variable middle + right (shared); the last anchor of `left` starts 9 bases before the middle"""
     left, right = rand_seq(rng, 40), rand_seq(rng, 40)
     mid = rand_seq(rng, mid_len)
@@ -71,7 +71,7 @@ def region_pile(rng, depth, mid_len, kind):
                     out.append(rng.choice("ACGT"))
                 out.append(rng.choice("ACGT") if x < 0.12 else c)
             m = out
-        ms = "".join(m)[:22]  # member = 9 bases of the left anchor + the middle: at most 31
+        ms = "".join(m)[:cap]  # member = 9 bases of the left anchor + the middle: at most 31 (tier Q; cap 54: at most 63, tier H)
         pile.append(left + ms + right)
     return pile
 
@@ -100,13 +100,35 @@ def test_regions_of_tier_q_shapes_match_the_oracle(engine, kind):
         assert int(ctr[18]) > 0, ctr[18:24]  # some outgrew it and were redone in tier S
 
 
+@pytest.mark.parametrize("kind", ["noise", "fan", "far", "grow"])
+def test_regions_of_tier_h_shapes_match_the_oracle(aids, monkeypatch, kind):
+    """the same shapes with middles of up to 54 bases: members of 32 .. 63 bases, tier H's (two tasks per wave, code words in the slab; the
+    tier is opt-in -- measured no faster than tier S -- and switched on with the test-aid build's CW_TIER_H)"""
+    monkeypatch.setenv("CW_TIER_H", "2")
+    engine = ca.Engine(ca.Params(*PRM))
+    rng = random.Random({"noise": 31, "fan": 32, "far": 33, "grow": 34}[kind])
+    piles = []
+    for _ in range(96):
+        depth = rng.choice((3, 5, 8, 12, 20, 33, 60))
+        piles.append(region_pile(rng, depth, rng.randrange(24, 55), kind, cap=54))
+    hb = ca.pack_piles(piles)
+    got = engine.run(hb)
+    ctr, _ = engine.profile()
+    exp, _ = oracle_lib.oracle_run(ca.Params(*PRM), hb, threads=8)
+    assert_same(got, exp, len(piles), kind)
+    engine.close()
+    assert int(ctr[11]) >= 3, ctr[6:12]  # regions were tier H's tasks (list 5; deep piles and long insertions route past it)
+    if kind == "grow":
+        assert int(ctr[21]) > 0, ctr[18:24]  # some outgrew its 128 nodes / 250 edges and were redone in tier L
+
+
 def test_unlike_tasks_share_a_wave(engine):
     """a window with a 2-member region beside one with 120 members, tiny middles beside long ones, in one batch"""
     rng = random.Random(21)
     piles = []
     for w in range(128):
         depth = (2, 120, 3, 40)[w % 4]
-        piles.append(region_pile(rng, depth, (1, 22, 22, 3)[w % 4], ("noise", "fan", "far", "noise")[(w // 4) % 4]))
+        piles.append(region_pile(rng, depth, (1, 22, 50, 3)[w % 4], ("noise", "fan", "far", "noise")[(w // 4) % 4], cap=(22, 22, 54, 22)[w % 4]))
     hb = ca.pack_piles(piles)
     got = engine.run(hb)
     exp, _ = oracle_lib.oracle_run(ca.Params(*PRM), hb, threads=8)

@@ -6,6 +6,6 @@ A=$1; B=$2; R=${3:-3}; WL=${4:-pacbio_d150_msa150}
 for i in $(seq $R); do
   for L in "$A" "$B"; do
     CONSENT_AMD_LIB=$PWD/$L python bench.py --steps 10 --warmup 2 --cpu-sample 0 --pcie-steps 0 --driver-leg 0 --workload $WL 2>/dev/null | \
-      python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('$L', round(d['ms_per_step'],2), 'one engine', round(d['stage_ms_one_batch_in_flight']['total'],2), 'Q', round(d['stage_ms_one_batch_in_flight']['poa_q'],2), 'S', round(d['stage_ms_one_batch_in_flight']['poa'],2), 'M1', round(d['stage_ms_one_batch_in_flight']['poa_m1'],2), 'index', round(d['stage_ms_one_batch_in_flight']['index'],2), 'finish', round(d['stage_ms_one_batch_in_flight']['finish'],2), 'M2', round(d['stage_ms_one_batch_in_flight']['poa_m2'],2), 'L', round(d['stage_ms_one_batch_in_flight']['poa_large'],2))"
+      python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('$L', round(d['ms_per_step'],2), 'one engine', round(d['stage_ms_one_batch_in_flight']['total'],2), 'Q', round(d['stage_ms_one_batch_in_flight']['poa_q'],2), 'H', round(d['stage_ms_one_batch_in_flight'].get('poa_h',0),2), 'S', round(d['stage_ms_one_batch_in_flight']['poa'],2), 'M1', round(d['stage_ms_one_batch_in_flight']['poa_m1'],2), 'index', round(d['stage_ms_one_batch_in_flight']['index'],2), 'finish', round(d['stage_ms_one_batch_in_flight']['finish'],2), 'M2', round(d['stage_ms_one_batch_in_flight']['poa_m2'],2), 'L', round(d['stage_ms_one_batch_in_flight']['poa_large'],2))"
   done
 done

@@ -93,9 +93,9 @@ def main():
                 why_cfg[WHY.get(int(info[w, 15]), "?")] = why_cfg.get(WHY.get(int(info[w, 15]), "?"), 0) + 1
                 why_hist[WHY.get(int(info[w, 15]), str(int(info[w, 15])))] = why_hist.get(WHY.get(int(info[w, 15]), str(int(info[w, 15]))), 0) + 1
         n_cfg += 1
-        if k < 8:  # with k-mers this short most anchors are chance hits and the segmented consensus comes out several times its template: windows whose
-            n_win_short_k += nw  # consensus outgrows the finish kernel's 3072-character strings stop there (CW_WHY_FIN_LEN, documented; counted apart)
-            n_over_short_k += n_over
+        if k < 8:  # with k-mers this short most anchors are chance hits and the segmented consensus comes out several times its template (until round 5
+            n_win_short_k += nw  # 5 % of these windows stopped on the finish kernel's 3072-character strings; its second pass holds 32768): counted apart,
+            n_over_short_k += n_over  # held to the same bar
         else:
             n_win_total += nw
             n_over_total += n_over
@@ -105,8 +105,9 @@ def main():
     share = n_over_total / max(1, n_win_total)
     print(f"{n_cfg} configurations, {n_win_total + n_win_short_k} windows, {bad} differences; k >= 8: {n_over_total} of {n_win_total} windows stopped by a capacity ({share:.5f}); "
           f"k < 8: {n_over_short_k} of {n_win_short_k}; by reason: {why_hist}")
-    if share > MAX_OVERFLOW_SHARE:
-        print(f"FAILED: capacity stops above {MAX_OVERFLOW_SHARE} of the windows")
+    share_short = n_over_short_k / max(1, n_win_short_k)
+    if share > MAX_OVERFLOW_SHARE or share_short > float(os.environ.get("CW_FUZZ_CAP_BAR_SHORT_K", "0.002")):
+        print(f"FAILED: capacity stops above {MAX_OVERFLOW_SHARE} of the windows (k >= 8: {share:.5f}; k < 8: {share_short:.5f})")
         return 1
     return 1 if bad else 0
 
