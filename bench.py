@@ -171,17 +171,37 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --- strong scaling, same JSON line: the weak-scaling line below is N independent processes; what `north_star` means by
+    # "reads sharded across the 8 GPUs" is ONE process feeding N devices from one PAF + read file.  It runs FIRST, while no rank has touched its
+    # device yet -- the other ranks wait for rank 0 in the process group's rendezvous below (measured: run after the kernel legs, beside this process's idle HIP context, the same command took 2.2x as long).
+    driver_leg = None
+    if args.driver_leg:
+        if rank == 0:
+            try:
+                da = argparse.Namespace(**vars(args))
+                da.driver_copies, da.driver_reps = 1, 2
+                d = driver_measure(da, dry_reps=2)
+                driver_leg = {
+                    "windows_per_s": d["value"], "s_total": d["s_inside_cw_run_correction"], "wall_s_process": d["wall_s_process"], "n_gpus": args.gpus,
+                    "windows": d["config"]["windows"], "jobs": d["config"]["jobs"], "workers": d["config"]["workers"],
+                    "per_device_busy": d["per_device"], "ms_index": d["ms_index"], "ms_engines": d["ms_engines"],
+                    "steady_state_windows_per_s": d["steady_state_windows_per_s"], "feeder_ceiling": d["feeder_ceiling"],
+                    "workload": d["config"]["workload"], "scaling": "strong",
+                    "what": "bin/CONSENT-correction (cw_run_correction): one host process, piles cut / corrected / re-assembled on the --gpus devices, FASTA out in PAF order; the set is fixed (4.6 Mbp, 30x), so this value at N = 1, 2, 4, 8 is the strong-scaling curve",
+                }
+            except (SystemExit, Exception) as exc:  # the contract line must survive a failure of the extra leg
+                driver_leg = {"error": str(exc)[-400:]}
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     if os.environ.get("CW_BENCH_SINGLE_DEVICE"):  # test aid: several ranks on one GPU (gloo only)
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the data path has no collective (north_star: "no RCCL"): the barrier and the one max-reduce of the timing go over gloo;
@@ -196,8 +216,10 @@ def main():
             print(f"[bench] {backend} init failed ({exc}); falling back to gloo for the barrier", file=sys.stderr)
             backend = "gloo"
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()  # (rank 0 arrives here after its driver leg)
     else:
         backend = None
+    torch.cuda.set_device(local_rank)
 
     import consent_amd as ca
     from consent_amd.engine import Batch, HostBatch, Result, alloc_results, synth_host
@@ -569,32 +591,8 @@ def main():
             dc = ("kind 0 (linear)", "kind 1", "kinds 2-3", "generic", "in-edges of generic rows", "slab loads of generic rows", "rows with a flag", "tb_trips", "members with code words in LDS", "members", "rows", "rows of members <= 31 bases")
             for i, t in enumerate(("S", "M1")):  # the recorded-decision fill (cw_poa_c.h) counts by row kind
                 print(f"diag tier {t}, coded fill:", {n: int(prof[72 + 12 * i + k]) for k, n in enumerate(dc)}, file=sys.stderr)
-    # --- strong scaling, same JSON line: the weak-scaling line above is N independent processes; what `north_star` means by
-    # "reads sharded across the 8 GPUs" is ONE process feeding N devices from one PAF + read file.  Every rank gives its device back first.
-    if args.driver_leg:
-        for e_ in engines:
-            e_.close()
-        del batches, keep, keep_r, t_cons, t_clen, t_stat, t_solid, t_slen, t_coff, t_soff
-        torch.cuda.empty_cache()
-        if world > 1:
-            dist.barrier()
-        if rank == 0:
-            try:
-                da = argparse.Namespace(**vars(args))
-                da.driver_copies, da.driver_reps = 1, 2
-                d = driver_measure(da, dry_reps=2)
-                out["driver_strong_scaling"] = {
-                    "windows_per_s": d["value"], "s_total": d["s_inside_cw_run_correction"], "wall_s_process": d["wall_s_process"], "n_gpus": args.gpus,
-                    "windows": d["config"]["windows"], "jobs": d["config"]["jobs"], "workers": d["config"]["workers"],
-                    "per_device_busy": d["per_device"], "ms_index": d["ms_index"], "ms_engines": d["ms_engines"],
-                    "steady_state_windows_per_s": d["steady_state_windows_per_s"], "feeder_ceiling": d["feeder_ceiling"],
-                    "workload": d["config"]["workload"], "scaling": "strong",
-                    "what": "bin/CONSENT-correction (cw_run_correction): one host process, piles cut / corrected / re-assembled on the --gpus devices, FASTA out in PAF order; the set is fixed (4.6 Mbp, 30x), so this value at N = 1, 2, 4, 8 is the strong-scaling curve",
-                }
-            except (SystemExit, Exception) as exc:  # the contract line must survive a failure of the extra leg
-                out["driver_strong_scaling"] = {"error": str(exc)[-400:]}
-        if world > 1:
-            dist.barrier()
+    if driver_leg is not None and rank == 0:
+        out["driver_strong_scaling"] = driver_leg
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

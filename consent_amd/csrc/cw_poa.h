@@ -64,7 +64,14 @@
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_EW_BYTES(EC) (CW_CONS_HEAVIEST_BUNDLE ? 2 * (EC) : 0) /* edge weights, kept only under the heaviest-bundle policy (cw_policy.h) */
-#define CW_POA_OV (CW_POA_MODE == CW_POA_MODE_OV) /* overlap mode (cw_policy.h): column 0 is free, the end cell is the best cell of a sink row, the walk stops in column 0 */
+#define CW_POA_SW (CW_POA_MODE == CW_POA_MODE_SW) /* local mode (cw_policy.h, round 5): rows 0 and column 0 are 0, no cell below 0, the end cell is the best cell anywhere, the walk
+                                                    stops at a cell of value 0.  Runs on the matrix paths only: no recorded decisions (CW_POA_CODES 0, CW_Q_CODES 0), no direction words */
+#define CW_POA_OV (CW_POA_MODE == CW_POA_MODE_OV || CW_POA_SW) /* overlap mode (cw_policy.h): column 0 is free, the end cell is the best cell of a sink row, the walk stops in column 0
+                                                                  (the local mode shares all three, with "any row" for "a sink's row") */
+#if CW_POA_SW
+#define CW_POA_CODES 0
+#define CW_Q_CODES 0
+#endif
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + CW_POA_EW_BYTES(EC) + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
@@ -240,7 +247,7 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
         act[c] = j < cols;
         sq_[c] = (j > 0 && act[c]) ? (int)M.sq[j - 1] : -1;
 #pragma unroll
-        for (int k = 0; k < RC; ++k) rc_[k][c] = j * G; /* row 0 */
+        for (int k = 0; k < RC; ++k) rc_[k][c] = CW_POA_SW ? 0 : j * G; /* row 0 */
     }
     uint32_t meta_n = M.rmeta[0];
 #ifdef CW_DIAG
@@ -303,6 +310,10 @@ __device__ __forceinline__ void poa_fill(const PoaMem<HT>& M, const int n, const
             }
         }
         if (CW_POA_OV) v[0] = lane == 0 ? 0 : v[0]; /* overlap mode: the graph's prefix is free */
+        if (CW_POA_SW) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v[c] = max(v[c], 0); /* local mode: no cell below 0 (clamping the candidates is clamping the cells: a gap from a clamped cell is negative) */
+        }
         int carry = CW_NEG;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -386,7 +397,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
         const int j0 = c * 128 + 2 * lane, j1 = j0 + 1;
         jg[c] = pk_make(j0 * G, j1 * G);
 #pragma unroll
-        for (int k = 0; k < RC; ++k) rc_[k][c] = jg[c]; /* row 0 */
+        for (int k = 0; k < RC; ++k) rc_[k][c] = CW_POA_SW ? 0 : jg[c]; /* row 0 */
         amask[c] = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
         const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
         qpk[c] = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0); /* see pk_score */
@@ -460,6 +471,10 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
             }
         }
         if (CW_POA_OV) v[0] = lane == 0 ? (int)((unsigned)v[0] & 0xFFFF0000u) : v[0]; /* overlap mode: column 0 (lane 0's even half) is free */
+        if (CW_POA_SW) {
+#pragma unroll
+            for (int c = 0; c < NCH2; ++c) v[c] = pk_max(v[c], 0); /* local mode: no cell below 0 */
+        }
         unsigned carry = 0u; /* biased (value + 32768): 0 is "nothing yet" */
 #pragma unroll
         for (int c = 0; c < NCH2; ++c) {
@@ -716,7 +731,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         const bool run_matrix_path = !coded;
 #endif
         if (run_matrix_path) {
-        for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(j * G);
+        for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(CW_POA_SW ? 0 : j * G);
         cw_wave_sync();
         const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
         const bool use_dirs = !CW_POA_OV && (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap; /* (overlap mode: the tile walk below only) */
@@ -754,7 +769,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         if (CW_POA_OV) { /* overlap mode: the best cell of a sink's row, columns 1..L; lowest rank, then lowest column on ties */
             int bs = CW_NEG * 2, br = 0x7FFFFFFF, bc = L;
             for (int r = lane; r < n; r += 64) {
-                if (M.has_out[M.r2n[r]]) continue;
+                if (!CW_POA_SW && M.has_out[M.r2n[r]]) continue; /* (local mode: any row) */
                 for (int j = 1; j <= L; ++j) {
                     const int h = M.H[(r + 1) * hs + j];
                     if (h > bs) { bs = h; br = r; bc = j; } /* ranks ascend within a lane, columns within a row */
@@ -883,7 +898,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     /* 0 diagonal, 1 vertical, 2 horizontal; 3 several predecessors, 4 no move explains the cell, 5 neighbours outside
                        the tile, 6 the virtual start row */
                     /* (selects, not branches: as an if-chain this was six nested execution-mask regions per tile) */
-                    const bool c_start = row <= 0 || (CW_POA_OV && col <= 0), c_edge = tr == 7 || (tc == 7 && col > 0); /* (overlap mode: the walk stops in column 0) */
+                    const bool c_start = row <= 0 || (CW_POA_OV && col <= 0) || (CW_POA_SW && valid && hv == 0), c_edge = tr == 7 || (tc == 7 && col > 0); /* (overlap mode: the walk stops in column 0; local mode: also at a cell of value 0) */
                     const bool c_d = col > 0 && hv == av + (sq_c == (meta_r & 3) ? MS : XS);
                     const bool c_m = CW_RM_NP((uint32_t)meta_r) != 1, c_v = hv == bv + G, c_h = col > 0 && hv == lv + G;
                     const int code = c_start ? 6 : c_edge ? 5 : c_d ? 0 : c_m ? 3 : c_v ? 1 : c_h ? 2 : 4;

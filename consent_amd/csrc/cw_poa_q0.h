@@ -29,7 +29,7 @@ __device__ __forceinline__ void poaq_fill(const PoaMem<int16_t>& M, const int n,
     int* Hw = (int*)M.H;
     const int j0 = 2 * gl, j1 = j0 + 1;
     const int jg = pk_make(j0 * G, j1 * G);
-    int rc0 = jg, rc1 = jg, rc2 = jg; /* the last three rows, rc0 = the previous one */
+    int rc0 = CW_POA_SW ? 0 : jg, rc1 = rc0, rc2 = rc0; /* the last three rows, rc0 = the previous one (row 0: j * gap, or 0 in the local mode) */
     const int amask = (j0 < cols ? 0xFFFF : 0) | (j1 < cols ? (int)0xFFFF0000 : 0);
     const int q0 = (j0 >= 1 && j0 < cols) ? (int)M.sq[j0 - 1] : -1, q1 = (j1 < cols) ? (int)M.sq[j1 - 1] : -1;
     const int qpk = (q0 >= 0 ? 1 << q0 : 0) | (q1 >= 0 ? 1 << (16 + q1) : 0);
@@ -51,6 +51,7 @@ __device__ __forceinline__ void poaq_fill(const PoaMem<int16_t>& M, const int n,
             v = pk_max(v, pk_max(pk_add(dg, srow), pk_add(up, GPK)));
         }
         if (CW_POA_OV && gl == 0) v = (int)((unsigned)v & 0xFFFF0000u); /* overlap mode (cw_policy.h): column 0 -- this lane's even half -- is free */
+        if (CW_POA_SW) v = pk_max(v, 0); /* local mode: no cell below 0 */
         int w = pk_sub(v, jg);
         w = (w & amask) | (CW_NEGPK & ~amask);
         w = pk_max(w, (w << 16) | 0x8AD0);                              /* odd column sees the even one of its lane */
@@ -126,7 +127,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         POAQ_PROF(0);
 
         /* ---- DP fill ---- */
-        for (int j = gl; j < cols; j += 16) M.H[j] = (int16_t)(j * G);
+        for (int j = gl; j < cols; j += 16) M.H[j] = (int16_t)(CW_POA_SW ? 0 : j * G);
         for (int j = gl; j < L; j += 16) M.seqrank[j] = CW_NONE16;
         cw_wave_sync();
         poaq_fill(M, n, cols, gl);
@@ -138,7 +139,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         if (CW_POA_OV) { /* overlap mode: the best cell of a sink's row, columns 1..L; lowest rank, then lowest column on ties */
             int bs = CW_NEG * 2, br = 0x7FFFFFFF, bc = L;
             for (int r = gl; r < n; r += 16) {
-                if (M.has_out[M.r2n[r]]) continue;
+                if (!CW_POA_SW && M.has_out[M.r2n[r]]) continue; /* (local mode: any row) */
                 for (int j = 1; j <= L; ++j) {
                     const int h = M.H[(r + 1) * HS + j];
                     if (h > bs) { bs = h; br = r; bc = j; }
@@ -172,6 +173,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
                 const int pr0 = (int)M.rpred0[i - 1];
                 const int base = (int)(meta & 3u), np = (int)((meta >> 2) & 0x3FFFu), off = (int)(meta >> 16);
                 const int h = M.H[i * HS + j];
+                if (CW_POA_SW && h == 0) break; /* local mode: the alignment starts where the score does */
                 const int sx = (j != 0 && (int)M.sq[j - 1] == base) ? MS : XS;
                 const int hh = j != 0 ? (int)M.H[i * HS + j - 1] : CW_NEG * 2;
                 int pi = i, pj = j;

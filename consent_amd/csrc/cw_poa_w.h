@@ -28,6 +28,9 @@
                         wide, and the rows of a member depend on one another.  There is nothing to spread over waves.  (What the run did show: with half as
                         many priority-3 waves of tier L on the machine, tiers S / M1 / M2 ran 28 -> 20, 41 -> 28, 35 -> 31 ms.) */
 #endif
+#if CW_POAL_MW > 1 && CW_POA_SW
+#error "cw_poa_w.h: the multi-wave fill of tier L has no local alignment mode (build it with CW_POAL_MW=1)"
+#endif
 #define CW_MW_CMD_FILL 1u
 #define CW_MW_CMD_EXIT 2u
 

@@ -66,7 +66,10 @@
 /* non-default consensus and checks that they still agree with each other and differ from the        */
 /* default).  A value that is named here but not implemented stops the build on both sides.          */
 #define CW_POA_MODE_NW 0 /* global alignment of the segment against the graph (implemented)          */
-#define CW_POA_MODE_SW 1 /* local                                                                     */
+#define CW_POA_MODE_SW 1 /* local (Smith-Waterman, spoa's kSW as published): first row and first column 0, no cell below 0, the alignment ends in the best
+                            cell anywhere (columns 1..L, lowest rank then lowest column on ties) and stops at the first cell of value 0 (or in the first row /
+                            column); the bases outside it are insertions.  Implemented on both sides since round 5; the engine runs it on its matrix paths
+                            only (no recorded decisions, tier Q with its DP matrix: cw_poa.h) */
 #define CW_POA_MODE_OV 2 /* semi-global / overlap, as spoa's kOV is published: first row gap-penalised, first column free, the alignment
                             ends in the best cell (columns 1..L, lowest rank then lowest column on ties) of a node without out-edges and stops where
                             it reaches the first row or column; the bases beyond the end cell and before the stop are insertions.  Implemented on both
@@ -104,7 +107,7 @@
 #ifndef CW_SEG_MISSING_ANCHOR
 #define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
 #endif
-#if (CW_POA_MODE != CW_POA_MODE_NW && CW_POA_MODE != CW_POA_MODE_OV) || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
+#if (CW_POA_MODE != CW_POA_MODE_NW && CW_POA_MODE != CW_POA_MODE_OV && CW_POA_MODE != CW_POA_MODE_SW) || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
     CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
 #error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
 #endif
@@ -153,6 +156,16 @@
  *           only its inserted/deleted base totals are used (correctionAlignment.cpp:28-45,111).
  * str2num on the mixed-case overlap strings (correctionAlignment.cpp:9): every character other than 'A','C','G' counts as T.
  * PARITY UNPINNED (library absent).                                                                                     */
+/* An AFFINE gap model for the POA (spoa >= 3 offers one; the version BMEAN bundles is unknown) is named here and NOT implemented on either side: */
+#define CW_POA_GAP_MODEL_LINEAR 0
+#define CW_POA_GAP_MODEL_AFFINE 1
+#ifndef CW_POA_GAP_MODEL
+#define CW_POA_GAP_MODEL CW_POA_GAP_MODEL_LINEAR
+#endif
+#if CW_POA_GAP_MODEL != CW_POA_GAP_MODEL_LINEAR
+#error "cw_policy.h: CW_POA_GAP_MODEL_AFFINE is named but not implemented (three DP layers per row in oracle/cw_oracle.cpp and in every fill of consent_amd/csrc/)"
+#endif
+
 #define CW_SSW_MATCH     2
 #define CW_SSW_MISMATCH  2
 #define CW_SSW_GAP_OPEN  3

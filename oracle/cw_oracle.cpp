@@ -144,7 +144,7 @@ struct PoaGraph {
         const int cols = L + 1;
         const int g = CW_POA_GAP;
         auto pred_row = [&](const PoaNode& nd, size_t p) { return node2rank[edges[nd.in_edges[p]].from] + 1; };
-#if defined(CWO_SIMD) && defined(__AVX2__)
+#if defined(CWO_SIMD) && defined(__AVX2__) && CW_POA_MODE != CW_POA_MODE_SW
         /* Row-vectorised fill for the CPU BASELINE leg of bench.py only (the real reference's POA, spoa, is SIMD code, so a
            scalar port flatters the GPU/CPU ratio).  Eight int32 columns per AVX2 register; rows are kept as W[i][j] = H[i][j] - j * gap,
            in which a horizontal move costs nothing: the horizontal recurrence is a prefix max (three shift-and-max steps inside a
@@ -195,12 +195,12 @@ struct PoaGraph {
         if (H.size() < (size_t)(n + 1) * cols) H.resize((size_t)(n + 1) * cols);
         auto at = [&](int i, int j) -> int32_t& { return H[(size_t)i * cols + j]; };
 
-        for (int j = 0; j < cols; ++j) at(0, j) = j * g;
+        for (int j = 0; j < cols; ++j) at(0, j) = CW_POA_MODE == CW_POA_MODE_SW ? 0 : j * g; /* local mode: the sequence's prefix is free too */
         for (int i = 1; i <= n; ++i) {
             const PoaNode& nd = nodes[rank2node[i - 1]];
             int32_t best = nd.in_edges.empty() ? 0 : INT_MIN;
             for (size_t p = 0; p < nd.in_edges.size(); ++p) best = std::max(best, at(pred_row(nd, p), 0));
-            at(i, 0) = CW_POA_MODE == CW_POA_MODE_OV ? 0 : best + g; /* overlap mode: the graph's prefix is free */
+            at(i, 0) = CW_POA_MODE != CW_POA_MODE_NW ? 0 : best + g; /* overlap and local mode: the graph's prefix is free */
         }
         for (int i = 1; i <= n; ++i) {
             const PoaNode& nd = nodes[rank2node[i - 1]];
@@ -214,13 +214,21 @@ struct PoaGraph {
                 }
             }
             for (int j = 1; j < cols; ++j) at(i, j) = std::max(at(i, j - 1) + g, at(i, j));
+#if CW_POA_MODE == CW_POA_MODE_SW
+            for (int j = 1; j < cols; ++j) at(i, j) = std::max(at(i, j), 0); /* local mode: no cell below 0 (a clamped cell never feeds a positive horizontal move: gaps cost) */
+#endif
         }
 #endif
         if (st) { st->dp_cells += (uint64_t)n * L; st->alignments++; }
 
         int bi = -1, bj = L;
         int32_t bs = INT_MIN;
-#if CW_POA_MODE == CW_POA_MODE_OV
+#if CW_POA_MODE == CW_POA_MODE_SW
+        /* local mode: the best cell anywhere, columns 1..L: lowest rank, then lowest column on ties; the bases beyond it are insertions */
+        for (int i = 1; i <= n; ++i)
+            for (int j = 1; j <= L; ++j) if (bi == -1 || bs < at(i, j)) { bs = at(i, j); bi = i; bj = j; }
+        for (int j = L; j > bj; --j) path.emplace_back(-1, j - 1);
+#elif CW_POA_MODE == CW_POA_MODE_OV
         /* overlap mode (spoa kOV as published: first row gap-penalised, first column free, the alignment ends in the best cell of a node
            without out-edges, columns 1..L, and stops where it reaches the first row or the first column): lowest rank, then lowest column on ties.
            The sequence's bases beyond the end cell and before the stop are on no graph node: insertions, as in the global mode's first row. */
@@ -236,8 +244,9 @@ struct PoaGraph {
         }
 #endif
         int i = bi, j = bj;
-        while (CW_POA_MODE == CW_POA_MODE_OV ? (i != 0 && j != 0) : !(i == 0 && j == 0)) {
+        while (CW_POA_MODE != CW_POA_MODE_NW ? (i != 0 && j != 0) : !(i == 0 && j == 0)) {
             const int32_t h = at(i, j);
+            if (CW_POA_MODE == CW_POA_MODE_SW && h == 0) break; /* local mode: the alignment starts where the score does */
             int pi = i, pj = j;
             bool found = false;
             if (i != 0 && j != 0) {
@@ -264,8 +273,8 @@ struct PoaGraph {
             path.emplace_back(i == pi ? -1 : rank2node[i - 1], j == pj ? -1 : j - 1);
             i = pi; j = pj;
         }
-#if CW_POA_MODE == CW_POA_MODE_OV
-        for (; j > 0; --j) path.emplace_back(-1, j - 1); /* stopped in the first row: the bases before are insertions */
+#if CW_POA_MODE != CW_POA_MODE_NW
+        for (; j > 0; --j) path.emplace_back(-1, j - 1); /* stopped in the first row (or, local mode, at a cell of value 0): the bases before are insertions */
 #endif
         std::reverse(path.begin(), path.end());
         return path;

@@ -113,3 +113,23 @@ def test_other_alignment_scores_are_honoured_by_engine_and_oracle(tmp_path):
     assert digest_default != digest_sc
     mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     assert not mixed
+
+
+@pytest.mark.timeout(1500)
+def test_local_alignment_mode_is_implemented_on_both_sides(tmp_path):
+    """-DCW_POA_MODE=1 (cw_policy.h CW_POA_MODE_SW, round 5): first row and column 0, no cell below 0, the alignment ends in the best cell anywhere and
+    stops at a cell of value 0; the bases outside it become insertions -- in the oracle and on the engine's matrix paths (under this mode the engine is
+    built without recorded decisions: every tier fills a DP matrix and walks its values).  The two sides agree window by window, the consensus is not
+    the global mode's, and mixing the sides disagrees."""
+    from consent_amd import _build
+
+    sw = ["-DCW_POA_MODE=1"]
+    alt_lib = str(tmp_path / "libconsent_amd_sw.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sw, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(sw)])
+    same_default, digest_default = run_child({})
+    same_sw, digest_sw = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_sw
+    assert digest_default != digest_sw
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed
