@@ -519,6 +519,87 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
     cw_wave_sync();
 }
 
+/* ---- round 5: FOUR MEMBERS PER FILL in the tall tiers ---------------------------------------------------------------------------------------
+ * The tasks of tiers M2 and L are the ragged first and last segments of a window: one long member makes a graph of hundreds of nodes, then dozens
+ * of short pieces are aligned against all of it (85-94 % of these tiers' members have at most 31 bases; 79-85 % of those change nothing in the
+ * graph but coverage counts).  A fill of such a member is tall and a quarter of a wave wide, and its rows depend on one another -- but the NEXT
+ * members' fills are the same rows of the same graph as long as the merge in between adds no node and no edge.  So up to four consecutive members
+ * of at most 31 bases are filled TOGETHER, one per 16-lane DPP row (two packed columns per lane), under the one scalar row loop of the graph; each
+ * is then traced back and merged in turn, and the first merge that changes the graph's structure voids the fills behind it (those members are
+ * filled again, with their successors).  Same cells, same direction words (layout of a packed 128-column row, member g in columns 32g .. 32g + 31),
+ * same results; half the row passes of these tiers at depth 150. */
+#ifndef CW_POA_GROUP_FILL
+#define CW_POA_GROUP_FILL 1
+#endif
+#define CW_GF_LC 31  /* longest member of a group fill */
+#define CW_GF_HS 128 /* row stride of its matrix: four members x 32 columns */
+template <bool DIRS>
+__device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int n, const int lane, const bool use_dirs_) {
+    const bool use_dirs = DIRS && use_dirs_;
+    const int G = CW_POA_GAP;
+    const int GPK = pk_make(G, G);
+    const int gl = lane & 15, mg = lane >> 4;
+    const int j0 = 2 * gl, j1 = j0 + 1;
+    const int jg = pk_make(j0 * G, j1 * G);
+    int rc0 = CW_POA_SW ? 0 : jg, rc1 = rc0, rc2 = rc0; /* rows i-1, i-2, i-3 (row 0) */
+    int* Hw = (int*)M.H;
+    /* the members' bases: member g at M.sq[32 g ..]; a position beyond its member matches nothing (0xFF) */
+    const int q0 = j0 >= 1 ? (int)M.sq[32 * mg + j0 - 1] : 255, q1 = (int)M.sq[32 * mg + j1 - 1];
+    const int qpk = (q0 < 4 ? 1 << q0 : 0) | (q1 < 4 ? 1 << (16 + q1) : 0);
+    Hw[lane] = rc0; /* row 0 */
+    uint32_t meta_n = M.rmeta[0];
+    for (int r = 0; r < n; ++r) {
+        const int i = r + 1;
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta_n);
+        if (r + 1 < n) meta_n = M.rmeta[r + 1];
+        const int base = (int)(meta & 3u), np = CW_RM_NP(meta), off = CW_RM_X(meta), pr0 = off;
+        const int srow = pk_score(qpk, base);
+        int v, dgv = CW_NEGPK, upv = CW_NEGPK;
+        if (CW_RM_LIN(meta)) {
+            const int sh = CW_DPP(CW_NEGPK, rc0, 0x111, 0xF); /* row_shr:1: the neighbour inside the member's 16 lanes, none for its column 0 */
+            dgv = pk_add(__builtin_amdgcn_alignbit(rc0, sh, 16), srow); upv = pk_add(rc0, GPK);
+            v = pk_max(dgv, upv);
+        } else {
+            v = CW_NEGPK;
+            for (int q = 0; q < np; ++q) {
+                const int prow = (np == 1) ? pr0 : __builtin_amdgcn_readfirstlane((int)M.plist[off + q]);
+                const int dist = i - prow;
+                int up;
+                if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
+                else { up = Hw[prow * (CW_GF_HS / 2) + lane]; asm volatile("" : "+v"(up)); } /* (see poa_fill_pk: the wait stays inside the branch) */
+                const int sh = CW_DPP(CW_NEGPK, up, 0x111, 0xF);
+                dgv = pk_add(__builtin_amdgcn_alignbit(up, sh, 16), srow); upv = pk_add(up, GPK);
+                v = pk_max(v, pk_max(dgv, upv));
+            }
+        }
+        if (CW_POA_OV) v = gl == 0 ? (int)((unsigned)v & 0xFFFF0000u) : v; /* overlap mode: every member's column 0 is free */
+        if (CW_POA_SW) v = pk_max(v, 0);
+        int w = pk_sub(v, jg);
+        w = pk_max(w, (w << 16) | 0x8AD0); /* the odd column sees the even one of its lane */
+        unsigned inc = ((unsigned)w >> 16) ^ 0x8000u; /* the prefix max stays inside the member's 16 lanes: four row shifts */
+        inc = max(inc, (unsigned)CW_DPP(0, (int)inc, 0x111, 0xF)); inc = max(inc, (unsigned)CW_DPP(0, (int)inc, 0x112, 0xF));
+        inc = max(inc, (unsigned)CW_DPP(0, (int)inc, 0x114, 0xF)); inc = max(inc, (unsigned)CW_DPP(0, (int)inc, 0x118, 0xF));
+        const unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x111, 0xF);
+        w = pk_max(w, pk_splat_lo((int)(ex ^ 0x8000u)));
+        const int nv = pk_add(w, jg);
+        rc2 = rc1; rc1 = rc0; rc0 = nv;
+        Hw[i * (CW_GF_HS / 2) + lane] = nv;
+        if (use_dirs) { /* as poa_fill_pk, one 128-column chunk per row */
+            unsigned long long e0, e1, o0, o1;
+            if (np == 1) {
+                const bool de = j0 > 0 && (short)nv == (short)dgv, ue = (short)nv == (short)upv;
+                const bool dd = (short)((unsigned)nv >> 16) == (short)((unsigned)dgv >> 16), uo = (short)((unsigned)nv >> 16) == (short)((unsigned)upv >> 16);
+                const unsigned long long bde = __ballot(de), bue = __ballot(ue), bdo = __ballot(dd), buo = __ballot(uo);
+                e0 = ~bde & bue; e1 = ~bde & ~bue; o0 = ~bdo & buo; o1 = ~bdo & ~buo;
+            } else {
+                e0 = e1 = o0 = o1 = ~0ull;
+            }
+            if (lane == 0) { unsigned long long* d = M.dirs + (size_t)r * 4; d[0] = e0; d[1] = e1; d[2] = o0; d[3] = o1; }
+        }
+    }
+    cw_wave_sync();
+}
+
 #include "cw_poa_c.h"
 #include "cw_poa_w.h"
 
@@ -618,6 +699,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
     int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
     bool meta_ok = false;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int gf_left = 0, gf_idx = 0; /* group fill (poa_fill_pk4): members behind the current one whose rows are already in the matrix; the current one's place in the group */
 
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
@@ -644,7 +726,21 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             continue;
         }
         const int cols = L + 1;
-        const bool packed = PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN); /* two columns per lane (int16 tiers, wide rows) */
+        /* group fill (tiers M2 / L, matrix path): is this member's fill already in the matrix -- filled together with its predecessor, and has no merge
+           since changed the graph's structure (meta_ok) -- or does it open a group with the members behind it? */
+        bool grp = false, grp_fill = false;
+        int jo = 0, gk = 1;
+        if constexpr (CW_POA_GROUP_FILL != 0 && PK != 0 && CM == 0 && sizeof(HT) == 2 && LCAP >= 511) {
+            if (gf_left > 0 && meta_ok) { grp = true; jo = 32 * (++gf_idx); --gf_left; }
+            else {
+                gf_left = 0; gf_idx = 0;
+                if (L <= CW_GF_LC && (uint32_t)((n + 1) * CW_GF_HS) <= M.h_cap && n + 32 <= CW_POA_PK_SPAN) {
+                    while (gk < 4 && mi + (uint32_t)gk < t.n_members && __builtin_amdgcn_readfirstlane((int)sc.members[t.member_off + mi + gk].len) <= CW_GF_LC) ++gk;
+                    if (gk >= 2) { grp = true; grp_fill = true; gf_left = gk - 1; }
+                }
+            }
+        }
+        const bool packed = grp || (PK && cols > 64 && (PK == 1 || n + cols <= CW_POA_PK_SPAN)); /* two columns per lane (int16 tiers, wide rows) */
         /* pad64 rests on an ordering the HSA memory model does not spell out: a lane beyond the member's columns stores into the first
            cells of LATER rows, which another lane of the same wave overwrites when that row is finished -- correct iff two stores of one wave to
            one address commit in issue order (they do on gfx9: one wave's vector memory instructions reach the L2 in order).  -DCW_NO_PAD64 builds
@@ -654,7 +750,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #else
         const bool pad = PK != 0 && !packed && M.pad64 && cols <= 64;
 #endif
-        const int hs = packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
+        const int hs = grp ? CW_GF_HS : packed ? ((cols + 1) & ~1) : cols;    /* row stride of the DP matrix */
         if ((uint32_t)((n + 1) * hs + (pad ? 64 : 0)) > M.h_cap) return 2;
 
         /* ---- per-rank metadata (parallel over ranks) ---- */
@@ -731,12 +827,29 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         const bool run_matrix_path = !coded;
 #endif
         if (run_matrix_path) {
-        for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(CW_POA_SW ? 0 : j * G);
+        PoaMem<HT> V = M; /* the member's view of the matrix: in a group fill its columns begin at jo */
+        V.H = M.H + jo;
+        if (!grp) { for (int j = lane; j < cols; j += 64) M.H[j] = (HT)(CW_POA_SW ? 0 : j * G); }
         cw_wave_sync();
-        const int nch = packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
+        const int nch = grp ? 1 : packed ? (cols + 127) >> 7 : (cols + 63) >> 6; /* direction-word chunks per row */
         const bool use_dirs = !CW_POA_OV && (uint32_t)(n * nch * (packed ? 2 : 1)) <= M.d_cap; /* (overlap mode: the tile walk below only) */
         if constexpr (PK != 0) {
-            if (!packed) {
+            if (grp) {
+                if constexpr (CW_POA_GROUP_FILL != 0 && CM == 0 && sizeof(HT) == 2 && LCAP >= 511) {
+                    if (grp_fill) { /* this member and the gk - 1 behind it, one per 16-lane row: their bases side by side in M.sq */
+                        for (int x = lane; x < 128; x += 64) { const int g_ = x >> 5, j_ = x & 31; if (g_ >= 1) M.sq[x] = 255; (void)j_; }
+                        if (lane >= L && lane < 32) M.sq[lane] = 255;
+                        for (int g_ = 1; g_ < gk; ++g_) {
+                            const PoaMember pg = sc.members[t.member_off + mi + g_];
+                            const uint32_t* wg = b.bases + b.seq_word_off[pg.seq];
+                            if (lane < (int)pg.len) M.sq[32 * g_ + lane] = (uint8_t)cw_base_at(wg, pg.start + lane);
+                        }
+                        cw_wave_sync();
+                        poa_fill_pk4<PK == 2>(M, n, lane, use_dirs);
+                    }
+                }
+            }
+            else if (!packed) {
                 if (cols <= 64) { if (pad) poa_fill<HT, 1, PK == 2, true>(M, n, cols, lane, use_dirs); else poa_fill<HT, 1, PK == 2>(M, n, cols, lane, use_dirs); }
                 else if constexpr (PK == 2 && LCAP > 511) { /* a very large graph in tier L: one column per lane */
                     if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
@@ -771,7 +884,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             for (int r = lane; r < n; r += 64) {
                 if (!CW_POA_SW && M.has_out[M.r2n[r]]) continue; /* (local mode: any row) */
                 for (int j = 1; j <= L; ++j) {
-                    const int h = M.H[(r + 1) * hs + j];
+                    const int h = V.H[(r + 1) * hs + j];
                     if (h > bs) { bs = h; br = r; bc = j; } /* ranks ascend within a lane, columns within a row */
                 }
             }
@@ -785,7 +898,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             int bs = CW_NEG * 2, br = 0x7FFFFFFF;
             for (int r = lane; r < n; r += 64) {
                 if (M.has_out[M.r2n[r]]) continue;
-                const int h = M.H[(r + 1) * hs + L];
+                const int h = V.H[(r + 1) * hs + L];
                 if (h > bs) { bs = h; br = r; } /* ranks ascend within a lane */
             }
             for (int o = 32; o > 0; o >>= 1) {
@@ -810,10 +923,10 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     const bool linear = rvalid && prow == row - 1;
                     int cD = 3, cV = 3, cH = 3;
                     if (rvalid) {
-                        cV = poa_dir_code(M.dirs, row - 1, j, nch, packed);
-                        if (j - t >= 1) cD = poa_dir_code(M.dirs, row - 1, j - t, nch, packed);
+                        cV = poa_dir_code(M.dirs, row - 1, j + jo, nch, packed);
+                        if (j - t >= 1) cD = poa_dir_code(M.dirs, row - 1, j - t + jo, nch, packed);
                     }
-                    if (j - t >= 1) cH = poa_dir_code(M.dirs, i - 1, j - t, nch, packed);
+                    if (j - t >= 1) cH = poa_dir_code(M.dirs, i - 1, j - t + jo, nch, packed);
                     const int code0 = __builtin_amdgcn_readlane(cV, 0);
                     const int pr0 = __builtin_amdgcn_readlane(prow, 0);
                     if (code0 == 2) {
@@ -823,7 +936,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     } else if (code0 == 3) {
                         /* several predecessors: decide from the cell values (same order of preference) */
                         int pi, pj;
-                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
+                        if (!poa_slow_step(V, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     } else if (pr0 != i - 1) {
@@ -844,7 +957,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             } else if (use_dirs) {
                 /* direction words, one step per LDS round trip: the row's words and its first predecessor together */
                 while (i > 0) {
-                    const int code = poa_dir_code(M.dirs, i - 1, j, nch, packed);
+                    const int code = poa_dir_code(M.dirs, i - 1, j + jo, nch, packed);
                     const int pr0 = M.rpred0[i - 1];
                     if (code == 0) {
                         if (lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
@@ -855,7 +968,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                         j--;
                     } else {
                         int pi, pj;
-                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
+                        if (!poa_slow_step(V, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     }
@@ -891,7 +1004,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     }
                     const int col = j - tc;
                     const bool valid = row >= 0 && col >= 0;
-                    const int hv = valid ? (int)M.H[row * hs + col] : 0;
+                    const int hv = valid ? (int)V.H[row * hs + col] : 0;
                     const int meta_r = row >= 1 ? (int)M.rmeta[row - 1] : 0; /* the 8 lanes of a tile row read one word */
                     const int sq_c = col >= 1 ? (int)M.sq[col - 1] : 255;
                     const int av = __shfl_down(hv, 9), bv = __shfl_down(hv, 8), lv = __shfl_down(hv, 1); /* (tr+1,tc+1), (tr+1,tc), (tr,tc+1) */
@@ -931,7 +1044,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #ifdef CW_DIAG
                         if (lane == 0 && M.diag) atomicAdd(&M.diag[8], 1ull);
 #endif
-                        if (!poa_slow_step(M, i, j, hs, pr0, lane, &pi, &pj)) return 3;
+                        if (!poa_slow_step(V, i, j, hs, pr0, lane, &pi, &pj)) return 3;
                         if (pj != j && pi != i && lane == 0) M.seqrank[j - 1] = (uint16_t)(i - 1);
                         i = pi; j = pj;
                     }
