@@ -137,7 +137,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
     put(p.exg, idx_wgs * CW_EXG_SLOTS * 8);
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
-    put(p.finvis, (size_t)cus * 2 * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
+    put(p.finvis, (size_t)cus * CW_FIN_WGS_PER_CU * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
     put(p.finretry, (size_t)n_windows * 4);
     p.total = o;
     return p;
@@ -543,7 +543,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, st, "finish");
     {
         uint32_t grid = (batch->n_windows + CW_FIN_WAVES - 1) / CW_FIN_WAVES;
-        if (grid > (uint32_t)cus * 2) grid = (uint32_t)cus * 2;
+        if (grid > (uint32_t)cus * CW_FIN_WGS_PER_CU) grid = (uint32_t)cus * CW_FIN_WGS_PER_CU;
         cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false><<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
         /* second pass: the windows whose strings outgrew the first pass's buffers (normally none: the kernel reads one counter and ends) */
         const uint32_t grid2 = batch->n_windows < 64u ? batch->n_windows : 64u;

@@ -15,8 +15,16 @@
 
 #include "cw_device.h"
 
+#ifndef CW_FIN_WAVES
 #define CW_FIN_WAVES 4
-#define CW_FIN_CB 3072        /* string capacity per buffer, first pass                                    */
+#endif
+#ifndef CW_FIN_WGS_PER_CU
+#define CW_FIN_WGS_PER_CU 2
+#endif
+#ifndef CW_FIN_CB
+#define CW_FIN_CB 3072
+#endif
+/* CW_FIN_CB: string capacity per buffer, first pass                                    */
 #define CW_FIN_CB_BIG 32768   /* ... of the second pass (round 5): windows whose consensus or polish outgrew the first are done again, one wave per
                                  work-group with 107 KB of LDS -- k < 8 (chance anchors: consensuses of several templates), heaviest-bundle policy */
 #ifndef CW_FIN_VIS_WORDS

@@ -531,6 +531,9 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
 #ifndef CW_POA_GROUP_FILL
 #define CW_POA_GROUP_FILL 1
 #endif
+#ifndef CW_POA_VPROBE
+#define CW_POA_VPROBE 1 /* the tile traceback looks down the column when it is inside a long vertical run (poa_run) */
+#endif
 #define CW_GF_LC 31  /* longest member of a group fill */
 #define CW_GF_HS 128 /* row stride of its matrix: four members x 32 columns */
 template <bool DIRS>
@@ -984,11 +987,36 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #ifdef CW_DIAG
                 if (lane == 0 && M.diag) atomicAdd(&M.diag[9], 1ull);
 #endif
+                bool vprobe = false; /* the last trip was seven vertical moves in one column: look down the column */
                 while (i > 0) {
 #ifdef CW_DIAG
                     if (lane == 0 && M.diag) atomicAdd(&M.diag[7], 1ull);
 #endif
                     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); /* wave-uniform: keep the walk on the scalar unit */
+#if CW_POA_VPROBE
+                    /* Round 5: the tall tiers align short members against graphs of hundreds of nodes -- most of such a path is ONE vertical run of
+                       hundreds of moves, seven per tile trip.  Inside a run the sixty-four lanes look down the column instead: lane t holds cell
+                       (i - t, j); along a stretch of the graph where every node's only predecessor is the rank before, the cell moves vertically iff
+                       the diagonal candidate does not explain it (the order of preference) and the cell above + gap does.  The leading lanes that
+                       do are consumed at once: up to 63 moves per round trip. */
+                    if (vprobe) {
+                        const int row_t = i - lane;
+                        const uint32_t m_t = row_t >= 1 ? M.rmeta[row_t - 1] : 0u;
+                        int c_t = 0, d_t = 0;
+                        if (row_t >= 0) c_t = (int)V.H[row_t * hs + j];
+                        if (row_t >= 1 && j > 0) d_t = (int)V.H[(row_t - 1) * hs + j - 1];
+                        const int u_t = __shfl_down(c_t, 1); /* the cell above: lane t + 1's */
+                        const int s_t = (j > 0 && (int)M.sq[j - 1] == (int)(m_t & 3u)) ? MS : XS;
+                        bool vert_t = row_t >= 1 && lane < 63 && CW_RM_LIN(m_t) && !(j > 0 && c_t == d_t + s_t) && c_t == u_t + G;
+                        if (CW_POA_SW) vert_t = vert_t && c_t != 0; /* (local mode: the walk stops at a cell of value 0) */
+                        if (CW_POA_OV && j <= 0) vert_t = false;    /* (overlap mode: it stops in column 0: the tile's business) */
+                        const unsigned long long vb = __ballot(vert_t);
+                        const int run = __ffsll((long long)~vb) - 1;
+                        i -= run;
+                        vprobe = run >= 32;
+                        if (run > 0) continue;
+                    }
+#endif
                     int row = i;
                     if (M.p2) { /* tr steps up the chain: 4 + 2 + 1 (unconditional reads and selects, see cw_poa_c.h) */
                         { uint32_t v = M.p4[row - 1]; asm volatile("" : "+v"(v)); row = (tr & 4) ? (v == CW_NONE16 ? -1 : (int)v) : row; }
@@ -1035,6 +1063,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     const int end_code = __builtin_amdgcn_readlane(code, pos);
                     i = __builtin_amdgcn_readlane(row, pos);
                     j -= pos & 7;
+                    vprobe = CW_POA_VPROBE && pos == 56 && on_diag == 0ull; /* seven vertical moves, no other: probably inside a long run */
                     if (end_code == 4) return 3;
                     if (end_code == 6) i = 0;
                     if (end_code == 3) {

@@ -7,6 +7,7 @@
   -DCW_POAL_MW=4    one tier-L task on the four waves of a work-group, the chunks of a wide packed row pipelined by rows (cw_poa_w.h: built in round 5,
                     measured no faster -- tier L's rows are narrow -- and off by default),
   -DCW_POA_GROUP_FILL=0  tiers M2 / L fill every member on its own (round 5's default fills up to four consecutive short members together),
+  -DCW_POA_VPROBE=0 the tile traceback without the look down the column inside a long vertical run,
   -DCW_Q_CODES=0    tier Q with the DP matrix in LDS and a walk over its values (rounds 3-4, cw_poa_q0.h) instead of recorded decisions,
 each compared with the oracle on piles of several depths (all tiers)."""
 import os
@@ -17,7 +18,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "lwaves": ["-DCW_POAL_MW=4"], "nogroup": ["-DCW_POA_GROUP_FILL=0"]}
+VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "lwaves": ["-DCW_POAL_MW=4"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
 
 CHILD = r"""
 import os, sys
