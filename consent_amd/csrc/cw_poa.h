@@ -537,7 +537,7 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
 #define CW_GF_LC 31  /* longest member of a group fill */
 #define CW_GF_HS 128 /* row stride of its matrix: four members x 32 columns */
 template <bool DIRS>
-__device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int n, const int lane, const bool use_dirs_) {
+__device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int n, const int lane, const bool use_dirs_, const uint32_t lens4) {
     const bool use_dirs = DIRS && use_dirs_;
     const int G = CW_POA_GAP;
     const int GPK = pk_make(G, G);
@@ -549,7 +549,10 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
     /* the members' bases: member g at M.sq[32 g ..]; a position beyond its member matches nothing (0xFF) */
     const int q0 = j0 >= 1 ? (int)M.sq[32 * mg + j0 - 1] : 255, q1 = (int)M.sq[32 * mg + j1 - 1];
     const int qpk = (q0 < 4 ? 1 << q0 : 0) | (q1 < 4 ? 1 << (16 + q1) : 0);
-    Hw[lane] = rc0; /* row 0 */
+    /* only the columns a member has are stored (lens4: the members' lengths, a byte each, 0 = no member in that row of lanes): what lies to the right
+       of them is computed, read by nobody, and would triple the bytes these tiers write */
+    const bool st = j0 <= (int)((lens4 >> (8 * mg)) & 255u) && ((lens4 >> (8 * mg)) & 255u) != 0u;
+    if (st) Hw[lane] = rc0; /* row 0 */
     uint32_t meta_n = M.rmeta[0];
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
@@ -569,7 +572,7 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
                 const int dist = i - prow;
                 int up;
                 if (dist <= 3) up = dist == 1 ? rc0 : dist == 2 ? rc1 : rc2;
-                else { up = Hw[prow * (CW_GF_HS / 2) + lane]; asm volatile("" : "+v"(up)); } /* (see poa_fill_pk: the wait stays inside the branch) */
+                else { up = st ? Hw[prow * (CW_GF_HS / 2) + lane] : CW_NEGPK; asm volatile("" : "+v"(up)); } /* (see poa_fill_pk: the wait stays inside the branch) */
                 const int sh = CW_DPP(CW_NEGPK, up, 0x111, 0xF);
                 dgv = pk_add(__builtin_amdgcn_alignbit(up, sh, 16), srow); upv = pk_add(up, GPK);
                 v = pk_max(v, pk_max(dgv, upv));
@@ -586,7 +589,7 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
         w = pk_max(w, pk_splat_lo((int)(ex ^ 0x8000u)));
         const int nv = pk_add(w, jg);
         rc2 = rc1; rc1 = rc0; rc0 = nv;
-        Hw[i * (CW_GF_HS / 2) + lane] = nv;
+        if (st) Hw[i * (CW_GF_HS / 2) + lane] = nv;
         if (use_dirs) { /* as poa_fill_pk, one 128-column chunk per row */
             unsigned long long e0, e1, o0, o1;
             if (np == 1) {
@@ -842,13 +845,15 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     if (grp_fill) { /* this member and the gk - 1 behind it, one per 16-lane row: their bases side by side in M.sq */
                         for (int x = lane; x < 128; x += 64) { const int g_ = x >> 5, j_ = x & 31; if (g_ >= 1) M.sq[x] = 255; (void)j_; }
                         if (lane >= L && lane < 32) M.sq[lane] = 255;
+                        uint32_t lens4 = (uint32_t)L;
                         for (int g_ = 1; g_ < gk; ++g_) {
                             const PoaMember pg = sc.members[t.member_off + mi + g_];
                             const uint32_t* wg = b.bases + b.seq_word_off[pg.seq];
                             if (lane < (int)pg.len) M.sq[32 * g_ + lane] = (uint8_t)cw_base_at(wg, pg.start + lane);
+                            lens4 |= (uint32_t)__builtin_amdgcn_readfirstlane((int)pg.len) << (8 * g_);
                         }
                         cw_wave_sync();
-                        poa_fill_pk4<PK == 2>(M, n, lane, use_dirs);
+                        poa_fill_pk4<PK == 2>(M, n, lane, use_dirs, lens4);
                     }
                 }
             }
