@@ -72,6 +72,9 @@
 #define CW_POA_CODES 0
 #define CW_Q_CODES 0
 #endif
+#ifndef CW_POA_VPROBE
+#define CW_POA_VPROBE 1 /* the tile traceback looks down the column when it is inside a long vertical run (poa_run, poa_trace_c) */
+#endif
 #define CW_POA_GRAPH_BYTES(NC, EC, LC) (((NC) * 29 + (EC) * 6 + CW_POA_EW_BYTES(EC) + 7 * ((LC) + 1) + 64 + 15) / 16 * 16)
 
 /* Slab tiers (M1 / M2 / L): LDS holds only what the fill and the traceback read ("hot": rank metadata, predecessor lists, first
@@ -530,9 +533,6 @@ __device__ __forceinline__ void poa_fill_pk(const PoaMem<int16_t>& M, const int 
  * same results; half the row passes of these tiers at depth 150. */
 #ifndef CW_POA_GROUP_FILL
 #define CW_POA_GROUP_FILL 1
-#endif
-#ifndef CW_POA_VPROBE
-#define CW_POA_VPROBE 1 /* the tile traceback looks down the column when it is inside a long vertical run (poa_run) */
 #endif
 #define CW_GF_LC 31  /* longest member of a group fill */
 #define CW_GF_HS 128 /* row stride of its matrix: four members x 32 columns */
