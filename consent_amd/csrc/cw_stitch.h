@@ -18,6 +18,9 @@
 #include "cw_device.h"
 #include "cw_poa.h" /* packed int16 helpers (pk_add, pk_max, pk_splat_lo, ...) */
 
+#ifndef CW_ST_PROF
+#define CW_ST_PROF 0 /* 1 (a scratch build): the debug trace holds the shader clocks of a window's phases instead of its alignment (tools/stitch_phases.py) */
+#endif
 #define CW_ST_WAVES 4
 #define CW_ST_QMAX 2048 /* consensus length */
 #define CW_ST_RMAX 2048 /* aligned slice of the read: window_size + 2*window_overlap */
@@ -61,11 +64,23 @@ __device__ __forceinline__ uint8_t st_upper(uint8_t c) { return (c >= 'a' && c <
 __device__ __forceinline__ bool st_is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
 
 /* Ordering point for LDS *and* global traffic between the lanes of one wave: the read under construction lives in global memory
-   (gap buffer) and is written and read back by different lanes. */
+   (gap buffer) and is written and read back by different lanes -- of the SAME wave, whose memory instructions go through one vector L1 in
+   issue order, so work-group scope (wait for the outstanding accesses; nothing to write back or invalidate) is all it takes.  Until round 5
+   these were agent-scope fences: an L2 write-back and invalidate on this XCD at each of the ~30 ordering points of a window, paid by the
+   consensus kernels of the other worker running beside this one as well (CW_ST_FENCE_AGENT=1 is that variant). */
+#ifndef CW_ST_FENCE_AGENT
+#define CW_ST_FENCE_AGENT 0
+#endif
 __device__ __forceinline__ void st_mem_sync() {
+#if CW_ST_FENCE_AGENT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 }
 
 /* the read under construction: logical string = buf[0, L) + buf[cap-R, cap) */
@@ -284,6 +299,119 @@ __device__ __forceinline__ StSweep st_sweep_pk(const uint8_t* q, int m, const ui
     return best;
 }
 
+/* ---- the sweep of the product build, STRIPED: the 128 slots of a wave (two per lane, the halves of a packed register) each hold NV CONSECUTIVE
+ * query positions (slot s: positions s*NV .. s*NV + NV - 1), one per register, instead of every register holding a chunk of 128 consecutive ones.
+ * The in-column gap F then runs down the registers of a lane as plain arithmetic (F' = max(F - ext, H - open)), and only its passage from one slot
+ * to the next needs the lanes: ONE exclusive prefix max per column -- over the slots, of (F leaving the slot + slot * NV * ext) -- where the chunked
+ * sweep above runs one such ladder per chunk.  What enters a slot is then applied to its positions in a second pass (H = max(H, Fin - v * ext));
+ * exact for the same reason as the ladder itself: open >= ext, so a cell raised by F never opens a better gap than the one that raised it.
+ * Per register and column: 13 + 7 instructions (9 with the reverse sweep's stop test) against 49 for a chunk, plus ~25 per column; a five-register
+ * column (a 500-base window) is ~135 issued instructions for 241 / 269.  Same recurrences, same tie rules, same results (CW_ST_STRIPED=0 is the
+ * variant; tests/test_gpu_variants.py). ---- */
+#ifndef CW_ST_STRIPED
+#define CW_ST_STRIPED 1
+#endif
+__device__ __forceinline__ int st_subsat(int a, int b) { /* both halves: max(a - b, 0) for unsigned halves */
+    int r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int NV, bool TERM>
+__device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
+    const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), D = NV * GE, DPK = pk_make(D, D);
+    m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
+    const int TERMPK = pk_make(terminate, terminate);
+    const int s0 = 2 * lane, s1 = s0 + 1;
+    const int jgs = pk_make(s0 * D, s1 * D); /* at most 127 * 16 * ext */
+    int hs[NV], ee[NV], qpk[NV], qok[NV], amask[NV], bestv[NV], bcol[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int j0 = s0 * NV + v, j1 = s1 * NV + v;
+        amask[v] = (j0 < m ? 0xFFFF : 0) | (j1 < m ? (int)0xFFFF0000 : 0);
+        const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
+        qpk[v] = pk_make(q0, q1);
+        qok[v] = (q0 < 4 ? 0xFFFF : 0) | (q1 < 4 ? (int)0xFFFF0000 : 0);
+        hs[v] = 0; ee[v] = 0; bestv[v] = 0; bcol[v] = -1;
+    }
+    int hit_col = -1;
+    int rc_next = r_first != r_last_excl ? (int)r[r_first] : 0; /* the slice letter is asked for a column ahead: its LDS round trip is off the column's chain */
+    for (int i = r_first; i != r_last_excl; i += step) {
+        const int rc = st_uni(rc_next);
+        if (i + step != r_last_excl) rc_next = (int)r[i + step];
+        const int rcpk = rc * 0x00010001;
+        /* a letter other than ACGT on the slice scores 0 against everything: the two constants of the score, chosen per column */
+        const int mul = rc <= 3 ? pk_make(-CW_SSW_MISMATCH - CW_SSW_MATCH, -CW_SSW_MISMATCH - CW_SSW_MATCH) : 0, add = rc <= 3 ? pk_make(CW_SSW_MATCH, CW_SSW_MATCH) : 0;
+        const int ipk = i * 0x00010001;
+        /* the diagonal of a slot's first position is the last position of the slot before it */
+        const int hl = hs[NV - 1];
+        int dg = __builtin_amdgcn_alignbit(hl, CW_DPP(0, hl, 0x138, 0xF), 16);
+        int f = 0;
+        int hq[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int hold = hs[v];
+            int t, sv;
+            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(qpk[v] ^ rcpk));
+            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(sv) : "v"(t), "v"(mul), "v"(add));
+            sv &= qok[v];
+            const int e = pk_max(pk_sub(ee[v], GEPK), st_subsat(hold, GOPK)); /* >= 0: no cell is negative */
+            const int h = pk_max(pk_max(pk_add(dg, sv), e), f);
+            ee[v] = e; hq[v] = h;
+            f = pk_max(pk_sub(f, GEPK), st_subsat(h, GOPK));
+            dg = hold;
+        }
+        /* what enters slot s: max over the slots t before it of (F leaving t) - (s - 1 - t) * D */
+        const int w = pk_add(f, jgs);
+        const int tot = pk_max(w, __builtin_amdgcn_perm(w, w, 0x01000302));
+        const unsigned inc = cw_wave_scan_max_u32(((unsigned)tot & 0xFFFFu) ^ 0x8000u);
+        const unsigned ex = (unsigned)CW_DPP(0, (int)inc, 0x138, 0xF);
+        const int pre = pk_max(pk_splat_lo((int)(ex ^ 0x8000u)), (w << 16) | (CW_NEGPK & 0xFFFF)); /* the odd slot also sees the even one of its lane */
+        int fi = pk_max(pk_add(pk_sub(pre, jgs), DPK), 0);
+        int zacc = -1;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int h = pk_max(hq[v], fi) & amask[v];
+            hs[v] = h;
+            fi = pk_sub(fi, GEPK);
+            int mask; /* all ones where the best improves (written out: the compiler turns a vector shift + select into two compares, two selects and a permute) */
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(mask) : "v"(pk_sub(bestv[v], h)));
+            bestv[v] = pk_max(bestv[v], h);
+            bcol[v] = (ipk & mask) | (bcol[v] & ~mask);
+            if (TERM) {
+                typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
+                zacc = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(st_u2, zacc), __builtin_bit_cast(st_u2, h ^ TERMPK)));
+            }
+        }
+        if (TERM) {
+            if (__ballot((zacc & 0xFFFF) == 0 || ((unsigned)zacc >> 16) == 0u)) { hit_col = i; break; }
+        }
+    }
+    int lm = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) lm = max(lm, max((int)(short)(bestv[v] & 0xFFFF), (int)(short)((unsigned)bestv[v] >> 16)));
+    const int M = hit_col >= 0 ? terminate : st_uni(cw_wave_max(lm));
+    StSweep best{0, -1, 0};
+    if (M <= 0) return best;
+    int kc = 0x7FFFFFFF;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if ((int)(short)(bestv[v] & 0xFFFF) == M) kc = min(kc, (int)(short)(bcol[v] & 0xFFFF) * step);
+        if ((int)(short)((unsigned)bestv[v] >> 16) == M) kc = min(kc, (int)(short)((unsigned)bcol[v] >> 16) * step);
+    }
+    kc = st_uni(-cw_wave_max(-kc));
+    const int col = kc * step;
+    int jr = 0x7FFFFFFF;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if ((int)(short)(bestv[v] & 0xFFFF) == M && (int)(short)(bcol[v] & 0xFFFF) == col) jr = min(jr, s0 * NV + v);
+        if ((int)(short)((unsigned)bestv[v] >> 16) == M && (int)(short)((unsigned)bcol[v] >> 16) == col) jr = min(jr, s1 * NV + v);
+    }
+    jr = st_uni(-cw_wave_max(-jr));
+    best.score = M; best.col = col; best.row = jr;
+    return best;
+}
+
 /* ---- the same sweep on several waves of one work-group (a read is a serial chain of windows, and a window is two sweeps of ~600
  * columns: with one wave per read a launch lasts as long as its longest read, ~0.4 ms per window).  The query's chunks of 128 positions
  * are dealt to the waves in order -- one chunk per wave up to 128 x waves positions, two beyond -- and a column moves down the waves as
@@ -492,6 +620,19 @@ __device__ __forceinline__ void st_sys_helper(StSys* sm, const uint8_t* lds_base
 template <int NCHK, bool TERM>
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
+#if CW_ST_STRIPED
+    m = st_uni(m);
+    if constexpr (NCHK <= 8) return st_sweep_st<NCHK, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 128) return st_sweep_st<1, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 256) return st_sweep_st<2, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 384) return st_sweep_st<3, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 512) return st_sweep_st<4, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 640) return st_sweep_st<5, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 768) return st_sweep_st<6, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1024) return st_sweep_st<8, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1536) return st_sweep_st<12, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    return st_sweep_st<CW_ST_QMAX / 128, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+#else
     if constexpr (NCHK <= 8) return st_sweep_pk<NCHK, false, TERM>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
     /* A variant per chunk count for the common lengths (a 500-base window's consensus is 500-600 positions: five chunks), each a
        branch-free column written chunk-interleaved (st_sweep_pk, EXACT); the rare long ones keep the sixteen-chunk loop that skips the
@@ -509,6 +650,7 @@ __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const u
     if (m <= 768) return st_sweep_pk<6, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 1024) return st_sweep_pk<8, true, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     return st_sweep_pk<CW_ST_QMAX / 128, false, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+#endif
 }
 
 /* banded traceback (ssw banded_sw): totals of inserted / deleted bases between the alignment's ends.  Wave-uniform, serial
@@ -726,6 +868,12 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
         bool have_old = false;
         for (uint32_t wi = 0; wi < jb.win_count && status == 0; ++wi) {
             const uint32_t w = jb.win_first + wi;
+#if CW_ST_PROF
+            long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = clock64();
+#define ST_PROF(k) do { const long long n_ = clock64(); pc[k] += n_ - pt; pt = n_; } while (0)
+#else
+#define ST_PROF(k) do { } while (0)
+#endif
             if (st_uni((int)a.win_status[w]) == CW_WIN_OVERFLOW) continue;                 /* no consensus for this window: leave the read as it is */
             uint32_t clen = st_uni(a.cons_len[w]);
             const bool long_enough = clen >= a.mer_size;                      /* :75 / :98 / :125 */
@@ -751,8 +899,10 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
             for (int x = lane; x < size_al; x += 64) refc[x] = (uint8_t)st_code(g.at((uint32_t)al_pos + x));
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
             st_mem_sync();
+            ST_PROF(0);
             const StAlign al = st_align<NCHK, SYS>(qfw, (int)clen, qrv, refc, size_al, lane, sm, lds);     /* :90 */
-            if (a.trace && lane == 0) {
+            ST_PROF(1);
+            if (!CW_ST_PROF && a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
                 t[0] = (uint32_t)al_pos; t[1] = (uint32_t)size_al; t[2] = (uint32_t)al.score; t[3] = (uint32_t)al.ref_begin; t[4] = (uint32_t)al.ref_end;
                 t[5] = (uint32_t)al.query_begin; t[6] = (uint32_t)al.query_end; t[7] = clen;
@@ -772,6 +922,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                 }
             }
             bool emptied = false;
+            ST_PROF(2);
             if (wi != 0 && have_old && old_end >= beg) {                                                   /* :96 */
                 const uint32_t overlap = old_end - beg + 1;
                 if (long_enough && old_len >= overlap && cl >= overlap) {                                   /* :98 */
@@ -788,6 +939,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                             for (uint32_t x = lane; x < overlap; x += 64) { u1 += st_is_upper(seq1[x]) ? 1 : 0; u2 += st_is_upper(cur[x]) ? 1 : 0; }
                             s1 = st_uni(cw_wave_sum(u1)); s2 = st_uni(cw_wave_sum(u2));
                         }
+                        ST_PROF(3);
                         if (s1 > s2) {                                                                      /* :109-119 */
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
@@ -798,6 +950,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
                                                       sub.score, rows, CW_ST_ROWS_BYTES, dirbuf, a.dir_bytes, &ins, &del, lane)) { status = 2; break; }
                             }
+                            ST_PROF(4);
                             const uint32_t cut = overlap - ins + del;
                             if (cut < cl) {                                                                 /* :114-115 curCons = seq1 + curCons.substr(cut) */
                                 const uint32_t tail = cl - cut, nl = overlap + tail;
@@ -815,6 +968,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                     }
                 }
             }
+            ST_PROF(3);
             if (!emptied && cl > 0) {                                                                       /* :124 */
                 if (long_enough) {                                                                          /* :125-129 replace(beg, end-beg+1, upper(cur)) */
                     const uint32_t rl = end - beg + 1;
@@ -834,6 +988,10 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                     st_mem_sync();
                 }
             }
+#if CW_ST_PROF
+            ST_PROF(5);
+            if (a.trace && lane == 0) { uint32_t* t = a.trace + 8 * (size_t)w; for (int x = 0; x < 6; ++x) t[x] = (uint32_t)pc[x]; t[6] = clen; t[7] = (uint32_t)size_al; }
+#endif
         }
         /* make the string contiguous */
         if (status == 0) st_gap_to(g, g.len(), lane);

@@ -1,5 +1,6 @@
 """GPU: cw_stitch_device (alignConsensus + trimRead + dropRead on the device) against the oracle's restatement,
 fed with the same window consensuses and solid sets.  Bit-exact strings and statuses."""
+import os
 import random
 
 import numpy as np
@@ -147,7 +148,8 @@ def test_stitch_other_window_geometry_and_k():
 
 
 def test_stitch_long_consensuses_use_the_wide_sweeps():
-    """Consensuses of 600-1024 and of more than 1024 bases (junk around the true window sequence): the 8- and 16-chunk sweeps."""
+    """Consensuses of 600-1024, of more than 1024 and of more than 1536 bases (junk around the true window sequence): the sweeps of 6, 8, 12 and 16
+    registers per slot (the short last windows of the reads and the other tests cover 1-5)."""
     rng = random.Random(9)
 
     rep = 0
@@ -156,7 +158,7 @@ def test_stitch_long_consensuses_use_the_wide_sweeps():
         for w in range(len(piles)):
             o, n = int(res.cons_off[w]), int(res.cons_len[w])
             cap = int(res.cons_off[w + 1]) - o
-            extra = [0, 150, 600, 700][w % 4]
+            extra = [0, 150, 600, 700, 1150, 250][w % 6]
             if n + extra > cap or extra == 0:
                 continue
             s = res.cons[o : o + n].tobytes()
@@ -221,3 +223,20 @@ def test_stitch_several_waves_per_read(aids, monkeypatch):
     test_stitch_many_reads_in_one_launch()
     got, n_up = run_case(make_reads(118, 40, 10, lo=600, hi=1800))
     assert len(got) == 40 and n_up > 0
+
+
+
+@pytest.mark.timeout(1200)
+def test_stitch_chunked_sweep_build_variant(tmp_path):
+    """-DCW_ST_STRIPED=0: the chunked sweep of rounds 1-4 (a prefix-max ladder per chunk of 128 positions) instead of the striped one; the same
+    strings in every case of this file that runs on the product library."""
+    import subprocess
+    import sys
+
+    from consent_amd import _build
+
+    lib = str(tmp_path / "libconsent_amd_chunked.so")
+    subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCW_ST_STRIPED=0", *_build.SRC, "-o", lib], check=True)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not aids and not variant and not narrow and not several_waves and not capacity",
+                          "-p", "no:cacheprovider"], capture_output=True, text=True, env=dict(os.environ, CONSENT_AMD_LIB=lib), timeout=1000)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
