@@ -18,6 +18,9 @@
 #include "cw_device.h"
 #include "cw_poa.h" /* packed int16 helpers (pk_add, pk_max, pk_splat_lo, ...) */
 
+#ifndef CW_ST_BAND_PAR
+#define CW_ST_BAND_PAR 1 /* 0: the banded traceback's rows cell by cell on lane 0, as rounds 2-4 had them (variant test) */
+#endif
 #ifndef CW_ST_PROF
 #define CW_ST_PROF 0 /* 1 (a scratch build): the debug trace holds the shader clocks of a window's phases instead of its alignment (tools/stitch_phases.py) */
 #endif
@@ -316,7 +319,11 @@ __device__ __forceinline__ int st_subsat(int a, int b) { /* both halves: max(a -
     asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-template <int NV, bool TERM>
+/* TRACK = false (reverse sweeps): no per-position best and column -- the sweep ends at the first column that holds `terminate`, and the answer is that
+   column and the smallest position holding the score in it, read from the column itself.  Returns score -1 when no column holds it (cannot happen:
+   the reversed forward alignment is in the rectangle, and no cell of the rectangle exceeds the forward score); the caller then sweeps once more with
+   TRACK. */
+template <int NV, bool TERM, bool TRACK = true>
 __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
     const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
     const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE), D = NV * GE, DPK = pk_make(D, D);
@@ -374,10 +381,12 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
             const int h = pk_max(hq[v], fi) & amask[v];
             hs[v] = h;
             fi = pk_sub(fi, GEPK);
-            int mask; /* all ones where the best improves (written out: the compiler turns a vector shift + select into two compares, two selects and a permute) */
-            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(mask) : "v"(pk_sub(bestv[v], h)));
-            bestv[v] = pk_max(bestv[v], h);
-            bcol[v] = (ipk & mask) | (bcol[v] & ~mask);
+            if (TRACK) {
+                int mask; /* all ones where the best improves (written out: the compiler turns a vector shift + select into two compares, two selects and a permute) */
+                asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(mask) : "v"(pk_sub(bestv[v], h)));
+                bestv[v] = pk_max(bestv[v], h);
+                bcol[v] = (ipk & mask) | (bcol[v] & ~mask);
+            }
             if (TERM) {
                 typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
                 zacc = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(st_u2, zacc), __builtin_bit_cast(st_u2, h ^ TERMPK)));
@@ -387,11 +396,22 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
             if (__ballot((zacc & 0xFFFF) == 0 || ((unsigned)zacc >> 16) == 0u)) { hit_col = i; break; }
         }
     }
+    StSweep best{0, -1, 0};
+    if constexpr (!TRACK) {
+        if (hit_col < 0) { best.score = -1; return best; }
+        int jr = 0x7FFFFFFF;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if ((int)(hs[v] & 0xFFFF) == terminate) jr = min(jr, s0 * NV + v);
+            if ((int)((unsigned)hs[v] >> 16) == terminate) jr = min(jr, s1 * NV + v);
+        }
+        best.score = terminate; best.col = hit_col; best.row = st_uni(-cw_wave_max(-jr));
+        return best;
+    }
     int lm = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) lm = max(lm, max((int)(short)(bestv[v] & 0xFFFF), (int)(short)((unsigned)bestv[v] >> 16)));
     const int M = hit_col >= 0 ? terminate : st_uni(cw_wave_max(lm));
-    StSweep best{0, -1, 0};
     if (M <= 0) return best;
     int kc = 0x7FFFFFFF;
 #pragma unroll
@@ -410,6 +430,16 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
     jr = st_uni(-cw_wave_max(-jr));
     best.score = M; best.col = col; best.row = jr;
     return best;
+}
+
+/* a reverse sweep: without the per-position bookkeeping first */
+template <int NV, bool TERM>
+__device__ __forceinline__ StSweep st_sweep_st2(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
+    if constexpr (TERM) {
+        const StSweep sw = st_sweep_st<NV, true, false>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+        if (sw.score >= 0) return sw;
+    }
+    return st_sweep_st<NV, TERM, true>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 }
 
 /* ---- the same sweep on several waves of one work-group (a read is a serial chain of windows, and a window is two sweeps of ~600
@@ -622,16 +652,16 @@ __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const u
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
 #if CW_ST_STRIPED
     m = st_uni(m);
-    if constexpr (NCHK <= 8) return st_sweep_st<NCHK, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 128) return st_sweep_st<1, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 256) return st_sweep_st<2, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 384) return st_sweep_st<3, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 512) return st_sweep_st<4, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 640) return st_sweep_st<5, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 768) return st_sweep_st<6, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 1024) return st_sweep_st<8, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 1536) return st_sweep_st<12, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    return st_sweep_st<CW_ST_QMAX / 128, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if constexpr (NCHK <= 8) return st_sweep_st2<NCHK, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 128) return st_sweep_st2<1, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 256) return st_sweep_st2<2, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 384) return st_sweep_st2<3, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 512) return st_sweep_st2<4, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 640) return st_sweep_st2<5, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 768) return st_sweep_st2<6, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1024) return st_sweep_st2<8, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 1536) return st_sweep_st2<12, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    return st_sweep_st2<CW_ST_QMAX / 128, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 #else
     if constexpr (NCHK <= 8) return st_sweep_pk<NCHK, false, TERM>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
     /* A variant per chunk count for the common lengths (a 500-base window's consensus is 500-600 positions: five chunks), each a
@@ -657,7 +687,7 @@ __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const u
  * (lane 0 walks the band; rare: only when two overlapping windows disagree and the earlier one wins).
  * rows: int32 h_b/e_b/h_c (3*width) in LDS; dir: the direction bytes (width_d*readLen*3) in this wave's global scratch. */
 __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen, const uint8_t* read, int readLen, int score, uint8_t* rows, uint32_t rows_bytes,
-                                 int8_t* dir_all, uint32_t dir_bytes, unsigned* ins, unsigned* del, int lane) {
+                                 int8_t* dir_all, uint32_t dir_bytes, unsigned* ins, unsigned* del, int lane, int8_t* dir_lds = nullptr, uint32_t dir_lds_bytes = 0) {
     const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
     *ins = 0; *del = 0;
     refLen = st_uni(refLen); readLen = st_uni(readLen); score = st_uni(score);
@@ -676,13 +706,59 @@ __device__ __forceinline__ bool st_banded_indels(const uint8_t* ref, int refLen,
         const bool rows_in_lds = rows_need <= rows_bytes;
         if (dir_need + (rows_in_lds ? 0 : ((rows_need + 15) & ~(size_t)15)) > dir_bytes) return false;
         int* h_b = rows_in_lds ? (int*)rows : (int*)dir_all; int* e_b = h_b + w_rows; int* h_c = e_b + w_rows;
-        int8_t* dir = dir_all + (rows_in_lds ? 0 : ((rows_need + 15) & ~(size_t)15));
-        if (lane == 0) for (int x = 0; x < w_rows; ++x) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
+        /* the direction bytes of a narrow band over a hundred-odd rows are a kilobyte or two: in LDS when the caller has a free buffer (the walk
+           back is a chain of dependent one-byte reads) */
+        int8_t* dir = rows_in_lds && dir_need <= dir_lds_bytes ? dir_lds : dir_all + (rows_in_lds ? 0 : ((rows_need + 15) & ~(size_t)15));
+        for (int x = lane; x < 3 * w_rows; x += 64) h_b[x] = 0; /* h_b, e_b, h_c are one block */
         for (int x = lane; x < stride_d * readLen * 3; x += 64) dir[x] = 0; /* cells outside the band read as "stop" */
         dir_cur = dir;
         st_mem_sync();
         int mx = 0;
-        if (lane == 0) {
+        if (CW_ST_BAND_PAR && rows_in_lds && width_d <= 64) {
+            /* a row of the band on the lanes (lane t: cell j = beg + t), the arrays and their index rules -- including the zeroed `edge` slots and whatever
+               an earlier row left beyond the cells of the last one -- exactly those of the serial loop below: every lane reads its three cells of the
+               row before, then all write; the in-row gap f[t] = max(h[t-1] - open, f[t-1] - ext) is an exclusive prefix max of h'[s] - open + (s+1) ext
+               (h' = the cell without its f; exact as open >= ext and no h' is negative), the directions follow from the finished values. */
+            for (int i = 0; i < readLen; ++i) {
+                int beg = i - band, end = i + band;
+                beg = beg > 0 ? beg : 0; end = end < refLen - 1 ? end : refLen - 1;
+                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+                if (lane == 0) { h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0; }
+                st_mem_sync();
+                const int xo = i - band > 0 ? i - band : 0, xp = i - 1 - band > 0 ? i - 1 - band : 0;
+                const int j = beg + lane;
+                const bool on = j <= end;
+                const int u = j - xo + 1, e_i = j - xp + 1;
+                int hbe = 0, ebe = 0, hbd = 0, a = 4;
+                if (on) { hbe = h_b[e_i]; ebe = e_b[e_i]; hbd = h_b[e_i - 1]; a = ref[j]; }
+                const int bq = st_uni((int)read[i]);
+                const int t1e = i == 0 ? -GO : hbe - GO, t2e = i == 0 ? -GE : ebe - GE;
+                const int e_new = t1e > t2e ? t1e : t2e;
+                const int dir_e = t1e > t2e ? 3 : 2;
+                const int e1 = e_new > 0 ? e_new : 0;
+                const int diag = hbd + ((a == 4 || bq == 4) ? 0 : (a == bq ? CW_SSW_MATCH : -CW_SSW_MISMATCH));
+                const int hq = e1 > diag ? e1 : diag;
+                const unsigned key = on ? (unsigned)(hq - GO + (lane + 1) * GE + 0x40000000) : 0u;
+                const unsigned inc = cw_wave_scan_max_u32(key);
+                const int ex = (int)(unsigned)CW_DPP(0, (int)inc, 0x138, 0xF) - 0x40000000; /* lane 0: far below anything */
+                const int f = (ex > -GE ? ex : -GE) - lane * GE;
+                const int f1 = f > 0 ? f : 0;
+                const int t1h = e1 > f1 ? e1 : f1;
+                const int hc = t1h > diag ? t1h : diag;
+                const int hc_prev = CW_DPP(0, hc, 0x138, 0xF), f_prev = CW_DPP(0, f, 0x138, 0xF); /* lane 0: h_c[0] = 0 and f = 0 before the first cell */
+                const int dir_f = hc_prev - GO > f_prev - GE ? 5 : 4;
+                const int dir_h = t1h <= diag ? 1 : (e1 > f1 ? dir_e : dir_f);
+                if (on) {
+                    e_b[u] = e_new; h_c[u] = hc;
+                    int8_t* line = dir + (size_t)stride_d * i * 3 + 3 * lane;
+                    line[0] = (int8_t)dir_e; line[1] = (int8_t)dir_f; line[2] = (int8_t)dir_h;
+                    mx = hc > mx ? hc : mx;
+                }
+                st_mem_sync();
+                if (on) h_b[u] = hc; /* for (j = 1; j <= u; ++j) h_b[j] = h_c[j] */
+            }
+            mx = st_uni(cw_wave_max(mx));
+        } else if (lane == 0) {
             for (int i = 0; i < readLen; ++i) {
                 int beg = 0, end = refLen - 1, u = 0;
                 int j = i - band; beg = beg > j ? beg : j;
@@ -948,7 +1024,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,
-                                                      sub.score, rows, CW_ST_ROWS_BYTES, dirbuf, a.dir_bytes, &ins, &del, lane)) { status = 2; break; }
+                                                      sub.score, rows, CW_ST_ROWS_BYTES, dirbuf, a.dir_bytes, &ins, &del, lane, (int8_t*)qrv, a.dir_bytes >= QMAX ? QMAX : 0)) { status = 2; break; }
                             }
                             ST_PROF(4);
                             const uint32_t cut = overlap - ins + del;

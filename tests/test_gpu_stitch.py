@@ -228,7 +228,8 @@ def test_stitch_several_waves_per_read(aids, monkeypatch):
 
 @pytest.mark.timeout(1200)
 def test_stitch_chunked_sweep_build_variant(tmp_path):
-    """-DCW_ST_STRIPED=0: the chunked sweep of rounds 1-4 (a prefix-max ladder per chunk of 128 positions) instead of the striped one; the same
+    """-DCW_ST_STRIPED=0 -DCW_ST_BAND_PAR=0 -DCW_ST_FENCE_AGENT=1: the re-assembly kernel of rounds 1-4 (the chunked sweep with a prefix-max ladder per
+    chunk of 128 positions, the banded traceback's rows cell by cell on one lane, agent-scope ordering points) instead of round 5's; the same
     strings in every case of this file that runs on the product library."""
     import subprocess
     import sys
@@ -236,7 +237,7 @@ def test_stitch_chunked_sweep_build_variant(tmp_path):
     from consent_amd import _build
 
     lib = str(tmp_path / "libconsent_amd_chunked.so")
-    subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCW_ST_STRIPED=0", *_build.SRC, "-o", lib], check=True)
+    subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCW_ST_STRIPED=0", "-DCW_ST_BAND_PAR=0", "-DCW_ST_FENCE_AGENT=1", *_build.SRC, "-o", lib], check=True)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not aids and not variant and not narrow and not several_waves and not capacity",
                           "-p", "no:cacheprovider"], capture_output=True, text=True, env=dict(os.environ, CONSENT_AMD_LIB=lib), timeout=1000)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
