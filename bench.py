@@ -25,9 +25,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Must be in the environment before the HIP runtime starts (i.e. before torch is imported): HIP multiplexes a process's streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4).  Two engines have eight kernel streams (main + three tier streams each); with four
+# GPU_MAX_HW_QUEUES hardware queues (default 4).  Three engines have twelve kernel streams (main + three tier streams each); with four
 # queues a stream of the second engine lands behind the first engine's long-running tier-L kernel and the batches do not overlap.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WORKLOADS = {
     # name: (depth, maxMSA, windows per step per GPU)
@@ -157,7 +157,9 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "2")),
+    # (round 5: three -- four alternating runs each on one box: 53.4 52.8 54.2 52.2 ms per step with two engines and eight queues, 52.0 52.5 52.9 51.7 with three
+    # and sixteen; the native driver takes a third worker per device on long runs for the same reason)
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "3")),
                     help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
     ap.add_argument("--alone-steps", type=int, default=3, help="untimed steps after the timed region with ONE batch in flight: per-kernel HIP-event times that are work, not waiting (roofline.launch_ms)")
     ap.add_argument("--pcie-engines", type=int, default=1, help="engines the PCIe-inclusive leg spreads its host batches over")
@@ -428,7 +430,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_window": alg_bytes / n_win,
             "launch_ms": alone_avg[dom],
-            "launch_ms_two_batches_in_flight": stage_avg.get(dom),
+            "launch_ms_batches_in_flight": stage_avg.get(dom),
             "step_ms_one_batch_in_flight": alone_avg.get("total"),
             "frac_of_whole_step": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }

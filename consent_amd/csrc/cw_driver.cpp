@@ -515,6 +515,10 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
            1.97e5 windows/s with two workers, 2.36e5 with three, 2.77e5 with four; with jobs of 32768: 3.3e5 / 2.8e5 / 2.8e5) */
         const uint64_t est_per_dev = (tpl_bases / (a->window_size - a->window_overlap) + 1) / (uint64_t)(n_dev < want ? n_dev : want);
         int per_dev = est_per_dev < 100000ull ? (int)std::min<uint64_t>(4, est_per_dev / 4096 + 1) : 2; /* (no more workers than jobs: an engine costs ~60 ms and 1.3 GB to set up) */
+        /* a long run (dozens of jobs per device) takes a third worker: with round 5's shorter re-assembly two jobs are more often both in a tail
+           (tier L's longest tasks, the longest read) -- 80 jobs of 32768 on one GPU: 6.18 / 6.57 s with two workers, 5.89 / 5.94 with three,
+           6.18 / 6.23 with four; the 10-job set is no faster for it */
+        if (est_per_dev >= 1000000ull) per_dev = 3;
         if (const char* env = getenv("CW_WORKERS_PER_DEVICE")) { const int v = atoi(env); if (v >= 1 && v <= 8) per_dev = v; }
         for (int k = 0; k < per_dev; ++k) for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d);
     }

@@ -877,9 +877,14 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
     a.dir_bytes = CW_ST_DIR_BYTES;
     if (const char* env = CW_AID_ENV("CW_STITCH_DIR_BYTES")) a.dir_bytes = (uint32_t)strtoul(env, nullptr, 10);
     if (a.dir_bytes < 64) a.dir_bytes = 64;
-    rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, (size_t)wgs_max * CW_ST_WAVES * a.dir_bytes);
+    /* the last launch (consensuses beyond CW_ST_QMAX characters; one wave per work-group, everything in global memory) has its slabs behind the traceback scratch */
+    uint32_t wgs_h = n_reads < CW_STH_MAX_WGS ? n_reads : CW_STH_MAX_WGS;
+    if (wgs_h > wgs_max * CW_ST_WAVES) wgs_h = wgs_max * CW_ST_WAVES; /* (its waves use the first wgs_h traceback scratches) */
+    const size_t dir_total = (((size_t)wgs_max * CW_ST_WAVES * a.dir_bytes) + 255u) & ~(size_t)255u;
+    rc = ensure(&e->stitch_scratch, &e->stitch_scratch_bytes, dir_total + (size_t)wgs_h * CW_STH_WAVE_BYTES);
     if (rc) return rc;
     a.dir_scratch = (int8_t*)e->stitch_scratch;
+    a.huge = (uint8_t*)e->stitch_scratch + dir_total;
     a.prio = 1;
     if (const char* env = CW_AID_ENV("CW_STITCH_PRIO")) a.prio = atoi(env); /* measured: 69.6 -> 65.3 ms per job of 32768 windows (E. coli-scale ONT set) */
     cw_stitch_order_kernel<<<1, 1024, 0, st>>>(a);
@@ -896,6 +901,8 @@ int cw_stitch_device(cw_engine* e, const cw_read_set* reads, const cw_stitch_rea
         (void)lds_n; (void)lds_s; (void)wgs_n; (void)wgs_s; (void)narrow; (void)sys;
         cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false><<<wgs, 64 * CW_ST_WAVES, lds, st>>>(a);
     }
+    /* the reads the launches above marked (a window's consensus beyond CW_ST_QMAX characters: normally none, and the waves find nothing to do) */
+    cw_stitch_kernel<CW_STH_QMAX, CW_ST_RMAX, 0, 1, true><<<wgs_h, 64, 0, st>>>(a);
     CW_HIP(hipGetLastError());
     return CW_OK;
 }

@@ -58,6 +58,7 @@ struct StitchArgs {
     uint32_t dir_bytes;
     uint32_t* trace; /* debug: 8 words per window, NULL in production */
     int prio;        /* wave priorities by read length (CW_STITCH_PRIO) */
+    uint8_t* huge;   /* CW_STH_WAVE_BYTES per wave of the last launch (consensuses beyond CW_ST_QMAX): its buffers and the sweep's state, in global memory */
 };
 
 __device__ __forceinline__ int st_code(uint8_t c) {
@@ -342,13 +343,25 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
         hs[v] = 0; ee[v] = 0; bestv[v] = 0; bcol[v] = -1;
     }
     int hit_col = -1;
-    int rc_next = r_first != r_last_excl ? (int)r[r_first] : 0; /* the slice letter is asked for a column ahead: its LDS round trip is off the column's chain */
-    for (int i = r_first; i != r_last_excl; i += step) {
-        const int rc = st_uni(rc_next);
-        if (i + step != r_last_excl) rc_next = (int)r[i + step];
+    /* The scores of a column depend on nothing but the slice letter: they are computed a column ahead (svn), between the two passes of the column
+       before, where they fill the wait states of its prefix-max ladder; the letter itself is asked for at the top of that column. */
+    int svn[NV];
+    auto scores_of = [&](int rc_v) {
+        const int rc = st_uni(rc_v);
         const int rcpk = rc * 0x00010001;
         /* a letter other than ACGT on the slice scores 0 against everything: the two constants of the score, chosen per column */
         const int mul = rc <= 3 ? pk_make(-CW_SSW_MISMATCH - CW_SSW_MATCH, -CW_SSW_MISMATCH - CW_SSW_MATCH) : 0, add = rc <= 3 ? pk_make(CW_SSW_MATCH, CW_SSW_MATCH) : 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int t, sv;
+            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(qpk[v] ^ rcpk));
+            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(sv) : "v"(t), "v"(mul), "v"(add));
+            svn[v] = sv & qok[v];
+        }
+    };
+    scores_of(r_first != r_last_excl ? (int)r[r_first] : 0);
+    for (int i = r_first; i != r_last_excl; i += step) {
+        const int rc_next = i + step != r_last_excl ? (int)r[i + step] : 0;
         const int ipk = i * 0x00010001;
         /* the diagonal of a slot's first position is the last position of the slot before it */
         const int hl = hs[NV - 1];
@@ -358,16 +371,13 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int hold = hs[v];
-            int t, sv;
-            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(qpk[v] ^ rcpk));
-            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(sv) : "v"(t), "v"(mul), "v"(add));
-            sv &= qok[v];
             const int e = pk_max(pk_sub(ee[v], GEPK), st_subsat(hold, GOPK)); /* >= 0: no cell is negative */
-            const int h = pk_max(pk_max(pk_add(dg, sv), e), f);
+            const int h = pk_max(pk_max(pk_add(dg, svn[v]), e), f);
             ee[v] = e; hq[v] = h;
             f = pk_max(pk_sub(f, GEPK), st_subsat(h, GOPK));
             dg = hold;
         }
+        scores_of(rc_next);
         /* what enters slot s: max over the slots t before it of (F leaving t) - (s - 1 - t) * D */
         const int w = pk_add(f, jgs);
         const int tot = pk_max(w, __builtin_amdgcn_perm(w, w, 0x01000302));
@@ -378,7 +388,9 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
         int zacc = -1;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int h = pk_max(hq[v], fi) & amask[v];
+            /* (a forward sweep leaves the positions beyond the query unmasked: nothing flows from them to a position of the query, and their
+               best is dropped after the last column) */
+            const int h = TERM ? pk_max(hq[v], fi) & amask[v] : pk_max(hq[v], fi);
             hs[v] = h;
             fi = pk_sub(fi, GEPK);
             if (TRACK) {
@@ -410,7 +422,10 @@ __device__ __forceinline__ StSweep st_sweep_st(const uint8_t* q, int m, const ui
     }
     int lm = 0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) lm = max(lm, max((int)(short)(bestv[v] & 0xFFFF), (int)(short)((unsigned)bestv[v] >> 16)));
+    for (int v = 0; v < NV; ++v) {
+        if (!TERM) bestv[v] &= amask[v];
+        lm = max(lm, max((int)(short)(bestv[v] & 0xFFFF), (int)(short)((unsigned)bestv[v] >> 16)));
+    }
     const int M = hit_col >= 0 ? terminate : st_uni(cw_wave_max(lm));
     if (M <= 0) return best;
     int kc = 0x7FFFFFFF;
@@ -440,6 +455,116 @@ __device__ __forceinline__ StSweep st_sweep_st2(const uint8_t* q, int m, const u
         if (sw.score >= 0) return sw;
     }
     return st_sweep_st<NV, TERM, true>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+}
+
+/* ---- the same striped sweep for a consensus of ANY length (the slow path of the re-assembly: a window whose consensus is beyond CW_ST_QMAX
+ * characters -- chance anchors with k < 8 -- is taken by the last launch, cw_stitch_kernel<CW_STH_QMAX, ...>): NV = ceil(m / 128) registers per
+ * slot do not exist, so a slot's positions live in this wave's global scratch, one 16-byte record (H, E, best, first column of the best) and one
+ * word of letters per lane and position index, read and written twice per column (the next record is asked for before the present one is worked
+ * on).  Same recurrences, same tie rules as st_sweep_st; columns stay below 2048, scores below 2 * 2048. ---- */
+#define CW_STH_QMAX 32768
+#define CW_STH_NV (CW_STH_QMAX / 128)
+#define CW_STH_STATE_BYTES ((size_t)CW_STH_NV * 64 * 20)
+#define CW_STH_WAVE_BYTES (((((size_t)CW_ST_RMAX + 4 * (size_t)CW_STH_QMAX + CW_ST_ROWS_BYTES + 255u) & ~(size_t)255u) + CW_STH_STATE_BYTES + 255u) & ~(size_t)255u)
+#define CW_STH_MAX_WGS 64
+template <bool TERM>
+__device__ __forceinline__ StSweep st_sweep_mem(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane, uint8_t* state) {
+    const int GO = CW_SSW_GAP_OPEN, GE = CW_SSW_GAP_EXT;
+    const int GOPK = pk_make(GO, GO), GEPK = pk_make(GE, GE);
+    m = st_uni(m); r_first = st_uni(r_first); r_last_excl = st_uni(r_last_excl); terminate = st_uni(terminate);
+    const int NV = (m + 127) >> 7;
+    const int D = NV * GE; /* at most 256 */
+    const int TERMPK = pk_make(terminate, terminate);
+    const int s0 = 2 * lane, s1 = s0 + 1;
+    int4* const rec = (int4*)state + lane;                             /* [v * 64]: x = H, y = E, z = best, w = its first column */
+    int* const let = (int*)(state + (size_t)CW_STH_NV * 64 * 16) + lane; /* [v * 64]: the two letters */
+    for (int v = 0; v < NV; ++v) {
+        const int j0 = s0 * NV + v, j1 = s1 * NV + v;
+        const int q0 = j0 < m ? (int)q[j0] : 4, q1 = j1 < m ? (int)q[j1] : 4;
+        let[v * 64] = pk_make(q0, q1);
+        rec[v * 64] = make_int4(0, 0, 0, -1);
+    }
+    st_mem_sync();
+    int hit_col = -1;
+    for (int i = r_first; i != r_last_excl; i += step) {
+        const int rc = st_uni((int)r[i]);
+        const int rcpk = rc * 0x00010001;
+        const int mul = rc <= 3 ? pk_make(-CW_SSW_MISMATCH - CW_SSW_MATCH, -CW_SSW_MISMATCH - CW_SSW_MATCH) : 0, add = rc <= 3 ? pk_make(CW_SSW_MATCH, CW_SSW_MATCH) : 0;
+        const int ipk = i * 0x00010001;
+        const int hl = rec[(NV - 1) * 64].x;
+        int dg = __builtin_amdgcn_alignbit(hl, CW_DPP(0, hl, 0x138, 0xF), 16);
+        int f = 0;
+        int4 cur = rec[0];
+        int ql = let[0];
+        for (int v = 0; v < NV; ++v) {
+            const int vn = v + 1 < NV ? v + 1 : v;
+            const int4 nxt = rec[vn * 64];
+            const int qn = let[vn * 64];
+            const int hold = cur.x;
+            const int qok = ((ql & 0xFFFF) < 4 ? 0xFFFF : 0) | (((unsigned)ql >> 16) < 4u ? (int)0xFFFF0000 : 0);
+            int t, sv;
+            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(ql ^ rcpk));
+            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(sv) : "v"(t), "v"(mul), "v"(add));
+            sv &= qok;
+            const int e = pk_max(pk_sub(cur.y, GEPK), st_subsat(hold, GOPK));
+            const int h = pk_max(pk_max(pk_add(dg, sv), e), f);
+            f = pk_max(pk_sub(f, GEPK), st_subsat(h, GOPK));
+            dg = hold;
+            rec[v * 64] = make_int4(h, e, cur.z, cur.w);
+            cur = nxt; ql = qn;
+        }
+        /* what enters a slot, in 32 bits (slot * D outgrows a half here) */
+        const int klo = (int)(short)(f & 0xFFFF) + s0 * D, khi = (f >> 16) + s1 * D;
+        const unsigned inc = cw_wave_scan_max_u32((unsigned)(max(klo, khi) + 0x40000000));
+        const int ex = (int)(unsigned)CW_DPP(0, (int)inc, 0x138, 0xF) - 0x40000000; /* lane 0: far below anything */
+        const int flo = max(ex - s0 * D + D, 0), fhi = max(max(ex, klo) - s1 * D + D, 0);
+        int fi = pk_make(flo, fhi);
+        int zacc = -1;
+        st_mem_sync();
+        cur = rec[0];
+        for (int v = 0; v < NV; ++v) {
+            const int vn = v + 1 < NV ? v + 1 : v;
+            const int4 nxt = rec[vn * 64];
+            const int j0 = s0 * NV + v, j1 = s1 * NV + v;
+            const int amask = (j0 < m ? 0xFFFF : 0) | (j1 < m ? (int)0xFFFF0000 : 0);
+            const int h = pk_max(cur.x, fi) & amask;
+            fi = pk_sub(fi, GEPK);
+            int mask;
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(mask) : "v"(pk_sub(cur.z, h)));
+            rec[v * 64] = make_int4(h, cur.y, pk_max(cur.z, h), (ipk & mask) | (cur.w & ~mask));
+            if (TERM) {
+                typedef unsigned short st_u2 __attribute__((ext_vector_type(2)));
+                zacc = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(st_u2, zacc), __builtin_bit_cast(st_u2, h ^ TERMPK)));
+            }
+            cur = nxt;
+        }
+        st_mem_sync();
+        if (TERM) {
+            if (__ballot((zacc & 0xFFFF) == 0 || ((unsigned)zacc >> 16) == 0u)) { hit_col = i; break; }
+        }
+    }
+    int lm = 0;
+    for (int v = 0; v < NV; ++v) { const int b = rec[v * 64].z; lm = max(lm, max((int)(short)(b & 0xFFFF), (int)(short)((unsigned)b >> 16))); }
+    const int M = hit_col >= 0 ? terminate : st_uni(cw_wave_max(lm));
+    StSweep best{0, -1, 0};
+    if (M <= 0) return best;
+    int kc = 0x7FFFFFFF;
+    for (int v = 0; v < NV; ++v) {
+        const int4 c = rec[v * 64];
+        if ((int)(short)(c.z & 0xFFFF) == M) kc = min(kc, (int)(short)(c.w & 0xFFFF) * step);
+        if ((int)(short)((unsigned)c.z >> 16) == M) kc = min(kc, (int)(short)((unsigned)c.w >> 16) * step);
+    }
+    kc = st_uni(-cw_wave_max(-kc));
+    const int col = kc * step;
+    int jr = 0x7FFFFFFF;
+    for (int v = 0; v < NV; ++v) {
+        const int4 c = rec[v * 64];
+        if ((int)(short)(c.z & 0xFFFF) == M && (int)(short)(c.w & 0xFFFF) == col) jr = min(jr, s0 * NV + v);
+        if ((int)(short)((unsigned)c.z >> 16) == M && (int)(short)((unsigned)c.w >> 16) == col) jr = min(jr, s1 * NV + v);
+    }
+    jr = st_uni(-cw_wave_max(-jr));
+    best.score = M; best.col = col; best.row = jr;
+    return best;
 }
 
 /* ---- the same sweep on several waves of one work-group (a read is a serial chain of windows, and a window is two sweeps of ~600
@@ -647,12 +772,15 @@ __device__ __forceinline__ void st_sys_helper(StSys* sm, const uint8_t* lds_base
     }
 }
 
-template <int NCHK, bool TERM>
-__device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane) {
+template <int NCHK, bool TERM> /* NCHK: the most registers per slot (chunks) this kernel holds; 0 = the last launch, which has the memory-state sweep for what is longer still */
+__device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane, uint8_t* state = nullptr) {
+    if constexpr (NCHK == 0) {
+        if (st_uni(m) > CW_ST_QMAX) return st_sweep_mem<TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane, state);
+    }
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
 #if CW_ST_STRIPED
     m = st_uni(m);
-    if constexpr (NCHK <= 8) return st_sweep_st2<NCHK, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if constexpr (NCHK >= 1 && NCHK <= 8) return st_sweep_st2<NCHK, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 128) return st_sweep_st2<1, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 256) return st_sweep_st2<2, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 384) return st_sweep_st2<3, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
@@ -663,7 +791,7 @@ __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const u
     if (m <= 1536) return st_sweep_st2<12, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     return st_sweep_st2<CW_ST_QMAX / 128, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
 #else
-    if constexpr (NCHK <= 8) return st_sweep_pk<NCHK, false, TERM>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
+    if constexpr (NCHK >= 1 && NCHK <= 8) return st_sweep_pk<NCHK, false, TERM>(q, st_uni(m), r, r_first, r_last_excl, step, terminate, lane);
     /* A variant per chunk count for the common lengths (a 500-base window's consensus is 500-600 positions: five chunks), each a
        branch-free column written chunk-interleaved (st_sweep_pk, EXACT); the rare long ones keep the sixteen-chunk loop that skips the
        chunks beyond the query with a scalar branch.  Round 2 walked everything up to 1024 positions through an eight-chunk loop with those
@@ -828,13 +956,14 @@ struct StAlign { int score, ref_begin, ref_end, query_begin, query_end; };
 
 /* full alignment: forward sweep, reverse sweep.  qfw = query codes; qrv = scratch for the reversed prefix. */
 template <int NCHK, bool SYS = false>
-__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane, StSys* sm = nullptr, const uint8_t* lds_base = nullptr) {
+__device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* qrv, const uint8_t* ref, int n, int lane, StSys* sm = nullptr, const uint8_t* lds_base = nullptr,
+                                            uint8_t* state = nullptr) {
     StAlign a{0, 0, -1, 0, -1};
     m = st_uni(m); n = st_uni(n);
     if (m <= 0 || n <= 0) return a;
     StSweep fw;
     if constexpr (SYS) fw = st_sweep_post(sm, lds_base, qfw, m, ref, 0, n, 1, -1, lane);
-    else fw = st_sweep_any<NCHK, false>(qfw, m, ref, 0, n, 1, -1, lane);
+    else fw = st_sweep_any<NCHK, false>(qfw, m, ref, 0, n, 1, -1, lane, state);
     a.score = fw.score;
     if (fw.score <= 0) return a;
     a.ref_end = fw.col; a.query_end = fw.row;
@@ -843,7 +972,7 @@ __device__ __forceinline__ StAlign st_align(const uint8_t* qfw, int m, uint8_t* 
     st_mem_sync();
     StSweep bw;
     if constexpr (SYS) bw = st_sweep_post(sm, lds_base, qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
-    else bw = st_sweep_any<NCHK, true>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane);
+    else bw = st_sweep_any<NCHK, true>(qrv, pm, ref, fw.col, -1, -1, fw.score, lane, state);
     a.ref_begin = bw.col; a.query_begin = fw.row - bw.row;
     return a;
 }
@@ -896,7 +1025,8 @@ template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO, bool SYS = false>
 __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = SYS ? 0 : threadIdx.x >> 6;
-    const uint32_t too_big = NCHK <= 8 ? (uint32_t)CW_READ_REDO : (uint32_t)CW_READ_CAPACITY; /* the narrow kernel hands on what the wide one reports as a capacity */
+    constexpr bool HUGE = NCHK == 0; /* the last launch: one wave per work-group, every buffer in global memory, consensuses up to CW_STH_QMAX */
+    const uint32_t too_big = !HUGE && a.huge ? (uint32_t)CW_READ_REDO : (uint32_t)CW_READ_CAPACITY; /* a kernel hands on what the last one reports as a capacity */
     StSys* const sm = (StSys*)(lds + (((size_t)CW_ST_SLAB_OF(QMAX, RMAX) + 15u) & ~(size_t)15u));
     if constexpr (SYS) {
         static_assert(WAVES == 1 && QMAX <= CW_STS_QMAX && RMAX <= CW_STS_RMAX, "one read per work-group");
@@ -905,7 +1035,8 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
         if (lane == 0) { sm->progress[wv] = 0u; if (wv == 0) sm->fail = 0; }
         if (wv != 0) { st_sys_helper(sm, lds, lane, wv); return; }
     }
-    uint8_t* slab = lds + (size_t)wave * CW_ST_SLAB_OF(QMAX, RMAX);
+    uint8_t* slab = HUGE ? a.huge + (size_t)blockIdx.x * CW_STH_WAVE_BYTES : lds + (size_t)wave * CW_ST_SLAB_OF(QMAX, RMAX);
+    uint8_t* const state = HUGE ? slab + (((size_t)CW_ST_SLAB_OF(QMAX, RMAX) + 255u) & ~(size_t)255u) : nullptr;
     uint8_t* refc = slab;                              /* RMAX codes of the aligned slice              */
     uint8_t* cur = refc + RMAX;                        /* current consensus (chars), QMAX              */
     uint8_t* old = cur + QMAX;                         /* previous window's consensus as written, QMAX */
@@ -915,7 +1046,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
     int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * WAVES + wave) * a.dir_bytes;
     for (;;) {
         uint32_t ri = 0;
-        if (lane == 0) ri = atomicAdd(a.cursor + (REDO ? 1 : 0), 1u);
+        if (lane == 0) ri = atomicAdd(a.cursor + (HUGE ? 2 : REDO ? 1 : 0), 1u);
         ri = (uint32_t)cw_lane_value((int)ri, 0);
         if (ri >= a.n_reads) break;
         /* the launch lasts as long as its longest read: the waves that hold the longest reads (handed out first) issue before the others */
@@ -976,7 +1107,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
             for (uint32_t x = lane; x < clen; x += 64) qfw[x] = (uint8_t)st_code(cur[x]);
             st_mem_sync();
             ST_PROF(0);
-            const StAlign al = st_align<NCHK, SYS>(qfw, (int)clen, qrv, refc, size_al, lane, sm, lds);     /* :90 */
+            const StAlign al = st_align<NCHK, SYS>(qfw, (int)clen, qrv, refc, size_al, lane, sm, lds, state);     /* :90 */
             ST_PROF(1);
             if (!CW_ST_PROF && a.trace && lane == 0) {
                 uint32_t* t = a.trace + 8 * (size_t)w;
@@ -1018,9 +1149,10 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
                         ST_PROF(3);
                         if (s1 > s2) {                                                                      /* :109-119 */
                             /* Align(seq1, seq2, min(len)) then the cigar's indel totals */
+                            if (overlap > RMAX) { status = (uint32_t)CW_READ_CAPACITY; break; } /* (the last launch only: elsewhere a consensus is no longer than a slice may be) */
                             for (uint32_t x = lane; x < overlap; x += 64) { qfw[x] = (uint8_t)st_code(seq1[x]); refc[x] = (uint8_t)st_code(cur[x]); }
                             st_mem_sync();
-                            const StAlign sub = st_align<NCHK, SYS>(qfw, (int)overlap, qrv, refc, (int)overlap, lane, sm, lds);
+                            const StAlign sub = st_align<NCHK, SYS>(qfw, (int)overlap, qrv, refc, (int)overlap, lane, sm, lds, state);
                             unsigned ins = 0, del = 0;
                             if (sub.score > 0) {
                                 if (!st_banded_indels(refc + sub.ref_begin, sub.ref_end - sub.ref_begin + 1, qfw + sub.query_begin, sub.query_end - sub.query_begin + 1,

@@ -245,7 +245,7 @@ typedef struct cw_stitch_read {
 
 #define CW_READ_OK       0
 #define CW_READ_DROPPED  1  /* dropRead: fewer than 10 % corrected bases after trimming; out_len = 0                    */
-#define CW_READ_CAPACITY 2  /* output slot, consensus (> 2048) or aligned slice (> 2048) too large; out_len = 0          */
+#define CW_READ_CAPACITY 2  /* output slot, consensus (> 32768) or aligned slice (> 2048) too large; out_len = 0         */
 
 /* All pointers are DEVICE pointers.  `win_pos` = (beg,end) per window as cw_window_positions wrote them; `batch` = the piles
  * the consensuses were computed from (the first sequence of a window is its template, CONSENT-correction.cpp:37);

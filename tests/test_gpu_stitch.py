@@ -174,6 +174,35 @@ def test_stitch_long_consensuses_use_the_wide_sweeps():
     assert rep == 5
 
 
+def test_stitch_consensuses_beyond_2048_take_the_last_launch():
+    """A window whose consensus is longer than the 2048 characters the re-assembly kernel holds in LDS and registers (chance anchors with k < 8 make
+    them; here junk is put around the true window sequence, up to 9000 characters, in result slots as large as k = 7 gets them) marks its read, and
+    the last launch -- every buffer and the sweep's state in global memory -- does the read again: status 0 and the oracle's string, not
+    CW_READ_CAPACITY.  The other reads of the launch are untouched by it."""
+    rng = random.Random(19)
+    rep = 0
+
+    def mutate(res, piles):
+        hit = 0
+        for w in range(len(piles)):
+            o, n = int(res.cons_off[w]), int(res.cons_len[w])
+            cap = int(res.cons_off[w + 1]) - o
+            extra = [0, 0, 2300, 0, 0, 4100, 0, 9000][(w + rep) % 8]
+            if n == 0 or extra == 0 or n + extra > cap:
+                continue
+            s = res.cons[o : o + n].tobytes()
+            left = [extra // 2, extra, 0][(w + rep) % 3]
+            t = "".join(rng.choice("ACGT") for _ in range(left)).encode() + s + "".join(rng.choice("ACGT") for _ in range(extra - left)).encode()
+            res.cons[o : o + len(t)] = np.frombuffer(t, np.uint8)
+            res.cons_len[w] = len(t)
+            hit += 1
+        assert hit > 0
+
+    for rep in range(3):
+        got, n_up = run_case(make_reads(140 + rep, 5, 12), mutate=mutate, prm=ca.Params(7, SOLID, 8, 2, 150))
+        assert n_up > 0
+
+
 def test_stitch_many_reads_in_one_launch():
     got, n_up = run_case(make_reads(108, 40, 10, lo=600, hi=1800))
     assert len(got) == 40 and n_up > 0
