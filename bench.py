@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--driver-leg", type=int, default=1, help="kernel mode: after the timed region rank 0 also runs the native driver (ONE process over the --gpus devices) on the fixed BASELINE configs[3]-scale read set and reports it under `driver_strong_scaling` of the same JSON line (strong scaling: the set does not grow with N); 0 disables")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
@@ -230,7 +230,8 @@ def main():
     if args.windows > 0:
         n_win = args.windows
     prm = ca.Params(9, 4, 8, 2, max_msa)
-    engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, args.engines))]
+    # (an engine allocates its scratch in its first run: no more engines than warm-up steps, so that no first run falls into the timed region)
+    engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, min(args.engines, max(1, args.warmup))))]
     eng = engines[0]
     lib = eng.lib
     dev = torch.device("cuda", local_rank)
@@ -254,7 +255,7 @@ def main():
         keep.append((t_wfs, t_len, t_off, t_bases))
         batches.append(Batch(n_win, n_seqs, n_words, t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr()))
     torch.cuda.synchronize(dev)
-    cons_cap = 3 * spec0.window_len + 256
+    cons_cap = 32768  # the slot cw_plan_results_device gives every window (the longest consensus the engine produces)
     solid_cap = (depth + 1) * (spec0.window_len + 24) // prm.solid + 16
     t_cons = torch.zeros(n_win * cons_cap, dtype=torch.uint8, device=dev)
     t_coff = (torch.arange(n_win + 1, dtype=torch.int64, device=dev) * cons_cap)

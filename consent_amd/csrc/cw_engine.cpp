@@ -29,6 +29,8 @@ static_assert(4 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_E
 static_assert(CW_POAL_LDS_BYTES <= (CW_POAL_MW > 1 ? 61440 : 40960), "tier L: a work-group fits the hole an M1/M2 work-group leaves (one wave), or a third of a CU (several waves, cw_poa_w.h)");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
+static_assert(CW_FIN_CB_BIG == 32768, "cw_plan_need_kernel (cw_pack.h) and alloc_results (engine.py) give every window a slot of CW_FIN_CB_BIG characters");
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct TierCfg { uint32_t slots; size_t slab_bytes; };

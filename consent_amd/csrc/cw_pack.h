@@ -96,12 +96,10 @@ __global__ void __launch_bounds__(256) cw_plan_need_kernel(PlanArgs a) {
     for (uint32_t s = s0 + lane; s < s1; s += 64) { const uint32_t l = a.seq_len[s]; nk += l >= a.k ? l - a.k + 1 : 0; }
     for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o);
     if (lane == 0) {
-        /* three templates + 256, and never less than the finish kernel's own string capacity (CW_FIN_CB 3072): the slot is then not what stops a
-           window whose consensus comes out several times its template (short k, spurious anchors) */
-        /* (k < 8: chance anchors make consensuses of several templates -- the finish kernel's second pass holds them, the slot has to as well) */
-        const unsigned long long c3 = s1 > s0 ? (a.k < 8u ? 12ull : 3ull) * a.seq_len[s0] + 256ull : 256ull;
-        const unsigned long long floor_ = a.k < 8u ? 32768ull : 3072ull; /* CW_FIN_CB_BIG / CW_FIN_CB */
-        a.cons_off[w] = c3 < floor_ ? floor_ : c3;
+        /* Every window's slot is the longest consensus the finish kernel can produce (its second pass: CW_FIN_CB_BIG characters), whatever k: the
+           slot is then never what stops a window (through round 4 three templates + 256, with a larger rule for k < 8 -- and k = 8 piles with
+           chance anchors still outgrew it in the fuzzers).  Address space, not traffic: only the characters written are ever touched or copied. */
+        a.cons_off[w] = 32768ull; /* CW_FIN_CB_BIG (cw_finish.h) */
         a.solid_off[w] = nk / a.solid + 16ull;
     }
 }

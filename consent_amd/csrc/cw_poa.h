@@ -57,7 +57,7 @@
 #define CW_POAL_LC 1023
 #define CW_POAL_WAVES 1
 /* tier G: everything in a per-wave global slab (int32 cells) */
-#define CW_POAB_NC 2048
+#define CW_POAB_NC 4096 /* (2048 until round 5: the graphs that stopped a window in the fuzzers were all this tier's) */
 #define CW_POAB_EC 8192
 #define CW_POAB_LC 1023
 #define CW_POAB_HC ((CW_POAB_NC + 1) * (CW_POAB_LC + 1))

@@ -369,7 +369,7 @@ def alloc_results(batch, want_solid=True, solid_thresh=4, k=9):
     W = batch.n_windows
     wfs = batch.win_first_seq.astype(np.int64)
     tpl = batch.seq_len[wfs[:-1]].astype(np.int64)
-    cap = np.maximum((12 if k < 8 else 3) * tpl + 256, 32768 if k < 8 else 3072)  # as cw_plan_results_device sizes it (cw_pack.h; k < 8: consensuses of several templates)
+    cap = np.full(len(tpl), 32768, np.int64)  # as cw_plan_results_device sizes it (cw_pack.h): the longest consensus the engine produces, for every window (untouched pages cost nothing)
     cons_off = np.zeros(W + 1, np.uint64)
     cons_off[1:] = np.cumsum(cap)
     cons = np.zeros(int(cons_off[-1]), np.uint8)

@@ -267,6 +267,22 @@ def test_long_and_outlier_segments_exercise_all_tiers(engines):
     assert_same(got, exp, len(piles), "tiers")
 
 
+def test_graph_of_more_than_2048_nodes(engines):
+    """Members that share their two ends and nothing in between: one segment of several hundred unrelated bases per member, a graph of a few
+    thousand nodes.  Beyond 2048 nodes was a window-level capacity through round 4 (tier G's slab); tier G holds 4096 now."""
+    rng = random.Random(29)
+    head, tail = rand_seq(rng, 60), rand_seq(rng, 60)
+    piles = [[head + rand_seq(rng, rng.randrange(520, 640)) + tail for _ in range(depth)] for depth in (6, 8)]
+    prm = (9, 2, 8, 2, 150)
+    hb = ca.pack_piles(piles)
+    got = engines(*prm).run(hb)
+    exp, _ = oracle_lib.oracle_run(ca.Params(*prm), hb)
+    assert not (got.status == ca.WIN_OVERFLOW).any()
+    assert_same(got, exp, len(piles), "big graph")
+    prof = engines(*prm).profile()[0]
+    assert int(prof[22]) >= 1, prof[18:24]  # tasks handed to tier G (n_over[4])
+
+
 def test_tier_h_two_tasks_per_wave(aids, monkeypatch):
     """Tier H (cw_poa_q.h, round 5): segments whose longest member has up to 63 bases, two tasks per wave on 32-lane halves, recorded decisions.
     Windows with few anchors give such segments; deep piles make nodes with many predecessors (the ordinal of a code covers three, the rest
