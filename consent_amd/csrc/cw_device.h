@@ -133,6 +133,7 @@ struct DevScratch {
     unsigned long long* ex_fallback; /* index kernel: per-work-group exact table of saturated keys for very deep piles (CW_EXG_SLOTS each) */
     uint4* task_dbg;               /* NULL unless CW_TASK_TRACE is set: per task (start, duration) in 1024-cycle units, tier|rc|pass, wave */
     uint32_t* fin_retry;           /* finish kernel: windows whose strings outgrew the first pass (n_windows entries) */
+    uint8_t* fin_big;              /* finish kernel, second pass: 3 x CW_FIN_CB_BIG bytes per work-group (64 of them) */
     uint32_t* fin_vis;             /* finish kernel: per-wave visited bitmap for windows with more solid k-mers than the LDS bitmap covers */
     uint32_t fin_vis_words;        /* words per wave (4^9 / 32: a window cannot have more distinct k-mers counted) */
     unsigned long long* step_clock; /* [0] wall clock at which the last batch's finish kernel ended (inspection: idle time between batches) */

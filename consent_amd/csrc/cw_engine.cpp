@@ -83,7 +83,7 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
 }
 
 struct ScratchPlan {
-    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], qslab, hslab, finretry, pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
+    size_t win, solid_key, solid_cnt, seg_off, seg_len, arena, tasks, members, ctr, list[CW_TIERS], over[CW_TIERS], slab[CW_TIERS], qslab, hslab, finretry, finbig, pfall, ablock, finvis, exg, tdbg, sbusy[CW_TIERS], total;
     uint64_t pfall_elems, ablock_units;
     uint64_t solid_cap, seg_cap, arena_cap;
     uint32_t task_cap, member_cap, arena_scale;
@@ -141,6 +141,7 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
     put(p.finvis, (size_t)cus * CW_FIN_WGS_PER_CU * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
     put(p.finretry, (size_t)n_windows * 4);
+    put(p.finbig, (size_t)64 * 3 * CW_FIN_CB_BIG);
     p.total = o;
     return p;
 }
@@ -201,7 +202,7 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POAL_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB_BIG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB_OF(CW_FIN_CB_BIG)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB_BIG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB_OF(0)) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
 #ifdef CW_TEST_AIDS
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
@@ -356,6 +357,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     if (sc.task_dbg) CW_HIP(hipMemsetAsync(sc.task_dbg, 0, (size_t)p.task_cap * 16, st));
     sc.fin_vis = (uint32_t*)(base + p.finvis); sc.fin_vis_words = CW_FIN_VIS_GLB_WORDS;
     sc.fin_retry = (uint32_t*)(base + p.finretry);
+    sc.fin_big = base + p.finbig;
     sc.linger_wgs = e->linger_wgs ? e->linger_wgs : 64;
     if (const char* env = CW_AID_ENV("CW_LINGER_WGS")) { int v = atoi(env); if (v >= 0 && v <= 1024) sc.linger_wgs = (uint32_t)v; }
     /* grids of the four concurrent tier kernels: `yield` work-groups that run one chunk of tasks and end, then `persist` ones that loop
@@ -549,7 +551,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false><<<grid, 64 * CW_FIN_WAVES, CW_FIN_SLAB * CW_FIN_WAVES, st>>>(db, sc, e->prm, fo);
         /* second pass: the windows whose strings outgrew the first pass's buffers (normally none: the kernel reads one counter and ends) */
         const uint32_t grid2 = batch->n_windows < 64u ? batch->n_windows : 64u;
-        cw_finish_kernel<CW_FIN_CB_BIG, 1, true><<<grid2, 64, CW_FIN_SLAB_OF(CW_FIN_CB_BIG), st>>>(db, sc, e->prm, fo);
+        cw_finish_kernel<CW_FIN_CB_BIG, 1, true><<<grid2, 64, CW_FIN_SLAB_OF(0), st>>>(db, sc, e->prm, fo);
     }
     stage_end(e, st, sid);
     /* feedback for the next batch's linger_wgs (pinned destination: asynchronous) */

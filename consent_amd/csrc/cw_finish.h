@@ -481,12 +481,16 @@ template <int CB, int WAVES, bool RETRY>
 __global__ void __launch_bounds__(64 * WAVES) cw_finish_kernel(DevBatch b, DevScratch sc, cw_params prm, FinOut out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* slab = lds + (size_t)wave * CW_FIN_SLAB_OF(CB);
+    /* The second pass keeps its three strings (3 x 32 KB) in global memory: as 107 KB of LDS its work-groups waited for a CU with that much
+       free -- among the persistent POA kernels of the other batches in flight 1 ms at depth 150, 5 ms in the driver -- to read one counter and end. */
+    constexpr int CBL = RETRY ? 0 : CB; /* string bytes in LDS */
+    uint8_t* slab = lds + (size_t)wave * CW_FIN_SLAB_OF(CBL);
     FinLds M;
     M.cb = CB;
-    uint8_t* buf0 = slab; uint8_t* buf1 = slab + CB;
-    M.path = slab + 2 * CB;
-    uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CB);
+    uint8_t* const strings = RETRY ? sc.fin_big + (size_t)blockIdx.x * 3 * CB : slab;
+    uint8_t* buf0 = strings; uint8_t* buf1 = strings + CB;
+    M.path = strings + 2 * CB;
+    uint32_t* const vis_lds = (uint32_t*)(slab + 3 * CBL);
     M.vis = vis_lds; M.vis_glb = false;
     uint32_t* skey_lds = vis_lds + CW_FIN_VIS_WORDS; /* CW_FIN_SKEYS + 4 words, right behind the bitmap: the compact table runs through both */
     M.f_nbk = skey_lds + CW_FIN_SKEYS + 4;

@@ -1044,6 +1044,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
     uint8_t* qfw = rows + CW_ST_ROWS_BYTES;            /* QMAX query codes                              */
     uint8_t* qrv = qfw + QMAX;                         /* QMAX reversed prefix / build area             */
     int8_t* dirbuf = a.dir_scratch + ((size_t)blockIdx.x * WAVES + wave) * a.dir_bytes;
+    if constexpr (HUGE) { if (st_uni(*(volatile uint32_t*)(a.cursor + 3)) == 0u) return; } /* no read was marked: normally */
     for (;;) {
         uint32_t ri = 0;
         if (lane == 0) ri = atomicAdd(a.cursor + (HUGE ? 2 : REDO ? 1 : 0), 1u);
@@ -1227,7 +1228,10 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitc
         }
         flen = st_uni(flen); status = st_uni(status);
         if constexpr (SYS) { if (st_uni(sm->fail)) { flen = 0; status = (uint32_t)CW_READ_CAPACITY; if (lane == 0) sm->fail = 0; } }
-        if (lane == 0) { a.out_len[ri] = flen; a.read_status[ri] = (uint8_t)status; }
+        if (lane == 0) {
+            a.out_len[ri] = flen; a.read_status[ri] = (uint8_t)status;
+            if (!HUGE && status == (uint32_t)CW_READ_REDO) atomicAdd(a.cursor + 3, 1u); /* the last launch looks at this count first */
+        }
         st_mem_sync();
     }
     if constexpr (SYS) { /* the other waves wait for the next request: none */
