@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "3")),
                     help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
     ap.add_argument("--alone-steps", type=int, default=3, help="untimed steps after the timed region with ONE batch in flight: per-kernel HIP-event times that are work, not waiting (roofline.launch_ms)")
-    ap.add_argument("--pcie-engines", type=int, default=1, help="engines the PCIe-inclusive leg spreads its host batches over")
+    ap.add_argument("--pcie-engines", type=int, default=2, help="engines the PCIe-inclusive leg spreads its host batches over")
     ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
 
@@ -448,7 +448,9 @@ def main():
         soff_h = (np.arange(n_win + 1, dtype=np.uint64) * solid_cap)
         res_h = []
         ne_p = max(1, min(ne, args.pcie_engines))
-        depth_p = 2  # host batches in flight (measured: four in flight over two engines 1.59e5, two over two engines 1.75e5, two on one engine 1.87e5)
+        # host batches in flight.  Round 5, one box: two on one engine 2.41e5 windows/s, two over two engines 2.74e5, three over two 2.89e5, three over three 2.72e5
+        # (rounds 2-3, with longer steps and the results copied back whole: four over two engines 1.59e5, two over two 1.75e5, two on one 1.87e5)
+        depth_p = int(os.environ.get("CW_BENCH_PCIE_DEPTH", "3" if ne_p >= 2 else "2"))
         for _ in range(depth_p):
             arrs = (np.zeros(n_win * cons_cap, np.uint8), np.zeros(n_win, np.uint32), np.zeros(n_win, np.uint8), np.zeros(n_win * solid_cap, np.uint32), np.zeros(n_win, np.uint32))
             res_h.append((arrs, Result(arrs[0].ctypes.data, coff_h.ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, soff_h.ctypes.data, arrs[4].ctypes.data)))
@@ -480,7 +482,7 @@ def main():
         out["pcie_inclusive"] = {
             "value": n_win * n_p / pdt, "unit": "windows/s", "batches": n_p, "ms_per_batch": pdt / n_p * 1e3,
             "h2d_mb_per_batch": in_mb, "d2h_mb_per_batch": out_mb,
-            "engines": ne_p, "path": "cw_submit/cw_wait (= cw_run in two halves), inputs in pinned host memory, two batches in flight, results compacted on the device and only the used bytes copied back, then scattered to the caller's (pageable) arrays",
+            "engines": ne_p, "batches_in_flight": depth_p, "path": "cw_submit/cw_wait (= cw_run in two halves), inputs in pinned host memory, batches in flight over the engines as stated, results compacted on the device and only the used bytes copied back, then scattered to the caller's (pageable) arrays",
         }
         del host, res_h
 

@@ -774,8 +774,8 @@ __device__ __forceinline__ void st_sys_helper(StSys* sm, const uint8_t* lds_base
 
 template <int NCHK, bool TERM> /* NCHK: the most registers per slot (chunks) this kernel holds; 0 = the last launch, which has the memory-state sweep for what is longer still */
 __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const uint8_t* r, int r_first, int r_last_excl, int step, int terminate, int lane, uint8_t* state = nullptr) {
-    if constexpr (NCHK == 0) {
-        if (st_uni(m) > CW_ST_QMAX) return st_sweep_mem<TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane, state);
+    if constexpr (NCHK == 0) { /* (registers for the common lengths only: the last launch is compiled for 128 of them, so that its work-groups find room beside running kernels) */
+        if (st_uni(m) > 640) return st_sweep_mem<TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane, state);
     }
     /* the narrow kernel (consensuses of at most 640 positions: every 500-base window): five chunks, a third of the registers */
 #if CW_ST_STRIPED
@@ -785,7 +785,7 @@ __device__ __forceinline__ StSweep st_sweep_any(const uint8_t* q, int m, const u
     if (m <= 256) return st_sweep_st2<2, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 384) return st_sweep_st2<3, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 512) return st_sweep_st2<4, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
-    if (m <= 640) return st_sweep_st2<5, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
+    if (m <= 640 || NCHK == 0) return st_sweep_st2<5, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 768) return st_sweep_st2<6, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 1024) return st_sweep_st2<8, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
     if (m <= 1536) return st_sweep_st2<12, TERM>(q, m, r, r_first, r_last_excl, step, terminate, lane);
@@ -1022,7 +1022,9 @@ __global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
 template <int QMAX, int RMAX, int NCHK, int WAVES, bool REDO, bool SYS = false>
 /* (the wide kernel needs 243 + 16 registers: one wave per SIMD, 1024 reads in flight.  Capped at 256 for two waves per SIMD the launch
    is SLOWER, 60.5 against 55.3 ms per job of 32768 windows: it lasts as long as its longest read, and that read's wave then shares its SIMD) */
-__global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES) cw_stitch_kernel(StitchArgs a) {
+/* (the last launch is compiled for 128 registers and holds the register sweeps of the common lengths only: normally it has nothing to do, and as a
+   334-register kernel its work-groups waited 4 ms for a SIMD that free beside the other workers' kernels) */
+__global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES, NCHK == 0 ? 4 : 1) cw_stitch_kernel(StitchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = SYS ? 0 : threadIdx.x >> 6;
     constexpr bool HUGE = NCHK == 0; /* the last launch: one wave per work-group, every buffer in global memory, consensuses up to CW_STH_QMAX */
