@@ -408,7 +408,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.producer_wgs = wgs_s + wgs_m1 + wgs_m2 + wgs_h;
     if (CW_AID_ENV("CW_DEBUG_DONE")) fprintf(stderr, "[debug] producer_wgs %u = S %u + M1 %u + M2 %u, L %u, linger %u\n", sc.producer_wgs, wgs_s, wgs_m1, wgs_m2, wgs_l, sc.linger_wgs);
     sc.tier_list[0] = (uint32_t*)(base + p.list[0]); sc.over_list[0] = (uint32_t*)(base + p.over[0]);
-    sc.use_q = CW_AID_ENV("CW_NO_TIER_Q") ? 0u : 1u;
+    sc.use_q = (CW_AID_ENV("CW_NO_TIER_Q") || CW_POA_AFFINE) ? 0u : 1u; /* (the affine gap model runs in the global-memory tier only: cw_poa_a.h) */
     sc.q_slab = base + p.qslab;
     sc.h_slab = base + p.hslab;
     for (int t = 0; t < CW_TIERS; ++t) {

@@ -68,7 +68,7 @@
                                                     stops at a cell of value 0.  Runs on the matrix paths only: no recorded decisions (CW_POA_CODES 0, CW_Q_CODES 0), no direction words */
 #define CW_POA_OV (CW_POA_MODE == CW_POA_MODE_OV || CW_POA_SW) /* overlap mode (cw_policy.h): column 0 is free, the end cell is the best cell of a sink row, the walk stops in column 0
                                                                   (the local mode shares all three, with "any row" for "a sink's row") */
-#if CW_POA_SW
+#if CW_POA_SW || CW_POA_AFFINE /* (the affine gap model: cw_poa_a.h, the global-memory tier only) */
 #define CW_POA_CODES 0
 #define CW_Q_CODES 0
 #endif
@@ -696,9 +696,12 @@ __device__ __forceinline__ uint32_t poa_consensus_hb(const PoaMem<HT>& M, const 
 #ifndef CW_POA_CODES
 #define CW_POA_CODES 1
 #endif
+#include "cw_poa_a.h"
+
 template <typename HT, int PK, int CM = 0, int LCAP = 1023> /* LCAP: the tier's longest member -- fills for wider rows are not compiled into its kernel */
 __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int lane,
                        unsigned long long (&acc)[6]) {
+    if constexpr (CW_POA_AFFINE && sizeof(HT) != 4) return 2; /* the affine gap model keeps three int32 layers: every task is handed on to the global-memory tier */
     unsigned long long _pt = __builtin_readcyclecounter();
 #define POA_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
     const int G = CW_POA_GAP, MS = CW_POA_MATCH, XS = CW_POA_MISMATCH;
@@ -830,8 +833,14 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
 #ifdef CW_POA_VERIFY
         const bool run_matrix_path = true;
 #else
-        const bool run_matrix_path = !coded;
+        const bool run_matrix_path = !coded && !CW_POA_AFFINE;
 #endif
+        if constexpr (CW_POA_AFFINE && sizeof(HT) == 4) { /* cw_poa_a.h: fill, end cell and walk back under the affine gap model */
+            int end_row = 0;
+            const int arc = poa_affine_align(M, n, L, lane, &end_row);
+            if (arc) return arc;
+            POA_PROF(1);
+        }
         if (run_matrix_path) {
         PoaMem<HT> V = M; /* the member's view of the matrix: in a group fill its columns begin at jo */
         V.H = M.H + jo;

@@ -156,14 +156,35 @@
  *           only its inserted/deleted base totals are used (correctionAlignment.cpp:28-45,111).
  * str2num on the mixed-case overlap strings (correctionAlignment.cpp:9): every character other than 'A','C','G' counts as T.
  * PARITY UNPINNED (library absent).                                                                                     */
-/* An AFFINE gap model for the POA (spoa >= 3 offers one; the version BMEAN bundles is unknown) is named here and NOT implemented on either side: */
+/* The gap model of the POA.  LINEAR: a gap of length L costs L * CW_POA_GAP (the default: what the three-score engine call of the spoa that BMEAN
+ * bundles takes).  AFFINE (spoa >= 3 offers one; round 5, policy insurance): a gap of length L costs CW_POA_GAP_OPEN + (L - 1) * CW_POA_GAP_EXT, with
+ * CW_POA_GAP_OPEN <= CW_POA_GAP_EXT < 0 -- Gotoh's three layers on the graph, global mode only:
+ *   F[i][j] = max over the in-edges p of i, in order: max(H[p][j] + open, F[p][j] + ext)           (a gap in the sequence: the node is skipped)
+ *   E[i][j] = max(H[i][j-1] + open, E[i][j-1] + ext)                                               (a gap in the graph: the base is an insertion)
+ *   H[i][j] = max(max over p (H[p][j-1] + s), F[i][j], E[i][j]);  column 0: H = F, no E;  the start row: H[0][0] = 0, H[0][j] = E[0][j] = open + (j-1) ext, no F
+ *   end cell as in the linear model (best node without out-edges in the last column, lowest rank on ties); the walk back keeps a layer:
+ *     in H: diagonal through the in-edges in order, else F if H == F, else E;
+ *     in F: the first in-edge with F == H[p][j] + open (-> p, layer H), else the first with F == F[p][j] + ext (-> p, layer F);
+ *     in E: H[i][j-1] + open (-> layer H) before E[i][j-1] + ext (-> layer E).
+ * Implemented on both sides: oracle/cw_oracle.cpp PoaGraph::align, consent_amd/csrc/cw_poa_a.h (every task runs in the global-memory tier:
+ * three int32 layers per cell; a build for checking a policy, not for speed).  PARITY UNPINNED like the rest of A4 (spoa absent). */
 #define CW_POA_GAP_MODEL_LINEAR 0
 #define CW_POA_GAP_MODEL_AFFINE 1
 #ifndef CW_POA_GAP_MODEL
 #define CW_POA_GAP_MODEL CW_POA_GAP_MODEL_LINEAR
 #endif
-#if CW_POA_GAP_MODEL != CW_POA_GAP_MODEL_LINEAR
-#error "cw_policy.h: CW_POA_GAP_MODEL_AFFINE is named but not implemented (three DP layers per row in oracle/cw_oracle.cpp and in every fill of consent_amd/csrc/)"
+#ifndef CW_POA_GAP_OPEN
+#define CW_POA_GAP_OPEN CW_POA_GAP
+#endif
+#ifndef CW_POA_GAP_EXT
+#define CW_POA_GAP_EXT (-6)
+#endif
+#define CW_POA_AFFINE (CW_POA_GAP_MODEL == CW_POA_GAP_MODEL_AFFINE)
+#if CW_POA_GAP_MODEL != CW_POA_GAP_MODEL_LINEAR && CW_POA_GAP_MODEL != CW_POA_GAP_MODEL_AFFINE
+#error "cw_policy.h: CW_POA_GAP_MODEL is LINEAR (0) or AFFINE (1)"
+#endif
+#if CW_POA_AFFINE && (CW_POA_MODE != CW_POA_MODE_NW || CW_POA_GAP_OPEN > CW_POA_GAP_EXT || CW_POA_GAP_EXT >= 0 || CW_POA_GAP_OPEN < -64)
+#error "cw_policy.h: the affine gap model is implemented for the global mode, with -64 <= CW_POA_GAP_OPEN <= CW_POA_GAP_EXT < 0"
 #endif
 
 #define CW_SSW_MATCH     2

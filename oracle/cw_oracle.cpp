@@ -144,7 +144,86 @@ struct PoaGraph {
         const int cols = L + 1;
         const int g = CW_POA_GAP;
         auto pred_row = [&](const PoaNode& nd, size_t p) { return node2rank[edges[nd.in_edges[p]].from] + 1; };
-#if defined(CWO_SIMD) && defined(__AVX2__) && CW_POA_MODE != CW_POA_MODE_SW
+#if CW_POA_AFFINE
+        /* Affine gaps (cw_policy.h CW_POA_GAP_MODEL_AFFINE): three layers, a walk back that keeps its layer. */
+        {
+            (void)g;
+            const int32_t go = CW_POA_GAP_OPEN, ge = CW_POA_GAP_EXT, NEG = -(1 << 28);
+            static thread_local std::vector<int32_t> Hh, Ff, Ee;
+            const size_t cells = (size_t)(n + 1) * cols;
+            if (Hh.size() < cells) { Hh.resize(cells); Ff.resize(cells); Ee.resize(cells); }
+            auto h = [&](int i, int j) -> int32_t& { return Hh[(size_t)i * cols + j]; };
+            auto f = [&](int i, int j) -> int32_t& { return Ff[(size_t)i * cols + j]; };
+            auto e = [&](int i, int j) -> int32_t& { return Ee[(size_t)i * cols + j]; };
+            h(0, 0) = 0; f(0, 0) = NEG; e(0, 0) = NEG;
+            for (int j = 1; j < cols; ++j) { e(0, j) = go + (j - 1) * ge; h(0, j) = e(0, j); f(0, j) = NEG; }
+            for (int i = 1; i <= n; ++i) {
+                const PoaNode& nd = nodes[rank2node[i - 1]];
+                const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+                for (int j = 0; j < cols; ++j) {
+                    int32_t fv = NEG, dv = NEG;
+                    for (size_t p = 0; p < np; ++p) {
+                        const int pi = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                        fv = std::max(fv, std::max(h(pi, j) + go, f(pi, j) + ge));
+                        if (j >= 1) dv = std::max(dv, h(pi, j - 1) + ((seq[j - 1] == nd.base) ? CW_POA_MATCH : CW_POA_MISMATCH));
+                    }
+                    f(i, j) = fv;
+                    if (j == 0) { e(i, 0) = NEG; h(i, 0) = fv; }
+                    else {
+                        e(i, j) = std::max(h(i, j - 1) + go, e(i, j - 1) + ge);
+                        h(i, j) = std::max(std::max(dv, fv), e(i, j));
+                    }
+                }
+            }
+            if (st) { st->dp_cells += (uint64_t)n * L; st->alignments++; }
+            int bi = -1;
+            int32_t bs = INT_MIN;
+            for (int i = 1; i <= n; ++i) {
+                if (!nodes[rank2node[i - 1]].out_edges.empty()) continue;
+                if (bi == -1 || bs < h(i, L)) { bs = h(i, L); bi = i; }
+            }
+            int i = bi, j = L, layer = 0; /* 0 H, 1 F, 2 E */
+            while (!(i == 0 && j == 0 && layer == 0)) {
+                if (layer == 0) {
+                    bool found = false;
+                    if (i != 0 && j != 0) {
+                        const PoaNode& nd = nodes[rank2node[i - 1]];
+                        const int32_t sc = (seq[j - 1] == nd.base) ? CW_POA_MATCH : CW_POA_MISMATCH;
+                        const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+                        for (size_t p = 0; p < np && !found; ++p) {
+                            const int r = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                            if (h(i, j) == h(r, j - 1) + sc) { path.emplace_back(rank2node[i - 1], j - 1); i = r; j = j - 1; found = true; }
+                        }
+                    }
+                    if (!found) {
+                        if (i != 0 && h(i, j) == f(i, j)) layer = 1;
+                        else { assert(j != 0 && h(i, j) == e(i, j)); layer = 2; }
+                    }
+                } else if (layer == 1) {
+                    const PoaNode& nd = nodes[rank2node[i - 1]];
+                    const size_t np = nd.in_edges.empty() ? 1 : nd.in_edges.size();
+                    bool found = false;
+                    for (size_t p = 0; p < np && !found; ++p) {
+                        const int r = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                        if (f(i, j) == h(r, j) + go) { path.emplace_back(rank2node[i - 1], -1); i = r; layer = 0; found = true; }
+                    }
+                    for (size_t p = 0; p < np && !found; ++p) {
+                        const int r = nd.in_edges.empty() ? 0 : pred_row(nd, p);
+                        if (f(i, j) == f(r, j) + ge) { path.emplace_back(rank2node[i - 1], -1); i = r; found = true; }
+                    }
+                    assert(found);
+                } else {
+                    path.emplace_back(-1, j - 1);
+                    if (e(i, j) == h(i, j - 1) + go) layer = 0;
+                    else assert(e(i, j) == e(i, j - 1) + ge);
+                    j = j - 1;
+                }
+            }
+            std::reverse(path.begin(), path.end());
+            return path;
+        }
+#endif
+#if defined(CWO_SIMD) && defined(__AVX2__) && CW_POA_MODE != CW_POA_MODE_SW && !CW_POA_AFFINE
         /* Row-vectorised fill for the CPU BASELINE leg of bench.py only (the real reference's POA, spoa, is SIMD code, so a
            scalar port flatters the GPU/CPU ratio).  Eight int32 columns per AVX2 register; rows are kept as W[i][j] = H[i][j] - j * gap,
            in which a horizontal move costs nothing: the horizontal recurrence is a prefix max (three shift-and-max steps inside a

@@ -133,3 +133,28 @@ def test_local_alignment_mode_is_implemented_on_both_sides(tmp_path):
     assert digest_default != digest_sw
     mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     assert not mixed
+
+
+@pytest.mark.timeout(1800)
+def test_affine_gap_model_is_implemented_on_both_sides(tmp_path):
+    """-DCW_POA_GAP_MODEL=1 (cw_policy.h CW_POA_GAP_MODEL_AFFINE, round 5): a gap of length L costs open + (L - 1) ext -- Gotoh's three layers on the
+    graph and a walk back that keeps its layer, in the oracle and in the engine (cw_poa_a.h: every task in the global-memory tier).  The two sides agree
+    window by window, the consensus is not the linear model's, mixing the sides disagrees -- and with ext == open the affine build of the ENGINE gives
+    the linear model's consensuses bit for bit (the two models coincide there, tie rules included)."""
+    from consent_amd import _build
+
+    aff = ["-DCW_POA_GAP_MODEL=1", "-DCW_POA_GAP_OPEN=-8", "-DCW_POA_GAP_EXT=-6"]
+    same_as_linear = ["-DCW_POA_GAP_MODEL=1", "-DCW_POA_GAP_OPEN=-8", "-DCW_POA_GAP_EXT=-8"]
+    alt_lib, lin_lib = str(tmp_path / "libconsent_amd_affine.so"), str(tmp_path / "libconsent_amd_affine_eq.so")
+    p1 = subprocess.Popen([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *aff, *_build.SRC, "-o", alt_lib])
+    p2 = subprocess.Popen([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *same_as_linear, *_build.SRC, "-o", lin_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(aff)])
+    assert p1.wait() == 0 and p2.wait() == 0
+    same_default, digest_default = run_child({})
+    same_aff, digest_aff = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_aff
+    assert digest_default != digest_aff
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed
+    same_eq, digest_eq = run_child({"CONSENT_AMD_LIB": lin_lib})  # the affine engine with ext == open against the DEFAULT (linear) oracle
+    assert same_eq and digest_eq == digest_default

@@ -172,3 +172,10 @@ print("DIGEST", h.hexdigest())
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "policy", f"OUT={ovs}", "POLICY=-DCW_POA_MODE=2 -mavx2 -DCWO_SIMD -DCWO_FAST"])
     d_ov = run({"CW_ORACLE_LIB": str(ov / "liboracle.so")})
     assert d_ov == run({"CW_ORACLE_LIB": str(ovs / "liboracle.so")}) and d_ov != d_default
+    # the affine gap model (cw_policy.h CW_POA_GAP_MODEL_AFFINE, round 5): with ext == open it IS the linear model -- cell values, tie rules, consensuses --
+    # and with ext != open it is not
+    aeq, aff = tmp_path / "aeq", tmp_path / "aff"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "policy", f"OUT={aeq}", "POLICY=-DCW_POA_GAP_MODEL=1 -DCW_POA_GAP_OPEN=-8 -DCW_POA_GAP_EXT=-8"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "policy", f"OUT={aff}", "POLICY=-DCW_POA_GAP_MODEL=1 -DCW_POA_GAP_OPEN=-8 -DCW_POA_GAP_EXT=-6"])
+    assert run({"CW_ORACLE_LIB": str(aeq / "liboracle.so")}) == d_default
+    assert run({"CW_ORACLE_LIB": str(aff / "liboracle.so")}) != d_default

@@ -49,7 +49,8 @@ bash tools/fuzz_policy.sh "-DCW_POA_MODE=2" $((FZ / 2)) > $EV/fuzz_policy_ov.txt
 bash tools/fuzz_policy.sh "-DCW_POA_CONSENSUS=1" $((FZ / 2)) > $EV/fuzz_policy_hb.txt 2>&1
 bash tools/fuzz_policy.sh "-DCW_POA_MODE=1" $((FZ / 2)) > $EV/fuzz_policy_sw.txt 2>&1
 bash tools/fuzz_policy.sh "-DCW_POA_MATCH=2 -DCW_POA_MISMATCH=-4 -DCW_POA_GAP=-4" $((FZ / 2)) > $EV/fuzz_policy_scores.txt 2>&1
-tail -2 $EV/verify.txt; tail -1 $EV/fuzz_parity.txt; tail -2 $EV/fuzz_pipeline.txt; tail -1 $EV/fuzz_policy_ov.txt; tail -1 $EV/fuzz_policy_hb.txt; tail -1 $EV/fuzz_policy_sw.txt; tail -1 $EV/fuzz_policy_scores.txt
+CW_FUZZ_CAP_BAR=0.05 CW_FUZZ_CAP_BAR_SHORT_K=0.2 bash tools/fuzz_policy.sh "-DCW_POA_GAP_MODEL=1 -DCW_POA_GAP_OPEN=-8 -DCW_POA_GAP_EXT=-6" $((FZ / 2)) > $EV/fuzz_policy_affine.txt 2>&1
+tail -2 $EV/verify.txt; tail -1 $EV/fuzz_parity.txt; tail -2 $EV/fuzz_pipeline.txt; tail -1 $EV/fuzz_policy_ov.txt; tail -1 $EV/fuzz_policy_hb.txt; tail -1 $EV/fuzz_policy_sw.txt; tail -1 $EV/fuzz_policy_scores.txt; tail -1 $EV/fuzz_policy_affine.txt
 python -c "
 import json
 for f in ('bench_r05_pacbio_d150_msa150','bench_r05_pacbio_d30_msa20','bench_r05_pacbio_d150_msa150_one_engine','driver_r05_x1','driver_r05_x8'):
