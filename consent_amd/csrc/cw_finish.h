@@ -478,7 +478,7 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
 
 /* CB: string capacity; WAVES: waves per work-group; RETRY: the second pass over the windows the first pass could not hold (sc.fin_retry) */
 template <int CB, int WAVES, bool RETRY>
-__global__ void __launch_bounds__(64 * WAVES) cw_finish_kernel(DevBatch b, DevScratch sc, cw_params prm, FinOut out) {
+__global__ void __launch_bounds__(64 * WAVES, RETRY ? 4 : 1) /* (the second pass at 128 registers: it has to find room beside running kernels, normally to read one counter) */ cw_finish_kernel(DevBatch b, DevScratch sc, cw_params prm, FinOut out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* The second pass keeps its three strings (3 x 32 KB) in global memory: as 107 KB of LDS its work-groups waited for a CU with that much
