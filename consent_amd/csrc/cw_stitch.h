@@ -4,11 +4,13 @@
  *
  * The local alignment the reference gets from StripedSmithWaterman::Aligner is restated per include/cw_policy.h
  * (library absent: PARITY UNPINNED, bit-identical to the oracle's restatement):
- *   sweep      two query positions per lane (packed int16), loop over reference columns; H, E and the per-position best in
- *              registers; F (gap inside the column) as a DPP exclusive prefix max of h'[t] + t*ext, exact because open >= ext;
- *              forward sweep finds (score, end), reverse sweep on the reversed prefixes finds begin (stops when the forward
- *              score is reached)
- *   indels     banded traceback, run by the whole wave redundantly (rare: only when two overlapping windows disagree)
+ *   sweep      packed int16, loop over reference columns; H, E and the per-position best in registers; striped since round 5
+ *              (st_sweep_st: a slot of NV consecutive positions per lane-half, the in-column gap F down the registers of a lane and ONE
+ *              exclusive DPP prefix max per column for its passage between slots, exact because open >= ext; the chunked sweep of
+ *              rounds 1-4, st_sweep_pk, is the -DCW_ST_STRIPED=0 variant); forward sweep finds (score, end), reverse sweep on the
+ *              reversed prefixes finds begin (stops when the forward score is reached); consensuses beyond 2048 characters: the last
+ *              launch with the sweep's state in global memory (st_sweep_mem)
+ *   indels     banded traceback when two overlapping windows disagree and the earlier one wins: its rows on the lanes of the wave
  *   the read   lives in its output slot as a gap buffer (left part at the front, untouched tail right-aligned), so a
  *              replace that changes the length moves only the few hundred characters between the gap and the edit.
  */
@@ -1008,10 +1010,12 @@ __global__ void __launch_bounds__(1024) cw_stitch_order_kernel(StitchArgs a) {
     for (uint32_t i = threadIdx.x; i < a.n_reads; i += 1024) a.order[atomicAdd(&hist[min(a.jobs[i].win_count, 1023u)], 1u)] = i;
 }
 
-/* Two instantiations: the NARROW one (consensus and read slice of at most 640 positions -- every window of the wrappers' defaults, 500 + 2 x 50 --
-   five packed chunks, 7.3 KB of LDS per wave, half the registers: twice the reads in flight per CU, and a read is a serial chain) runs over all
-   reads; a read that does not fit it (a longer consensus, a wider window) is marked CW_READ_REDO and taken by the WIDE one (2048 positions) in a
-   second launch.  REDO = this is that second launch: only marked reads. */
+/* The instantiations.  The product build launches the WIDE kernel (consensus and slice of at most 2048 positions, sweeps of 1..16 registers per slot)
+   over all reads, then the LAST one (NCHK = 0: consensuses up to CW_STH_QMAX, everything in global memory) over the reads the wide one marked
+   CW_READ_REDO -- normally none.  REDO = a launch that takes only marked reads.  The test-aid build also has the NARROW kernel (consensus and slice
+   of at most 640 positions -- every window of the wrappers' defaults, 500 + 2 x 50 -- five registers per slot, 7.3 KB of LDS per wave: twice the
+   reads in flight per CU; what does not fit it is marked and taken by the wide one as a REDO launch) and the several-waves-per-read one (SYS);
+   both bit-identical and measured no faster. */
 #define CW_READ_REDO 0xFEu
 #define CW_ST_SLAB_OF(QMAX, RMAX) ((RMAX) + 2 * (QMAX) + CW_ST_ROWS_BYTES + 2 * (QMAX))
 #define CW_STN_QMAX 640
