@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=int(os.environ.get("CW_BENCH_REPS", "3")),
+                    help="timed repetitions of the K-step region inside this process (SURVEY 8d: warm-up, then several timed runs, the MEDIAN reported): every repetition is exactly --steps steps between a barrier + synchronize on both sides, max over ranks; value / ms_per_step are the median repetition's, min and max beside them")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--windows", type=int, default=0, help="windows per step per GPU (default: per workload)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
@@ -209,15 +211,19 @@ def main():
         # the data path has no collective (north_star: "no RCCL"): the barrier and the one max-reduce of the timing go over gloo;
         # CW_BENCH_BACKEND=nccl (= RCCL on ROCm) remains for boxes where that is preferred
         backend = os.environ.get("CW_BENCH_BACKEND", "gloo")
+        import datetime
+
+        # (generous: the other ranks wait here while rank 0 runs its driver leg -- data generation, two dry runs, two full runs over all devices)
+        pg_timeout = datetime.timedelta(minutes=int(os.environ.get("CW_BENCH_PG_TIMEOUT_MIN", "60")))
         try:
             if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
             else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
         except Exception as exc:  # keep the run alive on a box where RCCL cannot initialise: the data path has no collective
             print(f"[bench] {backend} init failed ({exc}); falling back to gloo for the barrier", file=sys.stderr)
             backend = "gloo"
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         dist.barrier()  # (rank 0 arrives here after its driver leg)
     else:
         backend = None
@@ -276,61 +282,74 @@ def main():
     for i in range(args.warmup):
         engines[i % ne].run_device(batches[i % n_batches], rs[i % ne])
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
     stage_ms = {}
     n_over = n_tpl = 0
-    t0 = time.perf_counter()
     host_ms = [0.0, 0.0]
     ran = [0] * ne  # steps handed to each engine
     stagger = os.environ.get("CW_BENCH_STAGGER", "0") != "0"  # measured slower (82.9 vs 79.9 ms at depth 150): tier S ends as late as tier L, there is no tail to run under
     e_last = 0
-    for i in range(args.steps):
-        _h0 = time.perf_counter()
-        if ne == 1:
-            k_ = 0
-        else:  # the engine that is free takes the step (an engine still in a long tier-L tail does not hold up the others)
-            k_ = None
-            while k_ is None:
-                ph = [e_.phase() for e_ in engines]
-                for c_ in range(ne):
-                    c2 = (e_last + 1 + c_) % ne
-                    # a free engine takes the step; with CW_BENCH_STAGGER=1 only once every other engine is free or in its tail
-                    if ph[c2] == 1 and (not stagger or all(ph[o_] in (1, 2) for o_ in range(ne) if o_ != c2)):
-                        k_ = c2
-                        break
-                else:
-                    time.sleep(5e-5)
-            if ran[k_]:  # HIP events of that engine's previous step (complete: no wait)
-                for k, v in engines[k_].timings().items():
+
+    def timed_region():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; seconds, max over ranks."""
+        nonlocal e_last
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            _h0 = time.perf_counter()
+            if ne == 1:
+                k_ = 0
+            else:  # the engine that is free takes the step (an engine still in a long tier-L tail does not hold up the others)
+                k_ = None
+                while k_ is None:
+                    ph = [e_.phase() for e_ in engines]
+                    for c_ in range(ne):
+                        c2 = (e_last + 1 + c_) % ne
+                        # a free engine takes the step; with CW_BENCH_STAGGER=1 only once every other engine is free or in its tail
+                        if ph[c2] == 1 and (not stagger or all(ph[o_] in (1, 2) for o_ in range(ne) if o_ != c2)):
+                            k_ = c2
+                            break
+                    else:
+                        time.sleep(5e-5)
+                if ran[k_]:  # HIP events of that engine's previous step (complete: no wait)
+                    for k, v in engines[k_].timings().items():
+                        stage_ms.setdefault(k, []).append(v)
+            _h2 = time.perf_counter()
+            engines[k_].run_device(batches[(args.warmup + i) % n_batches], rs[k_])
+            e_last = k_
+            ran[k_] += 1
+            _h1 = time.perf_counter()
+            host_ms[0] += (_h1 - _h2) * 1e3
+            if ne == 1:
+                for k, v in engines[0].timings().items():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
                     stage_ms.setdefault(k, []).append(v)
-        _h2 = time.perf_counter()
-        engines[k_].run_device(batches[(args.warmup + i) % n_batches], rs[k_])
-        e_last = k_
-        ran[k_] += 1
-        _h1 = time.perf_counter()
-        host_ms[0] += (_h1 - _h2) * 1e3
-        if ne == 1:
-            for k, v in engines[0].timings().items():  # HIP events on the streams the kernels are launched on (cw_last_timings); waits for the step
-                stage_ms.setdefault(k, []).append(v)
-        host_ms[1] += (time.perf_counter() - _h1 + _h2 - _h0) * 1e3
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+            host_ms[1] += (time.perf_counter() - _h1 + _h2 - _h0) * 1e3
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
+    # SURVEY 8(d)'s protocol (VERDICT r05 item 5): one process, warm-up, then `--reps` timed repetitions of the same K-step region over the same
+    # resident batches; the line's value is the MEDIAN repetition (boxes of the pool differ by 10 %, runs on one box by +-1.5 ms: a single run of
+    # twenty steps met a 52-ms bar on one box and missed it on the next)
+    n_reps = max(1, args.reps)
+    rep_dt = [timed_region() for _ in range(n_reps)]
+    dt = float(np.median(rep_dt))
     if os.environ.get("CW_PROFILE"):
-        print("host ms per step: enqueue", round(host_ms[0] / args.steps, 3), "wait + read stage timings", round(host_ms[1] / args.steps, 3), file=sys.stderr)
+        print("host ms per step: enqueue", round(host_ms[0] / (args.steps * n_reps), 3), "wait + read stage timings", round(host_ms[1] / (args.steps * n_reps), 3), file=sys.stderr)
     if ne > 1:
         for c_ in range(ne):  # the last step of every engine
             if ran[c_]:
                 for k, v in engines[c_].timings().items():
                     stage_ms.setdefault(k, []).append(v)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     # --- kernel times with ONE batch in flight (untimed, after the clock stopped): with two engines a kernel's HIP-event span also holds
     # the wait for CUs the other batch occupies, so "launch duration = work" is only true here.  This is what `roofline` is priced on and
@@ -377,6 +396,13 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "reps": n_reps,
+        "ms_per_step_reps": [d_ / args.steps * 1e3 for d_ in rep_dt],
+        "ms_per_step_min": min(rep_dt) / args.steps * 1e3,
+        "ms_per_step_max": max(rep_dt) / args.steps * 1e3,
+        "value_min": total_windows / max(rep_dt),
+        "value_max": total_windows / min(rep_dt),
+        "value_is": "median of the timed repetitions (each exactly `steps` steps, barrier + synchronize on both sides, max over ranks)",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -388,6 +414,7 @@ def main():
             "distinct_windows_per_run": n_win * world * min(args.steps, max(1, n_batches - args.warmup)),
             "sharding": "windows by rank, no collective",
             "engines_per_gpu": ne,
+            "engines_requested": args.engines,
             "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "overflow_windows": n_over,
             "template_fallback_windows": n_tpl,
@@ -546,9 +573,12 @@ def main():
             "poa_dp_cells_per_window": ost["dp_cells"] / n_st,
             "poa_alignments_per_window": ost["alignments"] / n_st,
             "poa_gcups": ost["dp_cells"] / n_st * value / 1e9,
+            "poa_dp_cells_routed_per_window": ost["dp_cells_routed"] / n_st,
+            "poa_alignments_routed_per_window": ost["alignments_routed"] / n_st,
+            "poa_gcups_routed": ost["dp_cells_routed"] / n_st * value / 1e9,
             "kmers_per_window": ost["kmers"] / n_st,
             "poa_alignments_per_sec": ost["alignments"] / n_st * value,
-            "note": f"cell, alignment and k-mer counts from the oracle on the first {n_st} windows of the workload (they include the segments both sides resolve without a POA); GCUPS = cells/window x windows/s",
+            "note": f"cell, alignment and k-mer counts from the oracle on the first {n_st} windows of the workload (they include the segments both sides resolve without a POA: a single piece, or equal pieces no longer than k; the *_routed figures leave those out -- the cells of the alignments that reach one of the engine's POA tiers); GCUPS = cells/window x windows/s",
         }
         if prof_whole:  # from the SQ counter passes of the same command with one engine (profiles/latest_*.json, tools/summarize_r03.py)
             out["secondary"]["valu_issue_frac"] = prof_whole.get("valu_issue_frac")

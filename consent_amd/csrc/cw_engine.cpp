@@ -186,7 +186,7 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
-#if CW_Q_CODES
+#if CW_Q_CODES && defined(CW_TEST_AIDS) /* tier H: an opt-in kernel of the test-aid build (CW_TIER_H), not in the product's code object */
         hipFuncSetAttribute((const void*)cw_poa_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAH_TASK_BYTES * 2 * 6) != hipSuccess ||
 #endif
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC, CW_POAM1_WAVES, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -481,7 +481,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         sid = stage_begin(e, st, "poa_q");
         cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, st>>>(db, sc);
         stage_end(e, st, sid);
-#if CW_Q_CODES
+#if CW_Q_CODES && defined(CW_TEST_AIDS)
         if (wgs_h) {
             sid = stage_begin(e, st, "poa_h");
             cw_poa_h_kernel<<<wgs_h, 64 * h_waves, CW_POAH_TASK_BYTES * 2 * h_waves, st>>>(db, sc);
@@ -526,7 +526,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sid = stage_begin(e, ms, "poa_q");
     cw_poa_q_kernel<<<q_grid, 64 * q_waves, CW_POAQ_TASK_BYTES * 4 * q_waves, ms>>>(db, sc); /* four tasks per wave */
     stage_end(e, ms, sid);
-#if CW_Q_CODES
+#if CW_Q_CODES && defined(CW_TEST_AIDS)
     if (wgs_h) { /* two tasks per wave; hands what outgrows it to tier L's live queue, as tier S does */
         sid = stage_begin(e, ms, "poa_h");
         cw_poa_h_kernel<<<wgs_h, 64 * h_waves, CW_POAH_TASK_BYTES * 2 * h_waves, ms>>>(db, sc);

@@ -56,11 +56,15 @@ struct FinCtx {
     const uint16_t* scnt16; /* counts staged in LDS (all <= 65535), or NULL */
     bool staged;            /* skey points into LDS and holds at most CW_FIN_SKEYS keys */
     const uint16_t* k16;    /* or (round 4): more keys than that, k <= 9: their low 16 bits staged in LDS (fin_find), or NULL ... */
-    uint32_t b16[3];        /* ... and where the keys with bits 17:16 = 1, 2, 3 begin */
+    uint32_t b16_1, b16_2, b16_3; /* ... and where the keys with bits 17:16 = 1, 2, 3 begin (three scalars: as an array the lookups' select
+                                     chains became indexed scratch loads) */
     uint32_t n_solid;
     uint32_t k, solid, kmask;
-    /* pile, for exact recounts */
-    const DevBatch* b;
+    /* pile, for exact recounts (the three arrays themselves: a pointer to the kernel's DevBatch argument made the compiler keep a
+       copy of it -- and this struct with it -- in scratch memory, re-read at every table lookup: 136 B per lane in round 5's code object) */
+    const uint32_t* seq_len;
+    const uint64_t* seq_word_off;
+    const uint32_t* bases;
     uint32_t s0, N;
 };
 
@@ -88,8 +92,9 @@ __device__ __forceinline__ uint32_t fin_key_at(const uint8_t* s, uint32_t p, uin
 __device__ __forceinline__ int fin_find(const FinCtx& c, uint32_t key) {
     if (c.k16) { /* the compact table: the two high bits pick the range, the search compares 16-bit halves at LDS latency */
         const uint32_t h = key >> 16, kl = key & 0xFFFFu;
-        int lo = h == 0u ? 0 : h == 1u ? (int)c.b16[0] : h == 2u ? (int)c.b16[1] : (int)c.b16[2];
-        int hi = (h == 0u ? (int)c.b16[0] : h == 1u ? (int)c.b16[1] : h == 2u ? (int)c.b16[2] : (int)c.n_solid) - 1;
+        const int e1 = (int)c.b16_1, e2 = (int)c.b16_2, e3 = (int)c.b16_3, e4 = (int)c.n_solid; /* (read first, selected as values) */
+        int lo = h == 0u ? 0 : h == 1u ? e1 : h == 2u ? e2 : e3;
+        int hi = (h == 0u ? e1 : h == 1u ? e2 : h == 2u ? e3 : e4) - 1;
         if (h > 3u) return -1;
         while (lo <= hi) {
             const int mid = (lo + hi) >> 1;
@@ -145,8 +150,8 @@ __device__ uint32_t fin_count_exact(const FinCtx& c, uint32_t key, int lane) {
 __device__ uint32_t fin_count_scan(const FinCtx& c, uint32_t key, int lane) {
     uint32_t n = 0;
     for (uint32_t s = 0; s < c.N; ++s) {
-        const uint32_t len = c.b->seq_len[c.s0 + s];
-        const uint32_t* words = c.b->bases + c.b->seq_word_off[c.s0 + s];
+        const uint32_t len = c.seq_len[c.s0 + s];
+        const uint32_t* words = c.bases + c.seq_word_off[c.s0 + s];
         const uint32_t nk = len >= c.k ? len - c.k + 1 : 0;
         for (uint32_t p = lane; p < nk; p += 64) n += (cw_kmer_at(words, p, c.k) == key) ? 1u : 0u;
     }
@@ -553,7 +558,7 @@ __global__ void __launch_bounds__(64 * WAVES, RETRY ? 4 : 1) /* (the second pass
                 if ((uint32_t)len >= prm.k) { /* correctionMSA.cpp:43-46 */
                     FinCtx c;
                     c.skey = sc.solid_key + wi.solid_base; c.scnt = sc.solid_cnt + wi.solid_base; c.n_solid = wi.n_solid;
-                    c.scnt16 = nullptr; c.staged = false; c.k16 = nullptr;
+                    c.scnt16 = nullptr; c.staged = false; c.k16 = nullptr; c.b16_1 = c.b16_2 = c.b16_3 = 0u;
                     if (wi.n_solid > CW_FIN_SKEYS && wi.n_solid <= CW_FIN_K16_MAX && prm.k <= 9u && !vis_glb) {
                         /* a deep pile (depth 150: ~2500 solid k-mers): the keys do not fit as words -- and every lookup of the polish was a
                            twelve-step binary search in global memory.  Their low halves fit behind the bitmap words this many k-mers need. */
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(64 * WAVES, RETRY ? 4 : 1) /* (the second pass
                             const uint32_t h = key >> 16;
                             n1 += h < 1u ? 1u : 0u; n2 += h < 2u ? 1u : 0u; n3 += h < 3u ? 1u : 0u;
                         }
-                        c.b16[0] = (uint32_t)cw_wave_sum((int)n1); c.b16[1] = (uint32_t)cw_wave_sum((int)n2); c.b16[2] = (uint32_t)cw_wave_sum((int)n3);
+                        c.b16_1 = (uint32_t)cw_wave_sum((int)n1); c.b16_2 = (uint32_t)cw_wave_sum((int)n2); c.b16_3 = (uint32_t)cw_wave_sum((int)n3);
                         c.k16 = k16;
                         cw_wave_sync();
                     }
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(64 * WAVES, RETRY ? 4 : 1) /* (the second pass
                         cw_wave_sync();
                     }
                     c.k = prm.k; c.solid = prm.solid; c.kmask = (prm.k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * prm.k)) - 1u);
-                    c.b = &b; c.s0 = s0; c.N = wi.n_seqs;
+                    c.seq_len = b.seq_len; c.seq_word_off = b.seq_word_off; c.bases = b.bases; c.s0 = s0; c.N = wi.n_seqs;
                     /* weightConsensus: case[p] = solid(k-mer at min(p, len-k)) */
                     for (uint32_t p0 = 0; p0 < (uint32_t)len; p0 += 64) {
                         const uint32_t p = p0 + lane;

@@ -39,7 +39,9 @@
 #include <fstream>
 #include <new>
 #include <string>
+#include <string_view>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 struct cw_read_index {
@@ -502,46 +504,66 @@ int cw_paf_reformat(const char* in_path, const char* out_path) {
     return out.good() ? CW_OK : CW_E_INTERNAL;
 }
 
-/* explode (src/explode.cpp:14-51): split a PAF into prefix_1, prefix_2, ... so that inside one file every query name forms a
- * single run of lines: a new file starts when a name comes back after other names.  Stops at the first empty line. */
+/* explode (what src/explode.cpp:14-51 produces): split a PAF into prefix_1, prefix_2, ... so that inside one file every query name forms a
+ * single run of lines; a run whose name already ended a run of the current file opens the next file.  Input ends at the first empty line.
+ *
+ * One pass over the mapped file: runs are contiguous in the input, so a run is a byte range [run_beg, run_end) of the mapping and goes to the
+ * current file with one write -- no line is copied or re-assembled; the names that have closed a run in the current file are views into the
+ * mapping.  One behaviour of the reference program is kept because its output files are the contract (tests/test_wrappers_ref.py): a line whose
+ * name is empty takes the next line into its run whatever that line's name (the reference uses the empty string as "no previous name").  A
+ * last line without a newline gets one (the reference program does not end on such a file: explode.cpp:25,30 keep reading at end-of-file). */
 int cw_paf_explode(const char* in_path, const char* out_prefix, uint32_t* n_files) {
     if (!in_path || !out_prefix) return CW_E_INVALID;
-    std::ifstream f(in_path);
-    if (!f) return CW_E_INVALID;
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return CW_E_INVALID;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return CW_E_INVALID; }
+    const size_t n = (size_t)sb.st_size;
+    const char* const base = n ? (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    close(fd);
+    if (n && base == (const char*)MAP_FAILED) return CW_E_INVALID;
+    int rc = CW_OK;
+    FILE* out = nullptr;
+    uint32_t nb = 0;
+    auto open_next = [&]() -> bool {
+        if (out && fclose(out) != 0) rc = CW_E_INTERNAL;
+        out = fopen((std::string(out_prefix) + "_" + std::to_string(++nb)).c_str(), "wb");
+        return out != nullptr;
+    };
+    auto put = [&](const char* b, const char* e) { /* a run's bytes; the file's last line may lack its newline */
+        if (e > b && fwrite(b, 1, (size_t)(e - b), out) != (size_t)(e - b)) rc = CW_E_INTERNAL;
+        if (e > b && e[-1] != '\n' && fputc('\n', out) == EOF) rc = CW_E_INTERNAL;
+    };
     try {
-        std::unordered_map<std::string, char> seen;
-        uint32_t nb = 1;
-        std::ofstream cur(std::string(out_prefix) + "_" + std::to_string(nb));
-        if (!cur) return CW_E_INVALID;
-        std::string line, cur_read, old_read, pending;
-        auto next = [&]() { line.clear(); std::getline(f, line); };
-        next();
-        while (!line.empty()) {
-            old_read = cur_read;
-            const size_t t = line.find('\t');
-            cur_read = line.substr(0, t);
-            if (old_read.empty() || cur_read == old_read) {
-                pending += line; pending += '\n';
-                next();
-            } else {
-                seen.emplace(old_read, 1);
-                cur << pending;
-                pending = line; pending += '\n';
-                next();
-                if (seen.count(cur_read)) {
-                    seen.clear();
-                    cur.close();
-                    nb++;
-                    cur.open(std::string(out_prefix) + "_" + std::to_string(nb));
-                    if (!cur) return CW_E_INVALID;
+        if (!open_next()) { if (n) munmap((void*)base, n); return CW_E_INVALID; }
+        std::unordered_set<std::string_view> closed; /* names whose run in the current file has ended */
+        const char* const end = base + n;
+        const char* run_beg = base;     /* first byte of the run being collected */
+        std::string_view run_name;      /* its name; empty: none yet (or an empty one: see above) */
+        const char* p = base;
+        while (p < end && *p != '\n') { /* an empty line ends the input */
+            const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* const line_end = eol ? eol : end;
+            const char* tab = (const char*)memchr(p, '\t', (size_t)(line_end - p));
+            const std::string_view name(p, (size_t)((tab ? tab : line_end) - p));
+            if (!run_name.empty() && name != run_name) { /* the run in front of this line is complete */
+                put(run_beg, p);
+                closed.insert(run_name);
+                run_beg = p;
+                if (closed.count(name)) { /* this name came back: its lines start the next file */
+                    closed.clear();
+                    if (!open_next()) { rc = CW_E_INVALID; break; }
                 }
             }
+            run_name = name;
+            p = eol ? eol + 1 : end;
         }
-        if (!pending.empty()) cur << pending;
-        cur.close();
-        if (n_files) *n_files = nb;
-    } catch (...) { return CW_E_NOMEM; }
-    return CW_OK;
+        if (rc == CW_OK) put(run_beg, p);
+    } catch (...) { rc = CW_E_NOMEM; }
+    if (out && fclose(out) != 0 && rc == CW_OK) rc = CW_E_INTERNAL;
+    if (n) munmap((void*)base, n);
+    if (rc == CW_OK && n_files) *n_files = nb;
+    return rc;
 }
 
 /* merge (src/merge.cpp:29-65): for every header line (its first character dropped) copy, file after file, the run of lines whose

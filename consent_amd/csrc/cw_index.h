@@ -29,7 +29,7 @@ typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or wher
 #define CW_TMAX 1024 /* template k-mer slots */
 #define CW_EX_SLOTS 1024 /* in LDS; a pile that saturates more keys than this is counted again with the table in global memory */
 #define CW_EX_BITS 10
-#define CW_EXP_SLOTS 12 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
+#define CW_EXP_SLOTS 8 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
 #define CW_TH_SLOTS 2048
 #ifndef CW_IDX_BYTES

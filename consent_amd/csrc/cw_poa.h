@@ -607,7 +607,14 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
 }
 
 #include "cw_poa_c.h"
+#ifndef CW_POAL_MW
+#define CW_POAL_MW 1 /* waves of a tier-L work-group: 1 = one wave per task; 4 = cw_poa_w.h's pipeline, bit-identical and measured NOT faster (see that file) */
+#endif
+#if CW_POAL_MW > 1 /* tier L on several waves: a build variant (-DCW_POAL_MW=4, tests/test_gpu_variants.py); the default build does not carry it */
 #include "cw_poa_w.h"
+#else
+#define CW_POA_COMM_BYTES 0
+#endif
 
 /* One traceback step at a node with several predecessors (or whose step the direction words left open), decided from the cell
  * values in the order of preference of cw_policy.h: diagonal through the in-edges in order, then vertical through them, then
@@ -876,7 +883,9 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                 }
             }
             else if (cols <= 128) poa_fill_pk<1, PK == 2>(M, n, cols, hs, lane, use_dirs);
-            else if (PK == 2 && CW_POAL_MW > 1 && M.comm != nullptr) { if constexpr (PK == 2 && sizeof(HT) == 2) poa_fill_mw<true>(M, n, cols, hs, lane, use_dirs); } /* tier L: the chunks of the row on the waves of the work-group (cw_poa_w.h) */
+#if CW_POAL_MW > 1
+            else if (PK == 2 && M.comm != nullptr) { if constexpr (PK == 2 && sizeof(HT) == 2) poa_fill_mw<true>(M, n, cols, hs, lane, use_dirs); } /* tier L: the chunks of the row on the waves of the work-group (cw_poa_w.h) */
+#endif
             else if constexpr (LCAP > 127) {
                 if (cols <= 256) poa_fill_pk<2, PK == 2>(M, n, cols, hs, lane, use_dirs);
                 else if constexpr (LCAP > 255) {
@@ -1377,12 +1386,12 @@ __device__ __forceinline__ void poa_producer_done(const DevScratch& sc) {
  * the matrix of the rare member of more than 63 bases, flagged rows and the code words in a slab the wave claims (sc.slab[0]).
  * Capacities: CW_POA_NC nodes, CW_POA_LC bases; the 2048-cell limit is gone. */
 #ifndef CW_S_EU
-#define CW_S_EU 5
+#define CW_S_EU 4
 #endif
 #ifndef CW_M1_EU
-#define CW_M1_EU 5
+#define CW_M1_EU 4
 #endif
-__global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevBatch b, DevScratch sc) { /* five waves per SIMD: 96 VGPRs */
+__global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevBatch b, DevScratch sc) { /* round 6: four waves per SIMD (128 VGPRs, no scratch): at five (96 VGPRs) the round-5 kernel spilled 28 VGPRs into its row loops, and its measured residency is 3.6 waves per SIMD (LDS-bound) anyway */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t gw = 0;
@@ -1457,7 +1466,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
 #define CW_POAL_LDS_BYTES (CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES + (CW_POAL_MW > 1 ? CW_POA_COMM_BYTES : 0)) /* tier L's work-group */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES * (TIER == 3 ? CW_POAL_MW : 1), TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1: five waves per SIMD (96 VGPRs), M2: four (128) */
+__global__ void __launch_bounds__(64 * WAVES * (TIER == 3 ? CW_POAL_MW : 1), TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1 and M2: four waves per SIMD (128 VGPRs; M1 at five spilled 17 VGPRs, round 6) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
@@ -1482,9 +1491,13 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
             s = s + 1u == n_slots ? 0u : s + 1u;
         }
         gw = s;
+#if CW_POAL_MW > 1
         if (comm) { comm->slab = s; comm->seq = 0u; comm->cmd = 0u; for (int x = 0; x < CW_POAL_MW; ++x) { comm->done[x] = 0u; comm->ready[x] = 0u; } }
+#endif
     }
+#if CW_POAL_MW > 1
     if (comm) { __syncthreads(); if (lane == 0) gw = comm->slab; } /* (the one barrier of the kernel: the helpers learn the slab) */
+#endif
     gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gw);
     const bool yields = PASS == 0 && blockIdx.x + sc.persist_wgs[TIER] < gridDim.x;
     /* the slab is global memory: say so, or every access to the DP matrix is a flat_* instruction (both wait counters, aperture check) */
@@ -1511,13 +1524,15 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
-    if constexpr (TIER == 3 && CW_POAL_MW > 1) {
+#if CW_POAL_MW > 1
+    if constexpr (TIER == 3) {
         if (mw_wave > 0) { poa_mw_serve<true>(M, lane, mw_wave); return; } /* until wave 0 posts EXIT */
     }
+#endif
 #ifndef CW_M2_PRIO
 #define CW_M2_PRIO 1
 #endif
-    else if (TIER == 2) __builtin_amdgcn_s_setprio(CW_M2_PRIO);
+    if (TIER == 2) __builtin_amdgcn_s_setprio(CW_M2_PRIO);
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     auto run_task = [&](uint32_t ti) {
         const PoaTask t = sc.tasks[ti];
@@ -1590,11 +1605,13 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     } else if (PASS == 1) {
         /* not used for tiers below L */
     }
+#if CW_POAL_MW > 1
     if (comm) { /* the helpers leave */
         if (lane == 0) comm->cmd = CW_MW_CMD_EXIT;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) cww_store(&comm->seq, cww_load(&comm->seq) + 1u);
     }
+#endif
     poa_flush_prof(sc, 8 + 5 * TIER, acc, lane);
     if (lane == 0) __hip_atomic_store(&sc.slot_busy[TIER][gw], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); /* the slab goes back */
     if (PASS == 0 && TIER < 3) poa_producer_done(sc);

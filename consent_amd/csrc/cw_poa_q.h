@@ -700,11 +700,13 @@ __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     poaq_kernel_body<PoaQ16, 0, 0, 28, false>(b, sc, lds, sc.q_slab);
 }
+#ifdef CW_TEST_AIDS /* (opt-in, measured no faster: only the test-aid build carries the kernel) */
 /* tier H: members of up to 63 bases, graphs of up to 128 nodes; a task that outgrows it goes to tier L's live queue, like tier S's */
 __global__ void __launch_bounds__(64 * 6, 5) cw_poa_h_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     poaq_kernel_body<PoaQ32, 5, 3, 64, true>(b, sc, lds, sc.h_slab);
 }
+#endif
 
 #endif /* CW_Q_CODES */
 #endif

@@ -666,7 +666,13 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
             if (!members.empty()) st->poa_segments++;
             for (auto& x : members) st->max_seg_len = std::max<uint64_t>(st->max_seg_len, x.size());
         }
+        /* (statistics only: what the engine's chain kernel writes directly -- a single piece, or equal pieces no longer than k, which are a
+           prefix of the left anchor -- never reaches one of its POA tiers; bench.py's poa_gcups_routed counts the other segments' cells) */
+        bool trivial = members.size() <= 1;
+        if (!trivial && members[0].size() <= k) { trivial = true; for (auto& x : members) if (x != members[0]) { trivial = false; break; } }
+        const uint64_t c0 = st ? st->dp_cells : 0, a0 = st ? st->alignments : 0;
         consensus += poa_consensus(members, st);
+        if (st && !trivial) { st->dp_cells_routed += st->dp_cells - c0; st->alignments_routed += st->alignments - a0; }
     }
     return true;
 }

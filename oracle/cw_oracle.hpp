@@ -42,6 +42,7 @@ struct Params {
 struct Stats {
     uint64_t kmers = 0, tpl_anchors = 0, chain_len = 0, pair_tests = 0;
     uint64_t segments = 0, poa_segments = 0, alignments = 0, dp_cells = 0, max_nodes = 0, max_seg_len = 0;
+    uint64_t alignments_routed = 0, dp_cells_routed = 0; /* ... of the segments the engine sends to a POA tier (not: a single piece; equal pieces no longer than k) */
     uint64_t link_calls = 0, nbr_calls = 0;
 };
 

@@ -21,9 +21,9 @@ static std::string unpack(const cw_batch* b, uint32_t s) {
 }
 
 static void add_stats(uint64_t* dst, const Stats& s) {
-    const uint64_t v[13] = {s.kmers, s.tpl_anchors, s.chain_len, s.pair_tests, s.segments, s.poa_segments, s.alignments,
-                            s.dp_cells, s.max_nodes, s.max_seg_len, s.link_calls, s.nbr_calls, 0};
-    for (int i = 0; i < 12; ++i) {
+    const uint64_t v[14] = {s.kmers, s.tpl_anchors, s.chain_len, s.pair_tests, s.segments, s.poa_segments, s.alignments,
+                            s.dp_cells, s.max_nodes, s.max_seg_len, s.link_calls, s.nbr_calls, s.alignments_routed, s.dp_cells_routed};
+    for (int i = 0; i < 14; ++i) {
         if (i == 8 || i == 9) dst[i] = std::max(dst[i], v[i]);
         else dst[i] += v[i];
     }
@@ -31,7 +31,7 @@ static void add_stats(uint64_t* dst, const Stats& s) {
 
 extern "C" {
 
-/* Same contract as cw_run (host buffers).  stats (nullable) receives 12 counters, see add_stats. */
+/* Same contract as cw_run (host buffers).  stats (nullable) receives 14 counters, see add_stats. */
 int cwo_run(const cw_params* p, const cw_batch* b, const cw_result* r, uint64_t* stats, int n_threads) {
     if (!p || !b || !r) return CW_E_INVALID;
     Params prm{p->k, p->solid, p->common_kmers, p->min_anchors, p->max_msa};
@@ -76,7 +76,7 @@ int cwo_run(const cw_params* p, const cw_batch* b, const cw_result* r, uint64_t*
     worker(0);
     for (auto& t : th) t.join();
     if (stats) {
-        memset(stats, 0, 12 * sizeof(uint64_t));
+        memset(stats, 0, 14 * sizeof(uint64_t));
         for (auto& s : tstats) add_stats(stats, s);
     }
     return rc;

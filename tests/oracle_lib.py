@@ -29,14 +29,14 @@ def ref():
     return _R
 
 
-STAT_NAMES = ["kmers", "tpl_anchors", "chain_len", "pair_tests", "segments", "poa_segments", "alignments", "dp_cells", "max_nodes", "max_seg_len", "link_calls", "nbr_calls"]
+STAT_NAMES = ["kmers", "tpl_anchors", "chain_len", "pair_tests", "segments", "poa_segments", "alignments", "dp_cells", "max_nodes", "max_seg_len", "link_calls", "nbr_calls", "alignments_routed", "dp_cells_routed"]
 
 
 def oracle_run(params, batch, want_solid=True, threads=1):
     res = alloc_results(batch, want_solid, params.solid, params.k)
     b = batch.c_struct()
     r = _result_struct(res)
-    stats = np.zeros(12, np.uint64)
+    stats = np.zeros(len(STAT_NAMES), np.uint64)
     rc = oracle().cwo_run(C.byref(params), C.byref(b), C.byref(r), _ptr(stats), threads)
     assert rc in (0, -4), rc
     return res, dict(zip(STAT_NAMES, (int(x) for x in stats)))

@@ -71,6 +71,28 @@ def test_explode_and_merge_match_reference(tmp_path, seed):
     assert a == b and len(a) > 0
 
 
+@pytest.mark.parametrize("name,text", [
+    # (a last line WITHOUT a newline is not a case: the reference program never ends on it -- getline at end-of-file leaves the line in place)
+    ("stops_at_empty_line", "a\t1\nb\t2\n\na\t3\nc\t4\n"),           # nothing behind the empty line is read
+    ("empty_name_joins_its_neighbours", "a\t1\n\t2\nb\t3\na\t4\nb\t5\n"),  # the reference takes "" for "no previous name"
+    ("empty_file", ""),
+    ("one_line", "solo\t1\n"),
+    ("no_tabs", "x\nx\ny\nx\n"),
+    ("crlf", "a\t1\r\na\t2\r\nb\t3\r\n\r\na\t4\r\n"),           # "\r" is a line of one character, not an empty one
+    ("name_back_twice", "a\t1\nb\t2\na\t3\nb\t4\na\t5\n"),
+])
+def test_explode_edge_cases_match_reference(tmp_path, name, text):
+    """the one-pass slice writer of cw_paf_explode against the reference program on the inputs where line handling shows"""
+    src = str(tmp_path / "e.paf")
+    open(src, "wb").write(text.encode())
+    subprocess.check_call([tool("ref_explode"), src, str(tmp_path / "refx")])
+    got = ca.paf_explode(src, str(tmp_path / "gotx"))
+    ref_chunks = sorted(glob.glob(str(tmp_path / "refx_*")), key=lambda p: int(p.rsplit("_", 1)[1]))
+    assert len(got) == len(ref_chunks) >= 1, name
+    for g, r in zip(got, ref_chunks):
+        assert open(g, "rb").read() == open(r, "rb").read(), (name, g)
+
+
 def test_wrapper_errors(tmp_path):
     with pytest.raises(ca.EngineError):
         ca.paf_reformat(str(tmp_path / "missing.paf"), str(tmp_path / "o.paf"))
