@@ -261,7 +261,9 @@ def main():
         keep.append((t_wfs, t_len, t_off, t_bases))
         batches.append(Batch(n_win, n_seqs, n_words, t_wfs.data_ptr(), t_len.data_ptr(), t_off.data_ptr(), t_bases.data_ptr()))
     torch.cuda.synchronize(dev)
-    cons_cap = 32768  # the slot cw_plan_results_device gives every window (the longest consensus the engine produces)
+    from consent_amd.engine import cons_slot_bytes
+
+    cons_cap = int(cons_slot_bytes(prm.k, spec0.window_len))  # the slot cw_plan_results_device gives every window (include/consent_amd.h CW_CONS_SLOT_BYTES)
     solid_cap = (depth + 1) * (spec0.window_len + 24) // prm.solid + 16
     t_cons = torch.zeros(n_win * cons_cap, dtype=torch.uint8, device=dev)
     t_coff = (torch.arange(n_win + 1, dtype=torch.int64, device=dev) * cons_cap)

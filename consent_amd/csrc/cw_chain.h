@@ -29,6 +29,9 @@
 #define CW_CH_LIST_BYTES 1792
 #define CW_CH_TILE_STRIDE 66u /* u16 per row of phase D's tile: 64 sequences + 2 (33 words: a column read by 64 lanes hits every bank twice) */
 
+/* the successor's index inside a chain key (length + 1 << 48 | score << 16 | this): the largest key wins, so the field is 0xFFFF - b when equal
+   length and score go to the SMALLEST successor (the default) and b itself when they go to the largest (cw_policy.h CW_CHAIN_TIE) */
+#define CW_CH_BFIELD(b) (CW_CHAIN_TIE == CW_CHAIN_TIE_LARGEST_SUCCESSOR ? (uint32_t)(b) : 0xFFFFu - (uint32_t)(b))
 __device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t ch_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -126,9 +129,9 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                 const uint32_t hi = key ? (((uint32_t)(key >> 48) << 21) | (uint32_t)((key >> 16) & 0x1FFFFFull)) : 0u;
                 const uint32_t mx = (uint32_t)cw_lane_value((int)cw_wave_scan_max_u32(hi), 63); /* one fused 32-bit prefix max */
                 if (!mx) return 0ull;
-                const unsigned long long who = __ballot(hi == mx); /* the first lane holding it = the smallest b */
-                const uint32_t fb = b0 + (uint32_t)(__ffsll((long long)who) - 1);
-                return ((unsigned long long)(mx >> 21) << 48) | ((unsigned long long)(mx & 0x1FFFFFu) << 16) | (unsigned long long)(0xFFFFu - fb);
+                const unsigned long long who = __ballot(hi == mx); /* the first lane holding it = the smallest b (the last lane: the largest, CW_CHAIN_TIE) */
+                const uint32_t fb = b0 + (CW_CHAIN_TIE == CW_CHAIN_TIE_LARGEST_SUCCESSOR ? 63u - (uint32_t)__clzll((long long)who) : (uint32_t)(__ffsll((long long)who) - 1));
+                return ((unsigned long long)(mx >> 21) << 48) | ((unsigned long long)(mx & 0x1FFFFFu) << 16) | (unsigned long long)CW_CH_BFIELD(fb);
             };
             /* the window path, compiled once per (words of presence, correction rows or not): everything it tests is then a constant */
             auto chain_window = [&](auto nw_tag, auto delta_tag) {
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             if (DELTA) { cnt += d_b_cur; if (row_a != 0xFFu) cnt += row_at(row_a, bb); }
                             if ((int)cnt >= sup_min)
                                 key = ((unsigned long long)((uint32_t)r_len + 1u) << 48) | ((unsigned long long)((uint32_t)r_sc + cnt) << 16) |
-                                      (unsigned long long)(0xFFFFu - bb);
+                                      (unsigned long long)CW_CH_BFIELD(bb);
                         }
                         best = wave_best(key, b0);
                         if (best != 0ull && b0 + 64 < A) stop = sm_far < (int)(best >> 48) - 1;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                                 }
                                 if ((int)cnt >= sup_min)
                                     key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
-                                          (unsigned long long)(0xFFFFu - bb);
+                                          (unsigned long long)CW_CH_BFIELD(bb);
                             }
                             key = wave_best(key, b0);
                             best = key > best ? key : best;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     sm_run = la > sm_run ? la : sm_run;
                     if (lane == 0) {
                         clen[a] = (int16_t)la; csc[a] = sca;
-                        cnxt[a] = best == 0ull ? (int16_t)-1 : (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
+                        cnxt[a] = best == 0ull ? (int16_t)-1 : (int16_t)CW_CH_BFIELD((uint32_t)(best & 0xFFFFull));
                         smax[a] = (int16_t)sm_run;
                     }
                     /* slide the window: lane l takes lane l-1, lane 0 takes anchor a */
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         }
                         if ((int)cnt >= sup_min)
                             key = ((unsigned long long)((uint32_t)clen[bb] + 1u) << 48) | ((unsigned long long)((uint32_t)csc[bb] + cnt) << 16) |
-                                  (unsigned long long)(0xFFFFu - bb);
+                                  (unsigned long long)CW_CH_BFIELD(bb);
                     }
                     key = cw_wave_max_u64(key);
                     best = key > best ? key : best;
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         la = (int)(best >> 48); /* stored length+1 of b == length of a */
                         clen[a] = (int16_t)la;
                         csc[a] = (int32_t)((best >> 16) & 0xFFFFFFFFull);
-                        cnxt[a] = (int16_t)(0xFFFFu - (uint32_t)(best & 0xFFFFull));
+                        cnxt[a] = (int16_t)CW_CH_BFIELD((uint32_t)(best & 0xFFFFull));
                     }
                     const int sm = smax[a + 1];
                     smax[a] = (int16_t)(la > sm ? la : sm);
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                    in between, so the loads pipeline), then writes its own segment if it is trivial: empty, a prefix of its
                    left anchor (all pieces equal and no longer than k), or a single short piece.  The few segments that need
                    the whole wave -- POA tasks and long single pieces -- follow one by one. */
-                bool over = false;
+                bool over = false, over_arena = false; /* (over_arena is wave-uniform: decided from wave-uniform totals) */
                 uint32_t q_cnt = 0;
                 unsigned long long t_flush = 0;
                 uint16_t* d_tile = (uint16_t*)(slab + off_csc);                         /* 65 rows x 66 u16 */
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     const uint32_t need = n_mem == 0 ? 0u : (by_anchor || single) ? mx : 2 * mx + 2;
                     const int inc = cw_wave_scan_add((int)need);
                     const uint32_t total = (uint32_t)cw_lane_value(inc, 63);
-                    if (arena_used + total > arena_cap) { over = true; }
+                    if (arena_used + total > arena_cap) { over = true; over_arena = true; }
                     else {
                         const uint32_t abs_off = arena_base + arena_used + (uint32_t)inc - need;
                         const uint32_t slot = seg_base + seg;
@@ -567,7 +570,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                 }
                 if (!over && q_cnt) flush();
                 if (lane == 0) atomicAdd(&sc.ctr->prof[49], t_flush);
-                if (over) { new_status = CW_WIN_OVERFLOW; why = CW_WHY_TASKS; }
+                if (over) { new_status = CW_WIN_OVERFLOW; why = over_arena ? CW_WHY_ARENA : CW_WHY_TASKS; }
                 else n_segs_out = m + 1;
             }
             CW_PROF(sc.ctr, 6, lane == 0);

@@ -47,13 +47,15 @@ struct WinInfo {
 #define CW_WHY_TEMPLATE 4   /* template longer than CW_TMAX k-mers                                   */
 #define CW_WHY_MATRIX 5     /* position matrix larger than the fallback slot / the anchor block      */
 #define CW_WHY_SEGMENTS 6   /* more chain segments than slots                                        */
-#define CW_WHY_TASKS 7      /* task / member / arena capacity of the batch                           */
+#define CW_WHY_TASKS 7      /* task / member / list capacity of the batch                            */
 #define CW_WHY_POA 8        /* a POA task outgrew every tier, or its output slot                     */
 #define CW_WHY_FIN_LEN 9    /* consensus longer than the finish kernel's string buffers              */
 #define CW_WHY_FIN_SOLID 10 /* more solid k-mers than the visited bitmap covers                      */
 #define CW_WHY_FIN_POLISH 11/* the polish outgrew a buffer                                           */
 #define CW_WHY_OUT_CONS 12  /* the caller's consensus slot is too small                              */
 #define CW_WHY_OUT_SOLID 13 /* the caller's solid slot is too small                                  */
+#define CW_WHY_ARENA 14     /* the window's slice of the segment arena (round 6: told apart from CW_WHY_TASKS -- a plan whose arena scale is
+                               already clamped cannot cure it, and re-running the batch three times for nothing was ADVICE r05's finding)  */
 
 
 struct PoaTask {

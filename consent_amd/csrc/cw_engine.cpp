@@ -14,6 +14,7 @@
 #include "cw_stitch.h"
 #include "cw_pack.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +30,7 @@ static_assert(4 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_E
 static_assert(CW_POAL_LDS_BYTES <= (CW_POAL_MW > 1 ? 61440 : 40960), "tier L: a work-group fits the hole an M1/M2 work-group leaves (one wave), or a third of a CU (several waves, cw_poa_w.h)");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
-static_assert(CW_FIN_CB_BIG == 32768, "cw_plan_need_kernel (cw_pack.h) and alloc_results (engine.py) give every window a slot of CW_FIN_CB_BIG characters");
+static_assert(CW_FIN_CB_BIG == CW_CONS_SLOT_MAX, "the largest consensus slot (include/consent_amd.h CW_CONS_SLOT_BYTES, engine.py cons_slot_bytes) is what the finish kernel's second pass holds");
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -139,7 +140,8 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
     put(p.exg, idx_wgs * CW_EXG_SLOTS * 8);
     put(p.tdbg, getenv("CW_TASK_TRACE") ? (size_t)p.task_cap * 16 : 0);
-    put(p.finvis, (size_t)cus * CW_FIN_WGS_PER_CU * CW_FIN_WAVES * CW_FIN_VIS_GLB_WORDS * 4);
+    /* one visited bitmap per wave of the first finish pass -- and of the second (one wave per work-group, up to 64 of them): the larger of the two */
+    put(p.finvis, std::max<size_t>((size_t)cus * CW_FIN_WGS_PER_CU * CW_FIN_WAVES, 64) * CW_FIN_VIS_GLB_WORDS * 4);
     put(p.finretry, (size_t)n_windows * 4);
     put(p.finbig, (size_t)64 * 3 * CW_FIN_CB_BIG);
     p.total = o;
@@ -969,7 +971,7 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     sl.o_slen = put((size_t)W * 4);
     sl.o_pc = put(sl.cons_cap); sl.o_ps = put(sl.solid_cap * 4); /* the compacted copies */
     const size_t o_pco = put((size_t)(W + 1) * 8), o_pso = put((size_t)(W + 1) * 8);
-    sl.o_tot = put(24);
+    sl.o_tot = put(40);
     sl.o_cons = o_cons; sl.o_solid = o_solid;
     const size_t out_bytes = o;
     int rc = ensure(&sl.dev_in, &sl.dev_in_bytes, in_bytes);
@@ -1007,6 +1009,8 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     pa.pc = (char*)(dout + sl.o_pc); pa.ps = (uint32_t*)(dout + sl.o_ps);
     pa.pc_off = (uint64_t*)(dout + o_pco); pa.ps_off = (uint64_t*)(dout + o_pso); pa.totals = (uint64_t*)(dout + sl.o_tot);
     pa.win = (const WinInfo*)e->scratch; /* this batch's: the pack kernels follow its finish kernel on the compute stream */
+    pa.used = (const uint32_t*)((const uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks));
+    static_assert(offsetof(BatchCounters, n_members) == offsetof(BatchCounters, n_tasks) + 4, "cw_pack_scan_kernel reads the two counters as a pair");
     cw_pack_scan_kernel<<<1, 1024, 0, st>>>(pa);
     cw_pack_copy_kernel<<<(W + 3) / 4, 256, 0, st>>>(pa);
     CW_HIP(hipGetLastError());
@@ -1016,12 +1020,14 @@ int cw_submit(cw_engine* e, const cw_batch* b, const cw_result* r, int* ticket) 
     return CW_OK;
 }
 
-static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks);
+static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks, uint32_t* used = nullptr);
 int cw_wait(cw_engine* e, int ticket) { return wait_ticket(e, ticket, nullptr); }
 
 /* why_tasks (may be NULL): how many windows of THIS ticket stopped on the batch's task / member / arena capacities */
-static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks) {
+/* used (may be NULL): this ticket's task and member counts */
+static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks, uint32_t* used) {
     if (why_tasks) *why_tasks = 0;
+    if (used) used[0] = used[1] = 0xFFFFFFFFu;
     if (!e || ticket < 0 || ticket >= CW_SLOTS) return CW_E_INVALID;
     cw_slot& sl = e->slot[ticket];
     {
@@ -1037,9 +1043,9 @@ static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks) {
     const cw_result& r = sl.res;
     uint8_t* dout = (uint8_t*)sl.dev_out;
     hipStream_t co = e->copy_out;
-    uint64_t tot[3] = {0, 0, 0};
+    uint64_t tot[5] = {0, 0, 0, 0, 0};
     int rc = CW_OK;
-    if (hipMemcpyAsync(tot, dout + sl.o_tot, 24, hipMemcpyDeviceToHost, co) != hipSuccess ||
+    if (hipMemcpyAsync(tot, dout + sl.o_tot, 40, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.cons_len, dout + sl.o_clen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess ||
         hipMemcpyAsync(r.win_status, dout + sl.o_stat, W, hipMemcpyDeviceToHost, co) != hipSuccess ||
         (sl.want_solid && hipMemcpyAsync(r.solid_len, dout + sl.o_slen, (size_t)W * 4, hipMemcpyDeviceToHost, co) != hipSuccess) ||
@@ -1047,6 +1053,7 @@ static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks) {
         return fail(CW_E_NO_DEVICE);
     if (tot[0] > sl.cons_cap || tot[1] > sl.solid_cap) return fail(CW_E_INTERNAL);
     if (why_tasks) *why_tasks = tot[2];
+    if (used) { used[0] = (uint32_t)tot[3]; used[1] = (uint32_t)tot[4]; }
     const size_t need = align_up(tot[0], 256) + tot[1] * 4 + 256;
     if (sl.pin_out_bytes < need) {
         if (sl.pin_out) (void)hipHostFree(sl.pin_out);
@@ -1083,14 +1090,14 @@ static int wait_ticket(cw_engine* e, int ticket, uint64_t* why_tasks) {
    actually run: inside the 32-bit offsets (plan_scratch clamps the arena's own scale) and inside the device's free memory.  A scale that is not
    is refused here, and the run that has finished stands with its overflow statuses (it used to end the batch with CW_E_INVALID or
    CW_E_NOMEM).  known_any: -1 = look at the last run's WinInfo in scratch (cw_run_device_sync: the caller has just waited for that very run);
-   0 / 1 = the caller knows from its own ticket whether such windows exist (cw_run: scratch may already belong to another thread's batch). */
+   0 / 1 / 2 / 3 = the caller knows from its own ticket which kinds of such windows exist (bit 0 task / member slots, bit 1 arena slices) (cw_run: scratch may already belong to another thread's batch). */
 static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int known_any, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words) {
     *again = false;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->scratch || n_windows == 0 || e->cap_scale >= 64u) return CW_OK;
     if (CW_AID_ENV("CW_TASK_CAP") || CW_AID_ENV("CW_MEMBER_CAP")) return CW_OK; /* (test aids that shrink exactly these capacities) */
     CW_HIP(hipSetDevice(e->device));
-    bool any = known_any > 0;
+    int kinds = known_any > 0 ? known_any : 0; /* bit 0: windows stopped on task / member slots, bit 1: on their arena slices */
     if (known_any < 0) {
         if (e->last_windows != n_windows) return CW_OK;
         /* copies on the caller's stream, not hipMemcpy: the null stream would wait for every other stream of the device -- the other worker's job */
@@ -1102,12 +1109,21 @@ static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int kno
         CW_HIP(hipMemcpyAsync(wi.data(), e->scratch, (size_t)e->last_windows * sizeof(WinInfo), hipMemcpyDeviceToHost, st));
         CW_HIP(hipStreamSynchronize(st));
         /* (windows stopped for other reasons stay stopped: the loop ends when no window names these capacities, or at x64) */
-        for (const WinInfo& w : wi) any = any || (w.status == CW_WIN_OVERFLOW && w.pad_ == CW_WHY_TASKS);
+        for (const WinInfo& w : wi) if (w.status == CW_WIN_OVERFLOW) kinds |= w.pad_ == CW_WHY_TASKS ? 1 : w.pad_ == CW_WHY_ARENA ? 2 : 0;
     }
-    if (!any) return CW_OK;
+    if (!kinds) return CW_OK;
     const uint32_t next = e->cap_scale * 4u;
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, next);
+    {   /* does the larger plan grow what ran out?  (the arena's own scale is clamped to 32-bit offsets: a batch stopped on its arena slices
+           at a clamped scale is the same batch with the same arena at x4, x16 and x64) */
+        const ScratchPlan cur = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale);
+        const bool helps = ((kinds & 1) && (p.task_cap > cur.task_cap || p.member_cap > cur.member_cap)) || ((kinds & 2) && p.arena_scale > cur.arena_scale);
+        if (!helps) {
+            fprintf(stderr, "[consent_amd] windows stopped on the batch's %s capacity; a plan x%u does not enlarge it: keeping the run's result\n", (kinds & 2) ? "arena" : "task / member", next);
+            return CW_OK;
+        }
+    }
     size_t free_b = 0, total_b = 0;
     const bool mem_known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     if (!mem_known) (void)hipGetLastError();
@@ -1126,18 +1142,24 @@ static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int kno
 
 /* A grown plan is not forever: after a run at scale > 1 that used less than half of what the next smaller plan offers, the
    scale goes back a step; scratch that has become three times what the smaller plan needs is given back to the device. */
-static void decay_scale(cw_engine* e, hipStream_t st, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words) {
+/* known (may be NULL): the run's own task and member counts (cw_run: its ticket's totals -- the counters in scratch may by now be another thread's batch);
+   NULL: read them from scratch (cw_run_device_sync: the caller has just waited for that very run).  Scratch is only given back when nothing of this
+   engine is in flight. */
+static void decay_scale(cw_engine* e, hipStream_t st, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, const uint32_t* known = nullptr) {
     std::lock_guard<std::mutex> lk(e->mu);
-    if (e->cap_scale <= 1u || !e->scratch || e->last_windows != n_windows) return;
+    if (e->cap_scale <= 1u || !e->scratch || (!known && e->last_windows != n_windows)) return;
     if (hipSetDevice(e->device) != hipSuccess) return;
     uint32_t* used = e->host_fb + 10; /* pinned: n_tasks, n_members */
-    if (hipMemcpyAsync(used, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (known) { if (known[0] == 0xFFFFFFFFu) return; used[0] = known[0]; used[1] = known[1]; }
+    else if (hipMemcpyAsync(used, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale / 4u);
     if ((uint64_t)used[0] * 2u > lower.task_cap || (uint64_t)used[1] * 2u > lower.member_cap) return;
     e->cap_scale /= 4u;
-    if (e->scratch_bytes > 3 * lower.total + ((size_t)1 << 30)) { /* nothing of this engine is in flight: the caller has just waited for its stream */
+    bool in_flight = false;
+    for (int i = 0; i < CW_SLOTS; ++i) in_flight = in_flight || e->slot[i].busy; /* (cw_run: another thread's batch may be running on this scratch) */
+    if (!in_flight && e->scratch_bytes > 3 * lower.total + ((size_t)1 << 30)) { /* nothing of this engine is in flight: the caller has just waited for its stream */
         if (hipFree(e->scratch) != hipSuccess) (void)hipGetLastError();
         e->scratch = nullptr; e->scratch_bytes = 0;
     }
@@ -1186,14 +1208,18 @@ int cw_run(cw_engine* e, const cw_batch* b, const cw_result* r) {
             return rc;
         }
         uint64_t why_tasks = 0;
-        const int wrc = wait_ticket(e, t, &why_tasks);
+        uint32_t used[2];
+        const int wrc = wait_ticket(e, t, &why_tasks, used);
         if (wrc != CW_OK && wrc != CW_E_CAPACITY) return wrc;
         bool again = false;
         { std::lock_guard<std::mutex> lk(e->mu); scale_before = e->cap_scale; }
         /* the decision comes from this ticket's own totals (cw_pack_scan_kernel counts the windows stopped on CW_WHY_TASKS): other threads may have
            submitted since, and the WinInfo in scratch may be theirs */
-        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again, e->stream, why_tasks ? 1 : 0, b->n_windows, b->n_seqs, b->n_words)) != CW_OK) return rc;
-        if (!again) return wrc;
+        if (wrc == CW_E_CAPACITY && (rc = grow_if_that_helps(e, &again, e->stream, ((uint32_t)why_tasks ? 1 : 0) | ((why_tasks >> 32) ? 2 : 0), b->n_windows, b->n_seqs, b->n_words)) != CW_OK) return rc;
+        if (!again) {
+            if (!grown && wrc == CW_OK) decay_scale(e, e->stream, b->n_windows, b->n_seqs, b->n_words, used); /* the host path never lowered a grown scale */
+            return wrc;
+        }
         grown = true; first_rc = wrc;
     }
 }

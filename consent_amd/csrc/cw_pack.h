@@ -27,22 +27,24 @@ struct PackArgs {
     uint32_t* ps;      /* packed solid k-mers    */
     uint64_t* pc_off;  /* [n_windows + 1]        */
     uint64_t* ps_off;  /* [n_windows + 1]        */
-    uint64_t* totals;  /* [0] consensus bytes, [1] solid k-mers, [2] windows stopped on the batch's task / member / arena capacities (CW_WHY_TASKS) */
+    uint64_t* totals;  /* [0] consensus bytes, [1] solid k-mers, [2] windows stopped on the batch's task / member capacities (CW_WHY_TASKS, low half) and on their arena slices (CW_WHY_ARENA, high half) */
     const WinInfo* win; /* the batch's per-window records in the engine's scratch (read for [2] only) */
+    const uint32_t* used; /* the batch's counters n_tasks, n_members (BatchCounters): copied to totals[3], [4] -- what cw_run's scale decay goes by */
 };
 
 __global__ void __launch_bounds__(1024) cw_pack_scan_kernel(PackArgs a) {
     __shared__ unsigned long long pa[1024], pb[1024];
     __shared__ unsigned long long run[2];
-    __shared__ unsigned int why_tasks;
+    __shared__ unsigned int why_tasks, why_arena;
     const int tid = threadIdx.x;
     if (tid < 2) run[tid] = 0;
-    if (tid == 0) why_tasks = 0;
+    if (tid == 0) { why_tasks = 0; why_arena = 0; }
     __syncthreads();
     for (uint32_t w0 = 0; w0 < a.n_windows; w0 += 1024) {
         const uint32_t w = w0 + tid;
         const bool live = w < a.n_windows && a.win_status[w] != CW_WIN_OVERFLOW;
         if (w < a.n_windows && !live && a.win[w].status == CW_WIN_OVERFLOW && a.win[w].pad_ == CW_WHY_TASKS) atomicAdd(&why_tasks, 1u);
+        if (w < a.n_windows && !live && a.win[w].status == CW_WIN_OVERFLOW && a.win[w].pad_ == CW_WHY_ARENA) atomicAdd(&why_arena, 1u);
         const unsigned long long c = live ? a.cons_len[w] : 0, s = (live && a.solid) ? a.solid_len[w] : 0;
         pa[tid] = c; pb[tid] = s;
         __syncthreads();
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(1024) cw_pack_scan_kernel(PackArgs a) {
         if (tid == 0) { run[0] += pa[1023]; run[1] += pb[1023]; }
         __syncthreads();
     }
-    if (tid == 0) { a.pc_off[a.n_windows] = run[0]; a.ps_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; a.totals[2] = why_tasks; }
+    if (tid == 0) { a.pc_off[a.n_windows] = run[0]; a.ps_off[a.n_windows] = run[1]; a.totals[0] = run[0]; a.totals[1] = run[1]; a.totals[2] = (uint64_t)why_tasks | ((uint64_t)why_arena << 32); a.totals[3] = a.used[0]; a.totals[4] = a.used[1]; }
 }
 
 __global__ void __launch_bounds__(256) cw_pack_copy_kernel(PackArgs a) {
@@ -96,10 +98,10 @@ __global__ void __launch_bounds__(256) cw_plan_need_kernel(PlanArgs a) {
     for (uint32_t s = s0 + lane; s < s1; s += 64) { const uint32_t l = a.seq_len[s]; nk += l >= a.k ? l - a.k + 1 : 0; }
     for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o);
     if (lane == 0) {
-        /* Every window's slot is the longest consensus the finish kernel can produce (its second pass: CW_FIN_CB_BIG characters), whatever k: the
-           slot is then never what stops a window (through round 4 three templates + 256, with a larger rule for k < 8 -- and k = 8 piles with
-           chance anchors still outgrew it in the fuzzers).  Address space, not traffic: only the characters written are ever touched or copied. */
-        a.cons_off[w] = 32768ull; /* CW_FIN_CB_BIG (cw_finish.h) */
+        /* the slot rule of include/consent_amd.h (CW_CONS_SLOT_BYTES): real device memory, so it follows k (round 5 gave every window the finish
+           kernel's 32768 characters: 1 GiB per job of 32768 windows and worker, for a case the default k never met) */
+        const uint32_t tpl = s1 > s0 ? a.seq_len[s0] : 0u;
+        a.cons_off[w] = (unsigned long long)CW_CONS_SLOT_BYTES(a.k, tpl);
         a.solid_off[w] = nk / a.solid + 16ull;
     }
 }

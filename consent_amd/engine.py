@@ -365,11 +365,21 @@ class WindowResults:
         return self.solid[o : o + int(self.solid_len[w])]
 
 
+def cons_slot_bytes(k, tpl_len):
+    """CW_CONS_SLOT_BYTES of include/consent_amd.h: the consensus slot cw_plan_results_device gives a window (numpy-friendly)."""
+    tpl = np.asarray(tpl_len, np.int64)
+    if k >= 9:
+        return np.clip(4 * tpl + 1024, 3072, 32768)
+    if k == 8:
+        return np.minimum(16 * tpl + 1024, 32768)
+    return np.full_like(tpl, 32768)
+
+
 def alloc_results(batch, want_solid=True, solid_thresh=4, k=9):
     W = batch.n_windows
     wfs = batch.win_first_seq.astype(np.int64)
     tpl = batch.seq_len[wfs[:-1]].astype(np.int64)
-    cap = np.full(len(tpl), 32768, np.int64)  # as cw_plan_results_device sizes it (cw_pack.h): the longest consensus the engine produces, for every window (untouched pages cost nothing)
+    cap = cons_slot_bytes(k, tpl)  # as cw_plan_results_device sizes it (cw_pack.h)
     cons_off = np.zeros(W + 1, np.uint64)
     cons_off[1:] = np.cumsum(cap)
     cons = np.zeros(int(cons_off[-1]), np.uint8)

@@ -195,8 +195,18 @@ int cw_extract_piles_device(cw_engine* e, const cw_read_set* reads, const cw_ove
                             uint64_t* n_words, void* hip_stream);
 
 /* Result slots for a device-resident batch (what a caller of cw_run_device has to size before the call): writes the exclusive offsets
- * cons_off[n_windows+1] (3 x template length + 256 bytes per window: the polish may lengthen a consensus) and solid_off[n_windows+1]
- * (k-mers in the window's pile / solidThresh + 16 entries), both DEVICE arrays, and returns their totals (one synchronisation). */
+ * cons_off[n_windows+1] (CW_CONS_SLOT_BYTES(k, template length) per window) and solid_off[n_windows+1] (k-mers in the window's pile /
+ * solidThresh + 16 entries), both DEVICE arrays, and returns their totals (one synchronisation).
+ *
+ * The consensus slot.  A consensus is about as long as its template; the polish may lengthen it; with k < 9, chance anchors make consensuses of
+ * several templates (the finish kernel holds 32768 characters).  Slots are real device memory (and, through cw_submit, twice that per batch in
+ * flight), so the rule follows k: k >= 9 -- no window of the randomised testers (5e5 windows, k 9..16) ever went beyond three templates + 256 --
+ * gets four templates + 1024, at least 3072; k = 8 sixteen templates + 1024; k < 8 the full 32768.  A consensus that outgrows its slot is a
+ * reported capacity (window status 2, CW_WHY_OUT_CONS), never a truncation; a caller that sizes its own slots may give every window 32768. */
+#define CW_CONS_SLOT_MAX 32768u
+#define CW_CONS_SLOT_BYTES(k, tpl_len) \
+    ((k) >= 9u ? (4u * (uint32_t)(tpl_len) + 1024u < 3072u ? 3072u : (4u * (uint32_t)(tpl_len) + 1024u > CW_CONS_SLOT_MAX ? CW_CONS_SLOT_MAX : 4u * (uint32_t)(tpl_len) + 1024u)) \
+     : (k) == 8u ? (16u * (uint32_t)(tpl_len) + 1024u > CW_CONS_SLOT_MAX ? CW_CONS_SLOT_MAX : 16u * (uint32_t)(tpl_len) + 1024u) : CW_CONS_SLOT_MAX)
 int cw_plan_results_device(cw_engine* e, const cw_batch* batch, uint64_t* cons_off, uint64_t* solid_off, uint64_t* cons_total, uint64_t* solid_total,
                            void* hip_stream);
 

@@ -97,8 +97,8 @@
 #ifndef CW_POA_CONS_GAP
 #define CW_POA_CONS_GAP CW_CONS_GAP_STRICT
 #endif
-#define CW_CHAIN_TIE_SMALLEST_SUCCESSOR 0 /* equal length and score -> the smallest successor index (implemented) */
-#define CW_CHAIN_TIE_LARGEST_SUCCESSOR 1
+#define CW_CHAIN_TIE_SMALLEST_SUCCESSOR 0 /* equal length and score -> the smallest successor index (strict '>' while scanning the successors upward) */
+#define CW_CHAIN_TIE_LARGEST_SUCCESSOR 1  /* -> the largest ('>=' on the score: a memoised recursion that keeps the LAST best successor); both sides since round 6 */
 #ifndef CW_CHAIN_TIE
 #define CW_CHAIN_TIE CW_CHAIN_TIE_SMALLEST_SUCCESSOR
 #endif
@@ -108,7 +108,7 @@
 #define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
 #endif
 #if (CW_POA_MODE != CW_POA_MODE_NW && CW_POA_MODE != CW_POA_MODE_OV && CW_POA_MODE != CW_POA_MODE_SW) || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
-    CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
+    (CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR && CW_CHAIN_TIE != CW_CHAIN_TIE_LARGEST_SUCCESSOR) || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
 #error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
 #endif
 /* the column vote, one place for both sides: drop the column? / take the template's base on a tie? */

@@ -608,7 +608,7 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
             int s = pair_score(tpl[a], tpl[b]);
             if ((double)s >= anchor_support) {
                 if (len[b] > best_len) { best_len = len[b]; best_sc = sc[b] + s; best_next = b; }
-                else if (len[b] == best_len && sc[b] + s > best_sc) { best_sc = sc[b] + s; best_next = b; }
+                else if (len[b] == best_len && (CW_CHAIN_TIE == CW_CHAIN_TIE_LARGEST_SUCCESSOR ? sc[b] + s >= best_sc : sc[b] + s > best_sc)) { best_sc = sc[b] + s; best_next = b; } /* cw_policy.h CW_CHAIN_TIE: on equal length and score the scan upward keeps the first (smallest) successor, or takes the later (largest) one */
             }
         }
         len[a] = best_len + 1; sc[a] = best_sc; nxt[a] = best_next;

@@ -129,6 +129,28 @@ def test_bench_gpus_2_spawns_two_ranks_without_a_launcher():
     assert j["value"] > 0 and "roofline" in j
 
 
+@pytest.mark.timeout(1500)
+def test_bench_gpus_8_runs_eight_ranks_and_the_driver_leg_on_one_box():
+    """The command the driver runs once on an 8-GPU node, here with all eight ranks on the one GPU of the box (CW_BENCH_SINGLE_DEVICE, gloo): rank 0's
+    native-driver leg first with `-j 8` while the seven other ranks wait in the rendezvous, then 8 x 3 engines side by side, one JSON line with
+    n_gpus 8, a driver_strong_scaling object without an error, three timed repetitions and their median."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CW_BENCH_SINGLE_DEVICE="1", CW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--windows", "1024", "--steps", "4", "--warmup", "3"],
+                         capture_output=True, text=True, env=env, timeout=1400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["engines_per_gpu"] == 3 and j["config"]["distinct_windows_per_run"] == 8 * 4 * 1024
+    assert j["reps"] == 3 and len(j["ms_per_step_reps"]) == 3 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    d = j["driver_strong_scaling"]
+    assert "error" not in d, d
+    assert d["n_gpus"] == 8 and d["windows"] > 100000 and d["windows_per_s"] > 0 and d["scaling"] == "strong"
+    assert "cpu_baseline" not in j  # rank 0 at N = 1 only
+
+
 def test_two_engines_take_batches_in_turn_and_cw_poll_tells_which_is_free():
     """Two engines on one GPU, each with a batch in flight on its own streams (what bench.py does): cw_poll never blocks, turns 1 once
     the batch is done, and every result equals the oracle's."""

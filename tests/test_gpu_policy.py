@@ -158,3 +158,23 @@ def test_affine_gap_model_is_implemented_on_both_sides(tmp_path):
     assert not mixed
     same_eq, digest_eq = run_child({"CONSENT_AMD_LIB": lin_lib})  # the affine engine with ext == open against the DEFAULT (linear) oracle
     assert same_eq and digest_eq == digest_default
+
+
+@pytest.mark.timeout(1500)
+def test_chain_tie_largest_successor_is_implemented_on_both_sides(tmp_path):
+    """-DCW_CHAIN_TIE=1 (cw_policy.h CW_CHAIN_TIE_LARGEST_SUCCESSOR, round 6): among successors of equal chain length and score the LAST one wins
+    (`>=` in the oracle's scan; the successor's index itself instead of its complement in the engine's chain keys, the last lane instead of the first
+    in the 32-bit window path).  The two sides agree window by window under it, the consensus differs from the default's on these piles (10 of the 136
+    windows in the oracle), and one side alone under the policy disagrees with the other."""
+    from consent_amd import _build
+
+    ct = ["-DCW_CHAIN_TIE=1"]
+    alt_lib = str(tmp_path / "libconsent_amd_ct.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *ct, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(ct)])
+    same_default, digest_default = run_child({})
+    same_ct, digest_ct = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_ct
+    assert digest_default != digest_ct
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed

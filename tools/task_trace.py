@@ -16,7 +16,7 @@ from consent_amd.engine import Batch, Result  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "pacbio_d150_msa150"
 depth, msa = (150, 150) if "150" in wl else (30, 20)
-n_win = 16384
+n_win = int(os.environ.get("CW_TRACE_WINDOWS", "16384"))
 eng = ca.Engine(ca.Params(9, 4, 8, 2, msa))
 lib = eng.lib
 dev = torch.device("cuda", 0)
