@@ -425,7 +425,7 @@ def main():
         "stage_ms_one_batch_in_flight": alone_avg,
     }
     stage_kernel = {"index": "cw_index_kernel", "chain": "cw_chain_kernel", "poa": "cw_poa_kernel", "poa_q": "cw_poa_q_kernel", "poa_h": "cw_poa_h_kernel", "poa_m1": "cw_poa_slab_kernel<256", "poa_m2": "cw_poa_slab_kernel<512",
-                    "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0>", "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
+                    "poa_large": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0, 1, 3>", "poa_lw": "cw_poa_slab_kernel<1536, 4096, 1023, 1, 3, 0, 4, 5>", "poa_overflow": "cw_poa_big_kernel", "finish": "cw_finish_kernel", "setup": "cw_setup_kernel"}
     traffic, traffic_step, traffic_src, prof_whole = None, None, None, None
     prof_json = os.path.join(ROOT, "profiles", f"latest_{args.workload}.json")
     if dom and os.path.exists(prof_json):

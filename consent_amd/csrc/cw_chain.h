@@ -27,6 +27,12 @@
 #define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
 #endif
 #define CW_CH_LIST_BYTES 1792
+#ifndef CW_POALW_MIN_MEAN
+#define CW_POALW_MIN_MEAN 160 /* tier LW takes the tier-L tasks whose mean member length is at least this (two or more chunks per row for most members) ... */
+#endif
+#ifndef CW_POALW_MIN_MEMBERS
+#define CW_POALW_MIN_MEMBERS 6 /* ... and that have at least this many members */
+#endif
 #define CW_CH_TILE_STRIDE 66u /* u16 per row of phase D's tile: 64 sequences + 2 (33 words: a column read by 64 lanes hits every bank twice) */
 
 /* the successor's index inside a chain key (length + 1 << 48 | score << 16 | this): the largest key wins, so the field is 0xFFFF - b when equal
@@ -348,6 +354,37 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                    in between, so the loads pipeline), then writes its own segment if it is trivial: empty, a prefix of its
                    left anchor (all pieces equal and no longer than k), or a single short piece.  The few segments that need
                    the whole wave -- POA tasks and long single pieces -- follow one by one. */
+#if CW_SEG_MISSING_ANCHOR == CW_SEG_MISSING_ANCHOR_EXTRAPOLATE
+                /* cw_policy.h CW_SEG_MISSING_ANCHOR_EXTRAPOLATE (a policy build, round 6): the chain anchors a sequence lacks get the position the template's
+                   spacing gives them, counted from the nearest chain anchor the sequence holds (the one before, else the one after), written into the
+                   block's position matrix in place -- everything below then cuts the segments as ever.  Lanes = sequences; the template (sequence 0)
+                   holds every anchor at its template position. */
+                {
+                    uint16_t* Pw = const_cast<uint16_t*>(P);
+                    for (uint32_t sb = 0; sb < N; sb += 64) {
+                        const uint32_t s = sb + (uint32_t)lane;
+                        const bool in = s < N;
+                        const int top = in ? (int)min(b.seq_len[s0 + s], 65534u) : 0;
+                        int last_p = -1, last_t = 0, first_i = -1, first_p = 0, first_t = 0;
+                        for (uint32_t i = 0; i < m; ++i) {
+                            const uint32_t a = chain[i];
+                            const int t_i = (int)P[a * Np];
+                            const uint32_t pv = in ? (uint32_t)P[a * Np + s] : (uint32_t)CW_NONE16;
+                            if (pv != CW_NONE16) { last_p = (int)pv; last_t = t_i; if (first_i < 0) { first_i = (int)i; first_p = (int)pv; first_t = t_i; } }
+                            else if (in && last_p >= 0) Pw[a * Np + s] = (uint16_t)min(top, last_p + (t_i - last_t));
+                        }
+                        const int lead = cw_wave_max(in ? first_i : -1); /* the longest run of leading anchors any lane has to fill */
+                        for (int i = 0; i < lead; ++i) {
+                            const uint32_t a = chain[i];
+                            const int t_i = (int)P[a * Np];
+                            if (in && i < first_i) Pw[a * Np + s] = (uint16_t)min(top, max(0, first_p - (first_t - t_i)));
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the rows are read back below by other lanes of this wave, through the vector cache */
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    cw_wave_sync();
+                }
+#endif
                 bool over = false, over_arena = false; /* (over_arena is wave-uniform: decided from wave-uniform totals) */
                 uint32_t q_cnt = 0;
                 unsigned long long t_flush = 0;
@@ -368,13 +405,16 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                     /* tier H (two tasks per wave, cw_poa_q.h): members of up to 63 bases, graph expected (depth-aware) to stay inside its 128 nodes */
                     const bool fits_h = sc.use_h != 0u && e_mx <= (uint32_t)CW_POAH_LC && e_mx >= sc.h_min_len && est_s <= (uint32_t)CW_POAH_ROUTE_NODES;
                     const bool fits_s = est_s <= sc.s_route_cells && e_mx <= (uint32_t)CW_POA_LC; /* s_route_cells: a node count since round 4 */
-                    const uint32_t tier = !poa ? 0xFFu
+                    uint32_t tier = !poa ? 0xFFu
                                           : (sc.use_q && e_mx <= (uint32_t)CW_POAQ_LC && est_s <= (uint32_t)CW_POAQ_ROUTE_NODES) ? 4u
                                           : (fits_h && (sc.use_h > 1u || !fits_s)) ? 5u
                                           : fits_s ? 0u
                                           : ((sc.m1_route_depth && est_s > est ? est_s : est) <= (uint32_t)CW_POAM1_ROUTE && e_mx <= (uint32_t)CW_POAM1_LC) ? 1u
                                           : (est <= (uint32_t)CW_POAM2_ROUTE && e_mx <= (uint32_t)CW_POAM2_LC) ? 2u
                                                                                             : 3u;
+                    /* tier LW (round 6, cw_poa_w.h): a tier-L task whose members are wide ON AVERAGE (several 128-column chunks per DP row) and many runs
+                       on the four waves of a work-group -- list 5, which the product build has free (tier H is a test aid; with it on, no tier LW) */
+                    if (tier == 3u && sc.use_lw && e_n >= (uint32_t)CW_POALW_MIN_MEMBERS && q_sl[lane] / e_n >= (uint32_t)CW_POALW_MIN_MEAN) tier = 5u;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long pm = __ballot(poa);
                     const unsigned long long tm1 = __ballot(tier == 1u), tm2 = __ballot(tier == 2u), tm3 = __ballot(tier == 3u), tmq = __ballot(tier == 4u), tmh = __ballot(tier == 5u);
@@ -452,7 +492,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                                         const uint32_t pa = g_ca >= 0 ? (uint32_t)P[(uint32_t)g_ca * Np + s] : 0u;
                                         const uint32_t pb = g_cb >= 0 ? (uint32_t)P[(uint32_t)g_cb * Np + s] : 0u;
                                         if (g_seg == 0) { is = pb != CW_NONE16 && pb > 0; st = 0; ln = pb; }
-                                        else if (g_seg == m) { is = pa != CW_NONE16; st = pa; ln = b.seq_len[s0 + s] - pa; }
+                                        else if (g_seg == m) { const uint32_t sl_ = b.seq_len[s0 + s]; is = pa != CW_NONE16 && pa < sl_; st = pa; ln = sl_ - pa; } /* (pa < length: always, unless the position is an extrapolated one) */
                                         else { is = pa != CW_NONE16 && pb != CW_NONE16 && pa < pb; st = pa; ln = pb - pa; }
                                     }
                                     const unsigned long long bal = __ballot(is);
@@ -528,7 +568,8 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                         }
                         cw_wave_sync();
                     }
-                    const bool by_anchor = n_mem > 0 && seg > 0 && seg < m && mn == mx && mx <= k; /* all pieces = first mx bases of anchor a */
+                    /* all pieces = first mx bases of anchor a (not under CW_SEG_MISSING_ANCHOR_EXTRAPOLATE: a piece may start where the anchor is only assumed to be) */
+                    const bool by_anchor = CW_SEG_MISSING_ANCHOR == CW_SEG_MISSING_ANCHOR_DROP && n_mem > 0 && seg > 0 && seg < m && mn == mx && mx <= k;
                     const bool single = n_mem == 1;
                     const uint32_t need = n_mem == 0 ? 0u : (by_anchor || single) ? mx : 2 * mx + 2;
                     const int inc = cw_wave_scan_add((int)need);

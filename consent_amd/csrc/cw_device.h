@@ -146,6 +146,7 @@ struct DevScratch {
                                       it is redone in tier L, late).  (Until round 3: a bound on the cells of its LDS matrix, hence the name.) */
     uint32_t m1_route_depth;       /* tier M1 is chosen with the depth-aware graph estimate too (deep piles of ~100-base members outgrow its 256 nodes) */
     uint32_t use_h;                /* 0 = no tier H; 1 = tier H takes what would go to tier M1 or further; 2 (default) = also what tier S would take (CW_TIER_H) */
+    uint32_t use_lw;               /* round 6: tier L's tasks whose members are wide on average go to list 5 and run on four waves each (tier LW, cw_poa_w.h); off while tier H uses that list */
     uint32_t h_min_len;            /* shortest "longest member" tier H takes (CW_H_MIN_LEN, default CW_POAH_MIN_LEN) */
     uint32_t linger_wgs;           /* tier-L work-groups that stay on the live overflow queue */
     uint32_t producer_wgs;         /* work-groups launched for tiers S + M1 + M2 (tier L's live queue waits for them) */

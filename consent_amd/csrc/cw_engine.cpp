@@ -27,7 +27,8 @@ namespace {
 static_assert(4 * CW_POA_WAVES * CW_POA_SLAB_BYTES <= 163840, "tier S: at least four work-groups per CU (five under the default policy)");
 static_assert(4 * CW_POAM1_WAVES * CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) <= 163840, "tier M1: four work-groups per CU");
 static_assert(4 * CW_POAM2_WAVES * CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) <= 163840 || CW_M2_CHAIN_TABS || CW_M2_CODES, "tier M2: four work-groups per CU");
-static_assert(CW_POAL_LDS_BYTES <= (CW_POAL_MW > 1 ? 61440 : 40960), "tier L: a work-group fits the hole an M1/M2 work-group leaves (one wave), or a third of a CU (several waves, cw_poa_w.h)");
+static_assert(CW_POAL_LDS_BYTES <= 40960, "tier L: a work-group fits the hole an M1/M2 work-group leaves");
+static_assert(!CW_POA_LW || CW_POALW_LDS_BYTES <= 61440, "tier LW (cw_poa_w.h): a four-wave work-group takes a third of a CU at most");
 static_assert(CW_IDX_STAGE_OFF + 16 + CW_IDX_STAGE_N * 8 + 4 * CW_IDX_STAGE_WORDS <= CW_IDX_LDS_BYTES, "index kernel: stage area inside the LDS allocation");
 
 static_assert(CW_FIN_CB_BIG == CW_CONS_SLOT_MAX, "the largest consensus slot (include/consent_amd.h CW_CONS_SLOT_BYTES, engine.py cons_slot_bytes) is what the finish kernel's second pass holds");
@@ -49,7 +50,7 @@ size_t big_slab_bytes() {
    CW_WGS_S / _M1 / _M2 / _L override (experiments). */
 struct TierMix { uint32_t s, m1, m2, l; };
 TierMix tier_mix(bool deep) {
-    TierMix m = deep ? TierMix{4, 5, 4, CW_POAL_MW > 1 ? 1u : 2u} : TierMix{4, 5, 4, CW_POAL_MW > 1 ? 1u : 2u}; /* (tier L, round 5: one four-wave work-group of 56 KB per CU instead of two one-wave ones of 37) */ /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
+    TierMix m = deep ? TierMix{4, 5, 4, 2u} : TierMix{4, 5, 4, 2u}; /* see DESIGN.md: no static mix was robustly better than this one (round 4: tier S's work-groups take 24 KB, not 45) */
     auto knob = [](const char* name, uint32_t dflt) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const int x = atoi(v); return x >= 1 && x <= 12 ? (uint32_t)x : dflt; };
     m.s = knob("CW_WGS_S", m.s); m.m1 = knob("CW_WGS_M1", m.m1); m.m2 = knob("CW_WGS_M2", m.m2); m.l = knob("CW_WGS_L", m.l);
     if (m.s > 6) m.s = 6;
@@ -68,6 +69,14 @@ uint32_t tier_wgs_cap(int t, uint32_t n_windows, uint32_t full) {
     return want < full ? (uint32_t)want : full;
 }
 
+/* work-groups of tier LW (round 6: four waves each, one wide tier-L task at a time): its tasks are few -- a handful per thousand windows of a read
+   set's piles, fewer in the synthetic ones -- and long: one work-group per CU at most */
+uint32_t lw_wgs_cap(uint32_t n_windows, uint32_t cus) {
+    if (!CW_POA_LW) return 0u;
+    const uint32_t want = n_windows / 32u + 8u;
+    return want < cus ? want : cus;
+}
+
 void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[CW_TIERS]) {
     /* slabs: one per wave the hardware can hold at once plus a margin; waves claim them (slot_busy) */
     const TierMix mix = tier_mix(false);
@@ -77,7 +86,7 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
     t[0] = {(tier_wgs_cap(0, n_windows, (uint32_t)cus * mix.s) * 2u + 8u) * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
     t[1] = {(tier_wgs_cap(1, n_windows, (uint32_t)cus * mix.m1) * 3u / 2u + 8u) * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
     t[2] = {(tier_wgs_cap(2, n_windows, (uint32_t)cus * mix.m2) * 3u / 2u + 8u) * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
-    t[3] = {(l_wgs * 3u / 2u + 8u) * CW_POAL_WAVES, CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)};
+    t[3] = {(l_wgs * 3u / 2u + 8u) * CW_POAL_WAVES + lw_wgs_cap(n_windows, (uint32_t)cus), CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)}; /* (+ tier LW's work-groups: they claim tier L's slabs) */
     const uint64_t bs = (uint64_t)n_windows / 16u + 8u;
     t[4] = {bs < big_slots ? (uint32_t)bs / 4u * 4u : big_slots, big_slab_bytes()};
     t[5] = {8u, 64u}; /* (tier H's slabs go by resident task, not by claim: ScratchPlan::hslab) */
@@ -203,6 +212,10 @@ int set_kernel_attributes(const hipDeviceProp_t& prop) {
                             CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             CW_POAL_LDS_BYTES) != hipSuccess ||
+#if CW_POA_LW
+        hipFuncSetAttribute((const void*)cw_poa_slab_kernel<CW_POAL_NC, CW_POAL_EC, CW_POAL_LC, CW_POAL_WAVES, 3, 0, CW_POAL_MW, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CW_POALW_LDS_BYTES) != hipSuccess ||
+#endif
         hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB, CW_FIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB * CW_FIN_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_finish_kernel<CW_FIN_CB_BIG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_FIN_SLAB_OF(0)) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_stitch_kernel<CW_ST_QMAX, CW_ST_RMAX, 16, CW_ST_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_st) != hipSuccess ||
@@ -262,7 +275,7 @@ int cw_create(const cw_params* params, int device, cw_engine** out) {
               hipEventCreateWithFlags(&e->ev_join_s, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->host_fb, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) memset(e->host_fb, 0, 64);
-    for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < CW_MAX_STAGES && ok; ++i) ok = hipEventCreate(&e->ev0[i]) == hipSuccess && hipEventCreate(&e->ev1[i]) == hipSuccess;
     for (int i = 0; i < CW_SLOTS && ok; ++i)
         ok = hipEventCreateWithFlags(&e->slot[i].ev_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->slot[i].ev_done, hipEventDisableTiming) == hipSuccess;
@@ -291,7 +304,7 @@ void cw_destroy(cw_engine* e) {
     if (e->stitch_scratch) (void)hipFree(e->stitch_scratch);
     if (e->host_fb) (void)hipHostFree(e->host_fb);
     for (int i = 0; i < CW_MAX_STAGES; ++i) { if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]); if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]); }
-    for (int i = 0; i < 3; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
+    for (int i = 0; i < 4; ++i) { if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join_s) (void)hipEventDestroy(e->ev_join_s);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
@@ -397,6 +410,11 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     sc.use_h = 0u; sc.h_min_len = CW_POAH_MIN_LEN;
     if (const char* env = CW_AID_ENV("CW_TIER_H")) { const int v = atoi(env); if (v >= 0 && v <= 2 && CW_Q_CODES) sc.use_h = (uint32_t)v; }
     if (const char* env = CW_AID_ENV("CW_H_MIN_LEN")) { const int v = atoi(env); if (v >= 1 && v <= CW_POAH_LC) sc.h_min_len = (uint32_t)v; }
+    /* tier LW (round 6): on unless tier H has list 5 (test-aid build) or CW_LW=0 (test aid: every tier-L task on one wave, as through round 5) */
+    sc.use_lw = CW_POA_LW && !sc.use_h ? 1u : 0u;
+    if (const char* env = CW_AID_ENV("CW_LW")) { if (atoi(env) == 0) sc.use_lw = 0u; }
+    if (CW_AID_ENV("CW_PHASES")) sc.use_lw = 0u; /* (the staged-launch experiment below has no tier LW) */
+    const uint32_t wgs_lw = sc.use_lw ? lw_wgs_cap(W_, (uint32_t)cus) : 0u;
     uint32_t wgs_h = 0;
     const uint32_t h_waves = 3; /* waves per tier-H work-group (two tasks per wave) */
     if (sc.use_h) {
@@ -430,7 +448,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     const size_t lds_m1 = CW_POA_HOT2C_BYTES(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC) * CW_POAM1_WAVES;
     const size_t lds_m2 = CW_POA_HOT2T_BYTES(2, CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC) * CW_POAM2_WAVES;
     const size_t lds_l = CW_POAL_LDS_BYTES;
-    const uint32_t thr_l = 64 * CW_POAL_WAVES * CW_POAL_MW; /* tier L: one task per work-group, its wide rows on CW_POAL_MW waves (cw_poa_w.h) */
+    const uint32_t thr_l = 64 * CW_POAL_WAVES;
     int sid;
     CW_HIP(hipEventRecord(e->ev_begin, st));
     CW_HIP(hipMemsetAsync(sc.ctr, 0, sizeof(BatchCounters), st));
@@ -507,7 +525,14 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
         stage_end(e, st, sid);
     } else {
     CW_HIP(hipEventRecord(e->ev_fork, st));
-    for (int i = 0; i < 3; ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
+    for (int i = 0; i < (wgs_lw ? 4 : 3); ++i) CW_HIP(hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
+#if CW_POA_LW
+    if (wgs_lw) { /* tier LW first: its tasks are the longest of the batch (four waves each; cw_poa_w.h) */
+        sid = stage_begin(e, e->side[3], "poa_lw");
+        cw_poa_slab_kernel<L_ARGS, 0, CW_POAL_MW, 5><<<wgs_lw, 64 * CW_POAL_MW, CW_POALW_LDS_BYTES, e->side[3]>>>(db, sc);
+        stage_end(e, e->side[3], sid);
+    }
+#endif
     /* tier L also consumes the live overflow queue; only sc.linger_wgs of its work-groups stay for that (far fewer than
        CUs, so they can never keep the producers they wait for off the machine) */
     sid = stage_begin(e, e->side[2], "poa_large");
@@ -539,7 +564,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     cw_poa_kernel<<<wgs_s, 64 * CW_POA_WAVES, CW_POA_SLAB_BYTES * CW_POA_WAVES, ms>>>(db, sc); /* 11.3 KiB per wave: three work-groups per CU */
     stage_end(e, ms, sid);
     if (ms != st) { CW_HIP(hipEventRecord(e->ev_join_s, ms)); CW_HIP(hipStreamWaitEvent(st, e->ev_join_s, 0)); }
-    for (int i = 0; i < 3; ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
+    for (int i = 0; i < (wgs_lw ? 4 : 3); ++i) { CW_HIP(hipEventRecord(e->ev_join[i], e->side[i])); CW_HIP(hipStreamWaitEvent(st, e->ev_join[i], 0)); }
     }
     /* pass 1: tasks that outgrew their tier (normally a handful) go straight to tier L, and from there to G */
     sid = stage_begin(e, st, "poa_overflow");

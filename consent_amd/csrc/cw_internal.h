@@ -51,8 +51,8 @@ struct cw_engine {
     size_t stitch_scratch_bytes = 0;
     uint32_t* host_fb = nullptr; /* pinned: [0] tasks the last finished batch handed to tier L (feeds linger_wgs), [1] its sequence number */
     /* per-stage timing of the last run */
-    hipStream_t side[3] = {nullptr, nullptr, nullptr}; /* POA tiers run concurrently on their own streams */
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr}, ev_join_s = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr}; /* POA tiers run concurrently on their own streams (M1, M2, L; round 6: LW) */
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join_s = nullptr;
     hipEvent_t ev0[CW_MAX_STAGES] = {}, ev1[CW_MAX_STAGES] = {}; /* start/stop per stage, recorded on the stage's stream */
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int n_stages = 0;

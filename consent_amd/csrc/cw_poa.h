@@ -607,10 +607,13 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
 }
 
 #include "cw_poa_c.h"
-#ifndef CW_POAL_MW
-#define CW_POAL_MW 1 /* waves of a tier-L work-group: 1 = one wave per task; 4 = cw_poa_w.h's pipeline, bit-identical and measured NOT faster (see that file) */
+#ifndef CW_POA_LW
+#define CW_POA_LW (!CW_POA_SW) /* round 6, tier "LW": tier-L tasks whose members are wide on average run on the four waves of a work-group (cw_poa_w.h; a second
+                                  instance of the tier-L kernel on its own list and stream); 0 = every tier-L task on one wave, as through round 5
+                                  (tests/test_gpu_variants.py; the local alignment mode has no multi-wave fill) */
 #endif
-#if CW_POAL_MW > 1 /* tier L on several waves: a build variant (-DCW_POAL_MW=4, tests/test_gpu_variants.py); the default build does not carry it */
+#define CW_POAL_MW 4 /* waves of such a work-group */
+#if CW_POA_LW
 #include "cw_poa_w.h"
 #else
 #define CW_POA_COMM_BYTES 0
@@ -883,7 +886,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                 }
             }
             else if (cols <= 128) poa_fill_pk<1, PK == 2>(M, n, cols, hs, lane, use_dirs);
-#if CW_POAL_MW > 1
+#if CW_POA_LW
             else if (PK == 2 && M.comm != nullptr) { if constexpr (PK == 2 && sizeof(HT) == 2) poa_fill_mw<true>(M, n, cols, hs, lane, use_dirs); } /* tier L: the chunks of the row on the waves of the work-group (cw_poa_w.h) */
 #endif
             else if constexpr (LCAP > 127) {
@@ -1464,17 +1467,19 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
 /* ---- tiers M1 / M2 / L: graph in LDS, DP matrix in this wave's global slab ------------------------ */
 /* PASS 0 works through the tasks the index kernel routed to this tier (all tiers run concurrently on their own
    streams); tier L additionally drains the live overflow queue.  PASS 1 (tier L only, after the join) takes what is left. */
-#define CW_POAL_LDS_BYTES (CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES + (CW_POAL_MW > 1 ? CW_POA_COMM_BYTES : 0)) /* tier L's work-group */
-template <int NC, int EC, int LC, int WAVES, int TIER, int PASS>
-__global__ void __launch_bounds__(64 * WAVES * (TIER == 3 ? CW_POAL_MW : 1), TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1 and M2: four waves per SIMD (128 VGPRs; M1 at five spilled 17 VGPRs, round 6) */
+#define CW_POAL_LDS_BYTES (CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) * CW_POAL_WAVES) /* tier L's work-group */
+#define CW_POALW_LDS_BYTES (CW_POA_HOT2L_BYTES(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC) + CW_POA_COMM_BYTES) /* ... and the four-wave one's (tier LW: one task) */
+/* MW > 1 (tier LW, TIER = 3): ONE task per work-group of MW waves -- wave 0 is "the" wave of the code below, the others serve its FILL commands
+   (cw_poa_w.h) and share its LDS arrays; LIST: the routed list the kernel works through (tier LW: list 5, which the product build has free) */
+template <int NC, int EC, int LC, int WAVES, int TIER, int PASS, int MW = 1, int LIST = TIER>
+__global__ void __launch_bounds__(64 * WAVES * MW, TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1 and M2: four waves per SIMD (128 VGPRs; M1 at five spilled 17 VGPRs, round 6) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
-    /* tier L (round 5, cw_poa_w.h): ONE task per work-group, its wide rows on CW_POAL_MW waves -- wave 0 is "the" wave of the code below, the
-       others (mw_helper) serve its FILL commands and share its LDS arrays */
-    const int mw_wave = (TIER == 3 && CW_POAL_MW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const int wave = (TIER == 3 && CW_POAL_MW > 1) ? 0 : (int)(threadIdx.x >> 6);
-    PoaComm* const comm = (TIER == 3 && CW_POAL_MW > 1) ? (PoaComm*)(lds + CW_POA_HOT2L_BYTES(NC, EC, LC) * WAVES) : nullptr;
+    static_assert(MW == 1 || (TIER == 3 && WAVES == 1 && MW == CW_POAL_MW && CW_POA_LW), "several waves per task: tier L's wide tasks only");
+    const int mw_wave = MW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wave = MW > 1 ? 0 : (int)(threadIdx.x >> 6);
+    PoaComm* const comm = MW > 1 ? (PoaComm*)(lds + CW_POA_HOT2L_BYTES(NC, EC, LC) * WAVES) : nullptr;
     /* Yielding persistence.  The four tier kernels run side by side and share each CU's LDS; a work-group that loops until its tier's
        list is empty keeps its LDS for the whole stage, so whichever kernel reaches a CU first owns it (measured: tier S held every CU
        for 27 ms of a depth-150 batch while the long tasks of tier L had not started).  Here only the LAST persist_wgs work-groups of
@@ -1491,15 +1496,15 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
             s = s + 1u == n_slots ? 0u : s + 1u;
         }
         gw = s;
-#if CW_POAL_MW > 1
-        if (comm) { comm->slab = s; comm->seq = 0u; comm->cmd = 0u; for (int x = 0; x < CW_POAL_MW; ++x) { comm->done[x] = 0u; comm->ready[x] = 0u; } }
+#if CW_POA_LW
+        if constexpr (MW > 1) { comm->slab = s; comm->seq = 0u; comm->cmd = 0u; for (int x = 0; x < CW_POAL_MW; ++x) { comm->done[x] = 0u; comm->ready[x] = 0u; } }
 #endif
     }
-#if CW_POAL_MW > 1
-    if (comm) { __syncthreads(); if (lane == 0) gw = comm->slab; } /* (the one barrier of the kernel: the helpers learn the slab) */
+#if CW_POA_LW
+    if constexpr (MW > 1) { __syncthreads(); if (lane == 0) gw = comm->slab; } /* (the one barrier of the kernel: the helpers learn the slab) */
 #endif
     gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)gw);
-    const bool yields = PASS == 0 && blockIdx.x + sc.persist_wgs[TIER] < gridDim.x;
+    const bool yields = PASS == 0 && MW == 1 && blockIdx.x + sc.persist_wgs[TIER] < gridDim.x; /* (the few work-groups of tier LW stay until their list is empty) */
     /* the slab is global memory: say so, or every access to the DP matrix is a flat_* instruction (both wait counters, aperture check) */
     typedef __attribute__((address_space(1))) uint8_t* cw_gptr;
     uint8_t* my_slab = (uint8_t*)(cw_gptr)(sc.slab[TIER] + (size_t)gw * sc.slab_bytes[TIER]);
@@ -1524,8 +1529,8 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     /* the large tiers have few, long tasks and share their SIMDs with up to three waves of the small tiers: let them issue first,
        or tier L is still running long after the others have finished (depth 150) */
     if (TIER == 3) __builtin_amdgcn_s_setprio(3);
-#if CW_POAL_MW > 1
-    if constexpr (TIER == 3) {
+#if CW_POA_LW
+    if constexpr (MW > 1) {
         if (mw_wave > 0) { poa_mw_serve<true>(M, lane, mw_wave); return; } /* until wave 0 posts EXIT */
     }
 #endif
@@ -1545,26 +1550,26 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
         acc[5] = _t1 - _t0 > acc[5] ? _t1 - _t0 : acc[5];
         if (lane == 0 && sc.task_dbg) { /* inspection aid (CW_TASK_TRACE): when each task of the slab tiers ran (10 ns units since the tier sort), where, and how it ended */
             uint4 d;
-            d.x = (uint32_t)(_w0 - sc.ctr->prof[41]); d.y = (uint32_t)(wall_clock64() - _w0); d.z = (uint32_t)TIER | ((uint32_t)rc << 8) | ((uint32_t)PASS << 16); d.w = gw;
+            d.x = (uint32_t)(_w0 - sc.ctr->prof[41]); d.y = (uint32_t)(wall_clock64() - _w0); d.z = (uint32_t)TIER | ((uint32_t)rc << 8) | ((uint32_t)PASS << 16) | (MW > 1 ? 1u << 24 : 0u); d.w = gw;
             sc.task_dbg[ti] = d;
         }
         if (lane == 0) poa_hand_over(sc, t, ti, rc, TIER < 3 ? 3 : 4);
         cw_wave_sync();
     };
     if (PASS == 0) {
-        const uint32_t* list = sc.tier_list[TIER];
-        const uint32_t n_work = min(sc.ctr->n_tier[TIER], sc.list_cap);
+        const uint32_t* list = sc.tier_list[LIST];
+        const uint32_t n_work = min(sc.ctr->n_tier[LIST], sc.list_cap);
         uint32_t ran = 0;
         for (;;) {
             uint32_t mi = 0;
-            if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER], 1u);
+            if (lane == 0) mi = atomicAdd(&sc.ctr->next_tier[LIST], 1u);
             mi = (uint32_t)__shfl((int)mi, 0);
             if (mi >= n_work) break;
             run_task(list[mi]);
             if (yields && ++ran >= (TIER == 1 ? CW_POA_CHUNK_M1 : 1u)) break;
         }
     }
-    if (TIER == 3 && !yields && (PASS == 1 || gridDim.x - 1u - blockIdx.x < sc.linger_wgs)) {
+    if (TIER == 3 && MW == 1 && !yields && (PASS == 1 || gridDim.x - 1u - blockIdx.x < sc.linger_wgs)) {
         /* Live queue (only the last few work-groups of the grid stay for it: a lingering tier-L work-group holds 37 KB of LDS that
            the other tiers could use): tasks that outgrow tiers S/M1/M2 while those kernels are still running on their own streams are
            picked up here at once instead of waiting for a later pass.  An entry is its own flag (0xFFFFFFFF = not yet
@@ -1605,8 +1610,8 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     } else if (PASS == 1) {
         /* not used for tiers below L */
     }
-#if CW_POAL_MW > 1
-    if (comm) { /* the helpers leave */
+#if CW_POA_LW
+    if constexpr (MW > 1) { /* the helpers leave */
         if (lane == 0) comm->cmd = CW_MW_CMD_EXIT;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) cww_store(&comm->seq, cww_load(&comm->seq) + 1u);
@@ -1669,6 +1674,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
     extern __shared__ __attribute__((aligned(16))) uint8_t cls_lds[]; /* lds_cls bytes (<= CW_SORT_LDS_CLS) */
     const int tier = blockIdx.x == 3 ? 0 : blockIdx.x == 4 ? 5 : 1 + (int)blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63; /* 0 = tier Q's list, 5 = tier H's */
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.ctr->prof[41] = wall_clock64(); /* time base of the task trace */
+    const int cls_tier = tier == 5 && sc.use_lw ? 3 : tier; /* list 5 holds tier L's wide tasks (tier LW): ordered like tier L's */
     const uint32_t n = min(sc.ctr->n_tier[tier], sc.list_cap);
     const uint32_t nthr = blockDim.x, nwv = nthr >> 6; /* 4 .. 16 waves: a small work-group finds room beside another batch's persistent kernels */
     uint32_t* list = sc.tier_list[tier];
@@ -1689,7 +1695,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
         for (int j = 0; j < 8; ++j) {
             const uint32_t x = x0 + (uint32_t)j * 64u + (uint32_t)lane;
             if (ti[j] != 0xFFFFFFFFu) {
-                const uint32_t c = cw_sort_class(nm[j].x, nm[j].y, tier);
+                const uint32_t c = cw_sort_class(nm[j].x, nm[j].y, cls_tier);
                 atomicAdd(&cnt[wave][c], 1u);
                 if (x < lds_cls) cls_lds[x] = (uint8_t)c;
             }
@@ -1714,7 +1720,7 @@ __global__ void __launch_bounds__(1024) cw_sort_tier_kernel(DevScratch sc, uint3
             if (ti[j] != 0xFFFFFFFFu) {
                 uint32_t c;
                 if (x < lds_cls) c = cls_lds[x];
-                else { const uint2 v = *(const uint2*)&sc.tasks[ti[j]].n_members; c = cw_sort_class(v.x, v.y, tier); }
+                else { const uint2 v = *(const uint2*)&sc.tasks[ti[j]].n_members; c = cw_sort_class(v.x, v.y, cls_tier); }
                 tmp[atomicAdd(&cnt[wave][c], 1u)] = ti[j];
             }
         }

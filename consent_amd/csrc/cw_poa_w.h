@@ -19,18 +19,14 @@
 #ifndef CW_POA_W_H
 #define CW_POA_W_H
 
-#ifndef CW_POAL_MW
-#define CW_POAL_MW 1 /* waves of a tier-L work-group.  1 = one wave per task (the default); 4 = this file's pipeline (-DCW_POAL_MW=4, tests/test_gpu_variants.py).
-                        MEASURED (round 5, same box, depth 150): bit-identical and NOT faster -- tier L's kernel 45 -> 72 ms with one four-wave work-group per CU
-                        in place of two one-wave ones, its fill's wave-cycles unchanged (16.2 G), because tier L's rows are NARROW: a -DCW_DIAG batch counts 25.3 M
-                        rows of members of at most 63 bases against 0.5 M rows of wider ones.  Its tasks are the ragged first and last segments of a window: one
-                        long member that makes the graph (500-1500 nodes), then dozens of short pieces aligned globally against all of it -- tall, one chunk
-                        wide, and the rows of a member depend on one another.  There is nothing to spread over waves.  (What the run did show: with half as
-                        many priority-3 waves of tier L on the machine, tiers S / M1 / M2 ran 28 -> 20, 41 -> 28, 35 -> 31 ms.) */
-#endif
-#if CW_POAL_MW > 1 && CW_POA_SW
-#error "cw_poa_w.h: the multi-wave fill of tier L has no local alignment mode (build it with CW_POAL_MW=1)"
-#endif
+/* CW_POAL_MW (cw_poa.h): waves of such a work-group, 4.  Round 5 ran EVERY tier-L task this way (one four-wave work-group per CU in place of two one-wave
+   ones) and measured it bit-identical and not faster: tier L's kernel 45 -> 72 ms, its fill's wave-cycles unchanged, because most of tier L's rows are
+   NARROW -- a -DCW_DIAG batch counts 25.3 M rows of members of at most 63 bases against 0.5 M rows of wider ones: the ragged first and last segments
+   of a window are one long member that makes the graph, then dozens of short pieces aligned against all of it.  Round 6 (tier "LW"): only the tasks
+   whose MEMBERS are wide on average come here (cw_chain.h routes them to their own list, a second instance of the tier-L kernel with four waves
+   takes it on its own stream): they are few -- and they are the stragglers: one wave issues a vector instruction every four cycles at best, a
+   25-member task of 400-base members against 1000 nodes ran for 26 ms on it while the rest of tier L was done in 15
+   (tools/task_trace.py), and in the native driver, whose piles have more of them, tier L's kernel was the longest of a job (27.6 ms). */
 #define CW_MW_CMD_FILL 1u
 #define CW_MW_CMD_EXIT 2u
 

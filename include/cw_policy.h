@@ -102,13 +102,16 @@
 #ifndef CW_CHAIN_TIE
 #define CW_CHAIN_TIE CW_CHAIN_TIE_SMALLEST_SUCCESSOR
 #endif
-#define CW_SEG_MISSING_ANCHOR_DROP 0 /* a sequence lacking an anchor of a segment is left out of that segment (implemented) */
-#define CW_SEG_MISSING_ANCHOR_EXTRAPOLATE 1
+#define CW_SEG_MISSING_ANCHOR_DROP 0 /* a sequence lacking an anchor of a segment is left out of that segment */
+#define CW_SEG_MISSING_ANCHOR_EXTRAPOLATE 1 /* both sides since round 6: an anchor of the chain that a sequence lacks is placed where the TEMPLATE's spacing puts it,
+                                               counted from the nearest chain anchor the sequence does hold -- the one before it, else the one after: q_i = p_j + (t_i - t_j),
+                                               t = the anchors' template positions -- inside [0, min(length, 65534)]; then the segments are cut as under DROP with q for
+                                               p (a piece whose ends come out reversed or equal is left out; a sequence holding no chain anchor stays out of everything) */
 #ifndef CW_SEG_MISSING_ANCHOR
 #define CW_SEG_MISSING_ANCHOR CW_SEG_MISSING_ANCHOR_DROP
 #endif
 #if (CW_POA_MODE != CW_POA_MODE_NW && CW_POA_MODE != CW_POA_MODE_OV && CW_POA_MODE != CW_POA_MODE_SW) || (CW_POA_CONSENSUS != CW_POA_CONSENSUS_MAJORITY && CW_POA_CONSENSUS != CW_POA_CONSENSUS_HEAVIEST_BUNDLE) || \
-    (CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR && CW_CHAIN_TIE != CW_CHAIN_TIE_LARGEST_SUCCESSOR) || CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP
+    (CW_CHAIN_TIE != CW_CHAIN_TIE_SMALLEST_SUCCESSOR && CW_CHAIN_TIE != CW_CHAIN_TIE_LARGEST_SUCCESSOR) || (CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_DROP && CW_SEG_MISSING_ANCHOR != CW_SEG_MISSING_ANCHOR_EXTRAPOLATE)
 #error "cw_policy.h: this value of CW_POA_MODE / CW_POA_CONSENSUS / CW_CHAIN_TIE / CW_SEG_MISSING_ANCHOR is named but not implemented (oracle/cw_oracle.cpp and consent_amd/csrc/ would both have to change)"
 #endif
 /* the column vote, one place for both sides: drop the column? / take the template's base on a tie? */

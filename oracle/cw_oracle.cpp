@@ -641,21 +641,38 @@ bool segmented_poa(const std::vector<std::string>& pile, unsigned k, double anch
     };
     const size_t m = chain.size();
     consensus.clear();
+    /* cw_policy.h CW_SEG_MISSING_ANCHOR: where sequence s holds chain anchor i, or -1.  Under EXTRAPOLATE an anchor the sequence lacks is placed
+       where the template's spacing puts it, counted from the nearest anchor the sequence does hold (the one before it, else the one after),
+       inside [0, min(length, 65534)]; a sequence that holds no chain anchor at all stays out of every segment. */
+    std::vector<std::vector<int32_t>> qpos(pile.size(), std::vector<int32_t>(m, -1));
+    for (uint32_t s = 0; s < pile.size(); ++s) {
+        for (size_t i = 0; i < m; ++i) qpos[s][i] = pos_in(chain[i], s);
+#if CW_SEG_MISSING_ANCHOR == CW_SEG_MISSING_ANCHOR_EXTRAPOLATE
+        const int32_t top = (int32_t)std::min<size_t>(pile[s].size(), 65534);
+        std::vector<int32_t> held = qpos[s];
+        int last = -1, first = -1;
+        for (size_t i = 0; i < m; ++i) {
+            if (held[i] != -1) { last = (int)i; if (first == -1) first = (int)i; }
+            else if (last != -1) qpos[s][i] = std::min(top, held[last] + (pos_in(chain[i], 0) - pos_in(chain[last], 0)));
+        }
+        for (int i = 0; i < first; ++i) qpos[s][i] = std::min(top, std::max(0, held[first] - (pos_in(chain[first], 0) - pos_in(chain[i], 0))));
+#endif
+    }
     for (size_t seg = 0; seg <= m; ++seg) {
         std::vector<std::string> members;
         for (uint32_t s = 0; s < pile.size() && members.size() < max_msa; ++s) {
             const std::string& r = pile[s];
             std::string piece;
             if (seg == 0) {
-                int32_t p = pos_in(chain[0], s);
+                int32_t p = qpos[s][0];
                 if (p == -1) continue;
                 piece = r.substr(0, (size_t)p);
             } else if (seg == m) {
-                int32_t p = pos_in(chain[m - 1], s);
+                int32_t p = qpos[s][m - 1];
                 if (p == -1) continue;
                 piece = r.substr((size_t)p);
             } else {
-                int32_t p1 = pos_in(chain[seg - 1], s), p2 = pos_in(chain[seg], s);
+                int32_t p1 = qpos[s][seg - 1], p2 = qpos[s][seg];
                 if (p1 == -1 || p2 == -1 || p1 >= p2) continue;
                 piece = r.substr((size_t)p1, (size_t)(p2 - p1));
             }

@@ -178,3 +178,24 @@ def test_chain_tie_largest_successor_is_implemented_on_both_sides(tmp_path):
     assert digest_default != digest_ct
     mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     assert not mixed
+
+
+@pytest.mark.timeout(1800)
+def test_missing_anchor_extrapolation_is_implemented_on_both_sides(tmp_path):
+    """-DCW_SEG_MISSING_ANCHOR=1 (cw_policy.h CW_SEG_MISSING_ANCHOR_EXTRAPOLATE, round 6): a chain anchor that a sequence lacks is placed where the
+    template's spacing puts it, counted from the nearest chain anchor the sequence holds; the segments are then cut as ever.  Oracle: per-sequence
+    position table; engine: the chain kernel fills the block's position matrix in place before it cuts the segments (and drops the
+    equal-pieces shortcut, which rests on every member holding the left anchor).  The two sides agree window by window, every consensus differs from
+    the default policy's (far more members per segment), and one side alone under the policy disagrees with the other."""
+    from consent_amd import _build
+
+    ex = ["-DCW_SEG_MISSING_ANCHOR=1"]
+    alt_lib = str(tmp_path / "libconsent_amd_ex.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *ex, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(ex)])
+    same_default, digest_default = run_child({})
+    same_ex, digest_ex = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_ex
+    assert digest_default != digest_ex
+    mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
+    assert not mixed

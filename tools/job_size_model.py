@@ -46,6 +46,32 @@ if os.environ.get("JSM_MODE") == "parts":
         print(json.dumps({"set": "x1 / %d" % n, "windows": int(st.windows), "jobs": int(st.jobs), "s_total": st.ms_total / 1e3, "s_index": st.ms_index / 1e3,
                           "modelled_T_N": t_n, "speed_up_over_one_gpu": full.ms_total / 1e3 / t_n}), flush=True)
     sys.exit(0)
+if os.environ.get("JSM_MODE") == "sweep":
+    # Round 6: what one of N GPUs sees of the x1 set (a set of 1/N of the genome), under every (workers per device, windows per job) the driver could
+    # choose -- the table its own choice (cw_driver.cpp: workers by windows per device, eight jobs per device) is checked against.
+    full = run(fa, paf, None, 0)
+    print(json.dumps({"set": "x1", "windows": int(full.windows), "jobs": int(full.jobs), "s_total": full.ms_total / 1e3, "s_index": full.ms_index / 1e3}), flush=True)
+    for n in [int(x) for x in os.environ.get("JSM_PARTS", "8,4").split(",")]:
+        dn = os.path.join(d, "part%d" % n)
+        os.makedirs(dn, exist_ok=True)
+        fa_n, paf_n, _, _, _ = pb.generate(dn, 4600000 // n, 30, "ont")
+        os.environ.pop("CW_WORKERS_PER_DEVICE", None)
+        st = run(fa_n, paf_n, None, 0)
+        t_n = full.ms_index / 1e3 + (st.ms_total - st.ms_index) / 1e3
+        print(json.dumps({"set": "x1 / %d" % n, "choice": "driver's own", "windows": int(st.windows), "jobs": int(st.jobs), "s_after_index": (st.ms_total - st.ms_index) / 1e3,
+                          "modelled_T_N": t_n, "speed_up_over_one_gpu": full.ms_total / 1e3 / t_n}), flush=True)
+        for workers in (2, 3, 4, 6, 8):
+            for jobs_per_dev in (2, 3, 4, 6, 8, 12):
+                per_job = max(1024, int(st.windows) // jobs_per_dev + 1)
+                if jobs_per_dev < workers // 2:
+                    continue
+                os.environ["CW_WORKERS_PER_DEVICE"] = str(workers)
+                s2 = run(fa_n, paf_n, None, per_job)
+                t2 = full.ms_index / 1e3 + (s2.ms_total - s2.ms_index) / 1e3
+                print(json.dumps({"set": "x1 / %d" % n, "workers": workers, "windows_per_job": per_job, "jobs": int(s2.jobs), "s_after_index": round((s2.ms_total - s2.ms_index) / 1e3, 4),
+                                  "modelled_T_N": round(t2, 4), "speed_up_over_one_gpu": round(full.ms_total / 1e3 / t2, 3)}), flush=True)
+        os.environ.pop("CW_WORKERS_PER_DEVICE", None)
+    sys.exit(0)
 rows = []
 n_workers = int(os.environ.get("JSM_WORKERS", "2"))  # workers (engines) on device 0
 sizes = [int(x) for x in os.environ.get("JSM_SIZES", "32768,20000,10000,5000,4096").split(",")]

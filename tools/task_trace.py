@@ -49,6 +49,7 @@ mean_len = a[:, 4] >> 16
 a[:, 4] &= 0xFFFF
 tier = a[:, 10] & 0xFF
 rc = (a[:, 10] >> 8) & 0xFF
+lw = (a[:, 10] >> 24) & 1  # ran in tier LW (four waves per task, cw_poa_w.h)
 start, dur = a[:, 8] * 1e-5, a[:, 9] * 1e-5  # ms
 for tr, name in ((1, "M1"), (2, "M2"), (3, "L")):
     m = (tier == tr) & (dur > 0)
@@ -64,6 +65,13 @@ for tr, name in ((1, "M1"), (2, "M2"), (3, "L")):
     edges = np.linspace(0, end.max(), 11)
     occ = [int(((start[m] < e) & (start[m] + dur[m] > e)).sum()) for e in edges[1:-1]]
     print("    running at 10%..90% of the tier's span:", occ)
+m_lw = (tier == 3) & (lw == 1) & (dur > 0)
+if m_lw.any():
+    print(f"tier LW (part of tier L above): {int(m_lw.sum())} task runs, busy {dur[m_lw].sum():.0f} work-group-ms, last end {(start[m_lw] + dur[m_lw]).max():.2f} ms, longest {dur[m_lw].max():.2f} ms; mean member length 10/50/90: {np.percentile(mean_len[m_lw], [10, 50, 90])}")
+m_l1 = (tier == 3) & (lw == 0) & (dur > 0)
+if m_l1.any():
+    wide = m_l1 & (mean_len >= 100)
+    print(f"tier L on one wave: {int(m_l1.sum())} task runs, longest {dur[m_l1].max():.2f} ms; of them with mean member length >= 100: {int(wide.sum())}, busy {dur[wide].sum():.0f} wave-ms, longest {dur[wide].max() if wide.any() else 0:.2f} ms")
 s_m = tier == 0
 print(f"tier S: {int(s_m.sum())} tasks; max_len percentiles 10/50/90/99: {np.percentile(a[s_m, 4], [10, 50, 90, 99])}; members 10/50/90/99: {np.percentile(a[s_m, 3], [10, 50, 90, 99])}")
 ml, nm = a[s_m, 4].astype(np.int64), a[s_m, 3].astype(np.int64)
