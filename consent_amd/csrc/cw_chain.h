@@ -24,8 +24,9 @@
 
 #define CW_CH_WAVES 4
 #ifndef CW_CH_SLAB
-#define CW_CH_SLAB 20480 /* bytes of LDS per wave: 16 B per candidate (<= 1024) + the pending list + what fits of the bitsets */
+#define CW_CH_SLAB 20480 /* bytes of LDS per wave: 12 B per anchor + phase D's tile + the pending list + what fits of the bitsets: up to 1230 anchors */
 #endif
+#define CW_CH_SLAB_LONG 32768 /* ... of the instance an engine configured for long templates launches (cw_configure; round 6): up to CW_TMAX anchors, one work-group per CU */
 #define CW_CH_LIST_BYTES 1792
 #ifndef CW_POALW_MIN_MEAN
 #define CW_POALW_MIN_MEAN 160 /* tier LW takes the tier-L tasks whose mean member length is at least this (two or more chunks per row for most members) ... */
@@ -41,10 +42,11 @@
 __device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t ch_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+template <int SLAB>
 __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, DevScratch sc, cw_params prm) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* slab = lds + (size_t)wave * CW_CH_SLAB;
+    uint8_t* slab = lds + (size_t)wave * SLAB;
     const uint32_t k = prm.k;
 
     for (;;) {
@@ -59,7 +61,16 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
         uint32_t why = 0;
         uint32_t n_segs_out = 0, arena_used = 0;
         CW_PROF_T0();
+        /* more anchors than this instance's slab holds (a template beyond ~1240 bases in an engine that was not configured for long templates, cw_configure):
+           12 bytes per anchor, and phase D's tile behind the first 8 of them */
+        bool fits_slab = true;
         if (ready) {
+            const uint32_t A0 = ch_uni(((const uint32_t*)(sc.ablock + ((size_t)ch_uni(wi->ab_base) << 4)))[0]);
+            const uint32_t oc = (8u * A0 + 2u + 3u) & ~3u, ov = (oc + 4u * A0 + 7u) & ~7u;
+            fits_slab = ov <= (uint32_t)(SLAB - CW_CH_LIST_BYTES) && oc + 65u * CW_CH_TILE_STRIDE * 2u + 4u + 256u <= (uint32_t)(SLAB - CW_CH_LIST_BYTES);
+            if (!fits_slab) { new_status = CW_WIN_OVERFLOW; why = CW_WHY_ANCHORS; }
+        }
+        if (ready && fits_slab) {
             const uint32_t s0 = ch_uni(b.win_first_seq[w]);
             const uint8_t* blk = sc.ablock + ((size_t)ch_uni(wi->ab_base) << 4);
             const uint32_t* hdr = (const uint32_t*)blk;
@@ -93,7 +104,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             int32_t* csc = (int32_t*)(slab + off_csc);         /* A     */
             uint8_t* var = slab + off_var;
             /* the last CW_CH_LIST_BYTES of the slab: segments waiting for the whole wave (phase D), 64 entries */
-            uint32_t* q_off = (uint32_t*)(slab + CW_CH_SLAB - CW_CH_LIST_BYTES);   /* arena offset            */
+            uint32_t* q_off = (uint32_t*)(slab + SLAB - CW_CH_LIST_BYTES);   /* arena offset            */
             uint32_t* q_need = q_off + 64;                                           /* arena bytes reserved    */
             uint16_t* q_seg = (uint16_t*)(q_need + 64);
             int16_t* q_ca = (int16_t*)(q_seg + 64);
@@ -103,7 +114,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
             uint16_t* q_fs = q_mx + 64;
             uint16_t* q_fst = q_fs + 64;
             uint32_t* q_sl = (uint32_t*)(q_fst + 64);                               /* sum of the members' lengths */
-            const size_t var_room = (size_t)(CW_CH_SLAB - CW_CH_LIST_BYTES) - off_var;
+            const size_t var_room = (size_t)(SLAB - CW_CH_LIST_BYTES) - off_var;
             /* behind the presence bitsets: the correction rows (row ids + rows) when the block has them and they fit */
             const size_t pres_only = use_bits ? (size_t)A * Nw * 8 : 0;
             const size_t delta_bytes = (size_t)Ap + (size_t)n_rows * Ap;

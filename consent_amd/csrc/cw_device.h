@@ -54,6 +54,7 @@ struct WinInfo {
 #define CW_WHY_FIN_POLISH 11/* the polish outgrew a buffer                                           */
 #define CW_WHY_OUT_CONS 12  /* the caller's consensus slot is too small                              */
 #define CW_WHY_OUT_SOLID 13 /* the caller's solid slot is too small                                  */
+#define CW_WHY_ANCHORS 15   /* more anchors than the chain kernel's slab holds: an engine that was not configured for long templates (cw_configure) */
 #define CW_WHY_ARENA 14     /* the window's slice of the segment arena (round 6: told apart from CW_WHY_TASKS -- a plan whose arena scale is
                                already clamped cannot cure it, and re-running the batch three times for nothing was ADVICE r05's finding)  */
 

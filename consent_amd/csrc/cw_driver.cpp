@@ -151,6 +151,7 @@ struct Worker {
         cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
         rc = cw_create(&prm, phys, &eng);
         if (rc != CW_OK) return rc;
+        if (a.window_size > 1024u + a.mer_size - 1u && (rc = cw_configure(eng, a.window_size)) != CW_OK) return rc; /* templates are windows: at most window_size bases */
         if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
         if (owner) {
             if ((rc = reads_of_owner.get()) != CW_OK) return rc;
@@ -575,7 +576,13 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
     if (!a->windows_per_batch) {
         const uint64_t est_windows = tpl_bases / (a->window_size - a->window_overlap) + 1;
-        const uint64_t want = est_windows / (8ull * n_distinct_devs) + 1; /* eight jobs per device: four per worker with two workers, two with four */
+        /* jobs per device.  Eight (four per worker with two workers) while a device gets 1e5 windows or more; FOUR below that (round 6): a device that gets
+           4e4 windows -- the E. coli-scale set on eight GPUs -- ran its nine jobs of 5 200 windows on four workers in 0.234 s, and four jobs of 10 400 on the
+           same four workers in 0.134 s (two jobs of 20 800 on two: 0.138; tools/job_size_model.py JSM_MODE=sweep, profiles/r06_job_size_sweep.txt): a job's
+           fixed costs -- its longest POA task, its longest read, its launches and synchronisation points -- are paid once per job and worker, and small
+           jobs do not fill the GPU while they are paid */
+        const uint64_t jobs_per_dev = est_windows / n_distinct_devs < 100000ull ? 4ull : 8ull;
+        const uint64_t want = est_windows / (jobs_per_dev * n_distinct_devs) + 1;
         if (want < per_job) per_job = (uint32_t)(want < 4096 ? 4096 : want);
     }
     if (const char* env = CW_AID_ENV("CW_JOB_WINDOWS")) { const long v = atol(env); if (v >= 1 && v <= (long)CW_MAX_BATCH_WINDOWS) per_job = (uint32_t)v; } /* test aid: jobs of a few windows, so that a small data set reaches every worker */

@@ -73,8 +73,8 @@ uint32_t tier_wgs_cap(int t, uint32_t n_windows, uint32_t full) {
    set's piles, fewer in the synthetic ones -- and long: one work-group per CU at most */
 uint32_t lw_wgs_cap(uint32_t n_windows, uint32_t cus) {
     if (!CW_POA_LW) return 0u;
-    const uint32_t want = n_windows / 32u + 8u;
-    return want < cus ? want : cus;
+    const uint32_t want = n_windows / 128u + 8u, most = cus / 2u ? cus / 2u : 1u; /* (measured: eight such tasks in a 16 384-window batch of the depth-150 bench piles) */
+    return want < most ? want : most;
 }
 
 void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[CW_TIERS]) {
@@ -100,16 +100,18 @@ struct ScratchPlan {
     TierCfg tier[CW_TIERS];
 };
 
-ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t big_slots, uint32_t scale = 1) {
+/* tmax: template k-mers per window the plan provides for -- 1024 (templates of up to 1032 bases at k = 9: every window of the wrappers' defaults) unless the
+   engine was configured for longer ones (cw_configure, up to CW_TMAX): the index kernel takes any template of up to CW_TMAX k-mers, what grows is the plan */
+ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t big_slots, uint32_t scale = 1, uint32_t tmax = 1024) {
     ScratchPlan p;
     memset(&p, 0, sizeof(p));
     p.solid_cap = (16ull * n_words) / prm.solid + n_windows + 16;
-    p.seg_cap = (uint64_t)n_windows * (CW_TMAX + 2);
+    p.seg_cap = (uint64_t)n_windows * (tmax + 2);
     /* scale: 1, or 4 / 16 / 64 after a run whose windows stopped on the task / member / arena capacities -- heuristics of the batch, which a batch of
        few, heavy windows (900-base windows at depth 100) outgrows: cw_run_device_sync runs such a batch again with the larger plan */
     /* the arena is addressed with 32-bit offsets (WinInfo, PoaTask): its scale is the largest one <= scale that keeps the batch's arena inside them
        (x4 of a 52 000-window batch did not, and the re-run ended in CW_E_INVALID); tasks and members scale on their own */
-    const uint64_t arena1 = (uint64_t)n_windows * (16ull * (CW_TMAX + 16) + 4096);
+    const uint64_t arena1 = (uint64_t)n_windows * (16ull * (tmax + 16) + 4096);
     uint64_t as = scale;
     while (as > 1 && arena1 * as > 0xFFFFFFFFull) as /= 2;
     p.arena_scale = (uint32_t)as;
@@ -141,9 +143,9 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
     /* anchor blocks (cw_ab_bytes): header + keys + presence bitsets + dirty list + the position matrix, 2 bytes per (template k-mer,
        sequence); at most CW_TMAX template k-mers per window, so the bound is per sequence, whatever the pieces' lengths are
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
-    p.ablock_units = ((uint64_t)n_seqs * (2ull * CW_TMAX + 2 + CW_TMAX / 8) + (uint64_t)n_windows * (CW_TMAX * (4ull + 8 + 8 + 8) + 256)) / 16 + 64;
+    p.ablock_units = ((uint64_t)n_seqs * (2ull * tmax + 2 + tmax / 8) + (uint64_t)n_windows * (tmax * (4ull + 8 + 8 + 8) + 256)) / 16 + 64;
     put(p.ablock, (size_t)p.ablock_units * 16);
-    p.pfall_elems = (uint64_t)CW_TMAX * 4100; /* up to 1024 anchors x ~4096 sequences */
+    p.pfall_elems = (uint64_t)tmax * 4100; /* up to tmax anchors x ~4096 sequences */
     const size_t idx_wgs = n_windows < (uint32_t)cus ? n_windows : (size_t)cus; /* work-groups of the index kernel: one fallback slot each */
     put(p.pfall, idx_wgs * p.pfall_elems * 2);
     for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
@@ -193,7 +195,8 @@ size_t stitch_lds_one(const hipDeviceProp_t& prop) {
 int set_kernel_attributes(const hipDeviceProp_t& prop) {
     const int lds_st = (int)stitch_lds_one(prop);
     if (hipFuncSetAttribute((const void*)cw_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_IDX_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)cw_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_chain_kernel<CW_CH_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cw_chain_kernel<CW_CH_SLAB_LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_CH_WAVES * CW_CH_SLAB_LONG) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_sort_tier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_SORT_LDS_CLS) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POA_SLAB_BYTES * CW_POA_WAVES) != hipSuccess ||
         hipFuncSetAttribute((const void*)cw_poa_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_POAQ_TASK_BYTES * 4 * CW_POAQ_WAVES) != hipSuccess ||
@@ -334,7 +337,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     uint32_t big_slots = 256;
     if (const char* env = CW_AID_ENV("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots, e->cap_scale);
+    const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots, e->cap_scale, e->tmax_plan);
     if (p.solid_cap > 0xFFFFFFFFull || p.seg_cap > 0xFFFFFFFFull || p.arena_cap > 0xFFFFFFFFull) return CW_E_INVALID; /* see CW_MAX_BATCH_WINDOWS */
     e->last_windows = batch->n_windows; e->last_seqs = batch->n_seqs; e->last_words = batch->n_words; e->last_big_slots = big_slots;
     e->last_ctr_off = p.ctr;
@@ -468,7 +471,10 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     {
         const uint32_t want = (batch->n_windows + CW_CH_WAVES - 1) / CW_CH_WAVES;
         const uint32_t cap = (uint32_t)cus * 2u; /* 2 work-groups x 4 waves x 20 KiB per CU */
-        cw_chain_kernel<<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
+        if (e->tmax_plan > 1024u) /* an engine configured for long templates (cw_configure): 32 KiB per wave, up to CW_TMAX anchors, one work-group per CU */
+            cw_chain_kernel<CW_CH_SLAB_LONG><<<want < (uint32_t)cus ? want : (uint32_t)cus, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB_LONG, st>>>(db, sc, e->prm);
+        else
+            cw_chain_kernel<CW_CH_SLAB><<<want < cap ? want : cap, 64 * CW_CH_WAVES, CW_CH_WAVES * CW_CH_SLAB, st>>>(db, sc, e->prm);
     }
     stage_end(e, st, sid);
     auto knob_u = [](const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) { const char* v = CW_AID_ENV(name); if (!v) return dflt; const long x = atol(v); return x >= (long)lo && x <= (long)hi ? (uint32_t)x : dflt; };
@@ -600,6 +606,19 @@ int cw_run_device(cw_engine* e, const cw_batch* batch, const cw_result* res, voi
     if (!e) return CW_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     return run_device_locked(e, batch, res, hip_stream);
+}
+
+/* Templates longer than the default plan provides for (include/consent_amd.h): the scratch plan and the chain kernel's instance follow; takes effect with
+   the engine's next run. */
+int cw_configure(cw_engine* e, uint32_t max_template_len) {
+    if (!e) return CW_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const uint32_t k = e->prm.k ? e->prm.k : 1u;
+    uint32_t kmers = max_template_len >= k ? max_template_len - k + 1u : 1u;
+    if (kmers > (uint32_t)CW_TMAX) return CW_E_INVALID; /* beyond what the index kernel holds (CW_WHY_TEMPLATE) */
+    if (kmers < 1024u) kmers = 1024u;                   /* never below the default plan */
+    e->tmax_plan = kmers;
+    return CW_OK;
 }
 
 int cw_poll(cw_engine* e) {
@@ -1139,10 +1158,10 @@ static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int kno
     if (!kinds) return CW_OK;
     const uint32_t next = e->cap_scale * 4u;
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, next);
+    const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, next, e->tmax_plan);
     {   /* does the larger plan grow what ran out?  (the arena's own scale is clamped to 32-bit offsets: a batch stopped on its arena slices
            at a clamped scale is the same batch with the same arena at x4, x16 and x64) */
-        const ScratchPlan cur = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale);
+        const ScratchPlan cur = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale, e->tmax_plan);
         const bool helps = ((kinds & 1) && (p.task_cap > cur.task_cap || p.member_cap > cur.member_cap)) || ((kinds & 2) && p.arena_scale > cur.arena_scale);
         if (!helps) {
             fprintf(stderr, "[consent_amd] windows stopped on the batch's %s capacity; a plan x%u does not enlarge it: keeping the run's result\n", (kinds & 2) ? "arena" : "task / member", next);
@@ -1179,7 +1198,7 @@ static void decay_scale(cw_engine* e, hipStream_t st, uint32_t n_windows, uint32
     else if (hipMemcpyAsync(used, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale / 4u);
+    const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale / 4u, e->tmax_plan);
     if ((uint64_t)used[0] * 2u > lower.task_cap || (uint64_t)used[1] * 2u > lower.member_cap) return;
     e->cap_scale /= 4u;
     bool in_flight = false;

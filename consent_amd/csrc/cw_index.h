@@ -26,12 +26,12 @@ typedef __attribute__((address_space(1))) const uint32_t* cw_g32; /* ... or wher
 #define CW_IDX_THREADS 1024
 #define CW_IDX_WAVES 16
 #define CW_IDX_LDS_BYTES 163840
-#define CW_TMAX 1024 /* template k-mer slots */
+#define CW_TMAX 2048 /* template k-mer slots (round 6: 2048 -- templates of up to 2048 + k - 1 bases, `-l 1500` runs; 1024 through round 5) */
 #define CW_EX_SLOTS 1024 /* in LDS; a pile that saturates more keys than this is counted again with the table in global memory */
 #define CW_EX_BITS 10
 #define CW_EXP_SLOTS 8 /* solid keys a thread keeps in registers during the export of the count table; a thread that finds more walks its words again */
 #define CW_EXG_SLOTS 262144 /* per-work-group exact table in global memory for piles so deep that more than CW_EX_SLOTS / 2 keys can saturate */
-#define CW_TH_SLOTS 2048
+#define CW_TH_SLOTS 4096
 #ifndef CW_IDX_BYTES
 #ifndef CW_IDX_BYTES_RTN
 #define CW_IDX_BYTES_RTN 0 /* 1: the byte counters of phase A with returning adds, as round 4 had them */
@@ -158,15 +158,16 @@ __device__ __forceinline__ uint32_t cw_block_exscan(uint32_t v, uint32_t* scratc
 
 __device__ __forceinline__ uint32_t cw_hash32(uint32_t x) { return x * 2654435761u; }
 
-/* the template's k-mer table: 512 buckets of four entries, entry = (template position + 1) | the key's low 21 bits << 11 (the whole key
+/* the template's k-mer table: 1024 buckets of four entries, entry = (template position + 1) | the key's low 20 bits << 12 (the whole key
    when k <= 10).  A bucket is one 16-byte LDS read and its four entries are compared in registers; entries fill a bucket front to back
    and overflow into the next bucket, so a bucket with a free last entry ends the search.  (Linear probing over single entries took about
    eight dependent round trips to LDS per wave and lookup round at depth 150 -- half of the support pass.) */
-#define CW_TH_POS(e) ((e) & 2047u)
-#define CW_TH_FP(key) (((key) & 0x1FFFFFu) << 11)
+#define CW_TH_POS(e) ((e) & 4095u)
+#define CW_TH_FP(key) (((key) & 0xFFFFFu) << 12)
 #define CW_TH_BUCKETS (CW_TH_SLOTS / 4)
-#define CW_TH_HOME(key) (cw_hash32(key) >> (32 - 9))
-static_assert(CW_TH_BUCKETS == 512, "CW_TH_HOME takes nine bits of the hash");
+#define CW_TH_HOME(key) (cw_hash32(key) >> (32 - 10))
+static_assert(CW_TH_BUCKETS == 1024, "CW_TH_HOME takes ten bits of the hash");
+static_assert(CW_TMAX + 1 <= 4095, "an entry holds the template position + 1 in twelve bits");
 /* lookup of a template k-mer: returns its representative template position or -1 */
 __device__ __forceinline__ int cw_tpl_lookup(const uint32_t* th, const uint32_t* tkey, uint32_t key) {
     uint32_t bkt = CW_TH_HOME(key);
@@ -175,7 +176,7 @@ __device__ __forceinline__ int cw_tpl_lookup(const uint32_t* th, const uint32_t*
         for (uint32_t j = 0; j < 4u; ++j) {
             const uint32_t e = th[bkt * 4u + j];
             if (e == 0) return -1;
-            if ((e & ~2047u) == fp && tkey[CW_TH_POS(e) - 1] == key) return (int)CW_TH_POS(e) - 1;
+            if ((e & ~4095u) == fp && tkey[CW_TH_POS(e) - 1] == key) return (int)CW_TH_POS(e) - 1;
         }
         bkt = (bkt + 1) & (CW_TH_BUCKETS - 1);
     }
@@ -196,22 +197,16 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     uint32_t* scan_tmp = (uint32_t*)(lds + 131072 + CW_EX_SLOTS * 8);         /* 32 words                  */
     uint32_t* flags = scan_tmp + 32;                                          /* [0] overflow [1..] misc   */
     /* phase B..D carve (reuses the same bytes once phase A has been exported) */
-    uint32_t* th = (uint32_t*)lds;                                            /* 2048 x u32      @0      */
-    uint32_t* tkey = (uint32_t*)(lds + 8192);                                 /* 1024 x u32      @8192   */
-    uint32_t* tsup = (uint32_t*)(lds + 12288);                                /* 1024 x u32      @12288  */
-    uint8_t* trep = lds + 16384;                                              /* 1024 x u8       @16384  */
-    int16_t* tcand = (int16_t*)(lds + 17408);                                 /* 1024 x i16      @17408  */
-    uint16_t* cand_tp = (uint16_t*)(lds + 19456);                             /* 1024 x u16      @19456  */
-    uint32_t* seen = (uint32_t*)(lds + 21504);                                /* 16 x 32 x u32   @21504  */
-    int16_t* clen = (int16_t*)(lds + 23552);
-    int16_t* cnxt = (int16_t*)(lds + 25600);
-    int16_t* bnext = (int16_t*)(lds + 27648);
-    int16_t* lvl_head = (int16_t*)(lds + 29696);                              /* 1025 x i16 (2064 B)     */
-    int32_t* csc = (int32_t*)(lds + 31760);
-    uint16_t* chain = (uint16_t*)(lds + 35856);
-    uint32_t* misc = (uint32_t*)(lds + 37904);                                /* 64 words                */
-    uint16_t* const P_lds = (uint16_t*)(lds + 38400);
-    const uint32_t p_cap = (CW_IDX_STAGE_OFF - 38400) / 2;
+    uint32_t* th = (uint32_t*)lds;                                            /* 4096 x u32      @0      */
+    uint32_t* tkey = (uint32_t*)(lds + 16384);                                /* 2048 x u32      @16384  */
+    uint32_t* tsup = (uint32_t*)(lds + 24576);                                /* 2048 x u32      @24576  */
+    uint8_t* trep = lds + 32768;                                              /* 2048 x u8       @32768  */
+    int16_t* tcand = (int16_t*)(lds + 34816);                                 /* 2048 x i16      @34816  */
+    uint16_t* cand_tp = (uint16_t*)(lds + 38912);                             /* 2048 x u16      @38912  */
+    uint32_t* seen = (uint32_t*)(lds + 43008);                                /* 16 x 64 x u32   @43008  */
+    uint32_t* misc = (uint32_t*)(lds + 47104);                                /* 64 words                */
+    uint16_t* const P_lds = (uint16_t*)(lds + 47360);
+    const uint32_t p_cap = (CW_IDX_STAGE_OFF - 47360) / 2;
     uint32_t* st_hdr = (uint32_t*)(lds + CW_IDX_STAGE_OFF);                    /* [0] words staged          */
     uint32_t* s_len = st_hdr + 4;                                             /* CW_IDX_STAGE_N            */
     uint32_t* s_off = s_len + CW_IDX_STAGE_N;                                 /* CW_IDX_STAGE_N            */
@@ -859,21 +854,21 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
            pack or the list overflows.  (The scratch is the one of phase A's global exact table, which is exported by now.) */
         uint32_t* const hitlist = (uint32_t*)(sc.ex_fallback + (size_t)blockIdx.x * CW_EXG_SLOTS);
         const uint32_t hit_cap = CW_EXG_SLOTS * 2u;
-        const bool hl = !tfit && N <= 4096u;
+        const bool hl = !tfit && N <= 1024u; /* (a list entry holds the sequence in ten bits) */
         if (tid == 0) { misc[4] = 0; misc[5] = 0; }
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
-        for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; lvl_head[i] = -1; }
-        if (tid == 0) lvl_head[CW_TMAX] = -1;
-        if ((uint32_t)tid < nk0) tkey[tid] = stw ? cw_kmer_at(s_words, tid, k) : cw_kmer_at(b.bases + b.seq_word_off[s0], tid, k);
+        for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; }
+        /* (one thread per template k-mer, two rounds for a template of more than 1024 k-mers: round 6) */
+        for (uint32_t tp = tid; tp < nk0; tp += CW_IDX_THREADS) tkey[tp] = stw ? cw_kmer_at(s_words, tp, k) : cw_kmer_at(b.bases + b.seq_word_off[s0], tp, k);
         __syncthreads();
-        if ((uint32_t)tid < nk0) {
-            const uint32_t key = tkey[tid];
+        for (uint32_t tp = tid; tp < nk0; tp += CW_IDX_THREADS) {
+            const uint32_t key = tkey[tp];
             uint32_t bkt = CW_TH_HOME(key);
             for (bool placed = false; !placed; bkt = (bkt + 1) & (CW_TH_BUCKETS - 1)) {
                 for (uint32_t j = 0; j < 4u && !placed; ++j) {
-                    const uint32_t prev = atomicCAS(&th[bkt * 4u + j], 0u, ((uint32_t)tid + 1) | CW_TH_FP(key));
+                    const uint32_t prev = atomicCAS(&th[bkt * 4u + j], 0u, (tp + 1u) | CW_TH_FP(key));
                     if (prev == 0) placed = true;
-                    else if ((prev & ~2047u) == CW_TH_FP(key) && tkey[CW_TH_POS(prev) - 1] == key) { trep[CW_TH_POS(prev) - 1] = 1; placed = true; } /* repeated inside the template */
+                    else if ((prev & ~4095u) == CW_TH_FP(key) && tkey[CW_TH_POS(prev) - 1] == key) { trep[CW_TH_POS(prev) - 1] = 1; placed = true; } /* repeated inside the template */
                 }
             }
         }
@@ -895,7 +890,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) { key4[q] = (uint32_t)(x_ >> (64u - 2u * k)); bkt4[q] = CW_TH_HOME(key4[q]); }
                 if (fp_exact) {
                     auto match = [&](const uint4 v, const uint32_t fp) -> uint32_t {
-                        return (v.x & ~2047u) == fp ? v.x : (v.y & ~2047u) == fp ? v.y : (v.z & ~2047u) == fp ? v.z : (v.w & ~2047u) == fp ? v.w : 0u;
+                        return (v.x & ~4095u) == fp ? v.x : (v.y & ~4095u) == fp ? v.y : (v.z & ~4095u) == fp ? v.z : (v.w & ~4095u) == fp ? v.w : 0u;
                     };
                     uint4 v4[4];
 #pragma unroll
@@ -933,11 +928,11 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                         if (old4[q] & (1u << (e & 31u))) trep[e] = 1;
                         else atomicAdd(&tsup[e], 1u);
                         if (tfit) P_lds[e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
-                        else if (hl && p >= 1024u) misc[5] = 1;
+                        else if (hl && p >= 2048u) misc[5] = 1;
                     }
                     if (!tfit && hl) {
-                        const unsigned long long hm = __ballot(hit && p < 1024u);
-                        if (hit && p < 1024u) my_list |= (n_list + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))) << (8u * q); /* at most 256 hits per round */
+                        const unsigned long long hm = __ballot(hit && p < 2048u);
+                        if (hit && p < 2048u) my_list |= (n_list + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))) << (8u * q); /* at most 256 hits per round */
                         n_list += (uint32_t)__popcll(hm);
                     }
                 }
@@ -948,14 +943,14 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 #pragma unroll
                     for (uint32_t q = 0; q < 4u; ++q) {
                         const uint32_t p = p0 + q, hi_ = base + ((my_list >> (8u * q)) & 255u);
-                        if (e1[q] != 0u && p < 1024u && hi_ < hit_cap) hitlist[hi_] = ((CW_TH_POS(e1[q]) - 1u) << 22) | (s << 10) | p;
+                        if (e1[q] != 0u && p < 2048u && hi_ < hit_cap) hitlist[hi_] = ((CW_TH_POS(e1[q]) - 1u) << 21) | (s << 11) | p; /* template k-mer (11 bits), sequence (10), position (11) */
                     }
                 }
             }
         };
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
-            uint32_t* my_seen = seen + wave * 32;
-            if (lane < 32) my_seen[lane] = 0;
+            uint32_t* my_seen = seen + wave * 64; /* one bit per template k-mer */
+            my_seen[lane] = 0;
             cw_wave_sync();
             if (stw) support_seq((cw_l32)(s_words + s_off[s]), s_len[s], s, my_seen);
             else support_seq((cw_g32)(b.bases + b.seq_word_off[s0 + s]), stm ? s_len[s] : b.seq_len[s0 + s], s, my_seen);
@@ -966,13 +961,20 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         /* candidates in template order */
         uint32_t A;
         {
-            uint32_t ok = 0;
-            if ((uint32_t)tid < nk0) {
-                const int rep = cw_tpl_lookup(th, tkey, tkey[tid]);
-                ok = (rep == tid && trep[tid] == 0 && (int)tsup[tid] >= sup_min) ? 1u : 0u;
+            A = 0;
+            for (uint32_t tb = 0; tb < nk0; tb += CW_IDX_THREADS) { /* (the template's k-mers 1024 at a time: template order = round, then thread) */
+                const uint32_t tp = tb + (uint32_t)tid;
+                uint32_t ok = 0;
+                if (tp < nk0) {
+                    const int rep = cw_tpl_lookup(th, tkey, tkey[tp]);
+                    ok = (rep == (int)tp && trep[tp] == 0 && (int)tsup[tp] >= sup_min) ? 1u : 0u;
+                }
+                uint32_t a_round;
+                const uint32_t off = A + cw_block_exscan(ok, scan_tmp, &a_round);
+                if (ok) { tcand[tp] = (int16_t)off; cand_tp[off] = (uint16_t)tp; }
+                A += a_round;
+                __syncthreads(); /* (scan_tmp is used again by the next round) */
             }
-            const uint32_t off = cw_block_exscan(ok, scan_tmp, &A);
-            if (ok) { tcand[tid] = (int16_t)off; cand_tp[off] = (uint16_t)tid; }
         }
         __syncthreads();
         CW_PROF(sc.ctr, 58, tid == 0);
@@ -1001,8 +1003,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u) {
                         const uint32_t h = h4[u];
-                        const int a = i0 + u * CW_IDX_THREADS < n_hits ? tcand[h >> 22] : -1;
-                        if (a >= 0) PWR((uint32_t)a * Np + ((h >> 10) & 4095u), h & 1023u);
+                        const int a = i0 + u * CW_IDX_THREADS < n_hits ? tcand[h >> 21] : -1;
+                        if (a >= 0) PWR((uint32_t)a * Np + ((h >> 11) & 1023u), h & 2047u);
                     }
                 }
             } else
@@ -1083,14 +1085,26 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 for (uint32_t d = wave; d < nd; d += CW_IDX_WAVES) { const uint32_t s = dirty[d]; scan_seq(s, clean[s] == 0, true, d); }
                 __syncthreads();
                 /* correction rows: the anchors with a non-empty mask, numbered in anchor order */
-                uint32_t ok = 0;
-                if ((uint32_t)tid < A) for (uint32_t x = 0; x < W; ++x) ok |= badm[(size_t)tid * W + x] != 0ull ? 1u : 0u;
-                const uint32_t off = cw_block_exscan(ok, misc + 16, &n_rows);
+                /* (anchors 1024 at a time, like the candidates above: two rounds when a long template has more than 1024 anchors) */
+                uint32_t ok2[2] = {0u, 0u}, off2[2] = {0u, 0u};
+                n_rows = 0;
+                for (uint32_t r2 = 0; r2 < 2u; ++r2) {
+                    const uint32_t an = r2 * CW_IDX_THREADS + (uint32_t)tid;
+                    if (r2 * CW_IDX_THREADS >= A) break;
+                    if (an < A) for (uint32_t x = 0; x < W; ++x) ok2[r2] |= badm[(size_t)an * W + x] != 0ull ? 1u : 0u;
+                    uint32_t n_round;
+                    off2[r2] = n_rows + cw_block_exscan(ok2[r2], misc + 16, &n_round);
+                    n_rows += n_round;
+                    __syncthreads();
+                }
                 has_delta = n_rows >= 1u && n_rows <= CW_AB_ROWS_MAX && cw_ab_bytes(A, N, nd, n_rows) <= ((uint64_t)w_ab_cap << 4);
                 has_bm = W == 1u || has_delta;
                 if (has_delta) {
-                    if ((uint32_t)tid < A) rowid[tid] = ok ? (uint8_t)off : (uint8_t)0xFF;
-                    if (ok) rowanc[off] = (uint16_t)tid;
+                    for (uint32_t r2 = 0; r2 < 2u; ++r2) {
+                        const uint32_t an = r2 * CW_IDX_THREADS + (uint32_t)tid;
+                        if (an < A) rowid[an] = ok2[r2] ? (uint8_t)off2[r2] : (uint8_t)0xFF;
+                        if (ok2[r2]) rowanc[off2[r2]] = (uint16_t)an;
+                    }
                 } else n_rows = 0;
                 if (has_bm && (uint32_t)tid < nd) { const uint32_t s = dirty[tid]; clean[s] = (uint8_t)0x80u; if (N <= 1024u) didx[s] = (uint8_t)tid; else clean[s] = (uint8_t)(0x80u | (uint32_t)tid); }
                 __syncthreads();

@@ -60,6 +60,7 @@ struct cw_engine {
     float stage_ms[CW_MAX_STAGES] = {};
     bool timings_valid = false;
     uint32_t last_windows = 0, last_big_slots = 0, last_seqs = 0;
+    uint32_t tmax_plan = 1024; /* template k-mers per window the scratch plan provides for (cw_configure) */
     uint32_t linger_wgs = 0; /* tier-L work-groups kept on the live overflow queue (adapted from the previous batch) */
     uint32_t cap_scale = 1;  /* multiplier of the batch's task / member / arena capacities: grows (x4) after a run that stopped on them (cw_run_device_sync) */
     uint64_t last_words = 0;

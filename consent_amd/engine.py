@@ -131,6 +131,7 @@ def _load(p):
     lib.cw_host_free.restype = None
     lib.cw_poll.argtypes = [C.c_void_p]
     lib.cw_poll.restype = C.c_int
+    lib.cw_configure.argtypes = [C.c_void_p, C.c_uint32]
     lib.cw_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
     lib.cw_debug_win_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.cw_debug_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -519,6 +520,11 @@ class Engine:
         torch.cuda.synchronize(dev)
         out, olen, ost = t_out.cpu().numpy(), t_olen.cpu().numpy(), t_ost.cpu().numpy()
         return [(out[int(out_off[i]) : int(out_off[i]) + int(olen[i])].tobytes().decode("latin-1"), int(ost[i])) for i in range(len(jb))]
+
+    def configure(self, max_template_len):
+        """cw_configure: the longest template (window) this engine will see, before its first run -- templates beyond 1024 + k - 1 bases need a larger
+        scratch plan and the chain kernel's long instance (up to 2048 + k - 1 bases)."""
+        _check(self.lib, self.lib.cw_configure(self.handle, int(max_template_len)), "cw_configure")
 
     def idle(self):
         """cw_poll: True when the last run_device on this engine has completed (never blocks)."""

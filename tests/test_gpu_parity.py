@@ -307,12 +307,14 @@ def test_tier_h_two_tasks_per_wave(aids, monkeypatch):
     ctr, _ = e.profile()
     assert int(ctr[11]) > 0, ctr[6:12]  # tasks routed to tier H
     assert_same(got, exp, len(piles), "tier H")
+    monkeypatch.setenv("CW_LW", "0")  # (list 5 is tier H's only while tier LW is off: with tier H off, tier LW counts its tasks there -- round 6)
     for mode in ("1", "0"):
         monkeypatch.setenv("CW_TIER_H", mode)
         got = e.run(hb)
         ctr2, _ = e.profile()
         assert (int(ctr2[11]) <= int(ctr[11])) if mode == "1" else int(ctr2[11]) == 0
         assert_same(got, exp, len(piles), f"CW_TIER_H={mode}")
+    monkeypatch.delenv("CW_LW")
     monkeypatch.delenv("CW_TIER_H")
     hb2 = synth_host(ca.SynthSpec.pacbio(96, 150, first_window=7000))
     exp2, _ = oracle_lib.oracle_run(ca.Params(*prm), hb2, threads=os.cpu_count() or 1)
@@ -504,3 +506,38 @@ def test_cpp_adapter_runs_on_the_gpu(tmp_path):
                            "-lconsent_amd", "-Wl,-rpath," + os.path.join(root, "consent_amd"), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "status: consensus" in out.stdout, out.stdout + out.stderr
+
+
+def test_templates_of_up_to_2048_kmers_after_cw_configure():
+    """Round 6 (`-l 1500` must run: the reference takes any window size, src/main.cpp:46-47).  The index kernel holds templates of up to 2048 k-mers (1024
+    through round 5); an engine told about them (cw_configure: scratch plan, the chain kernel's 32 KB instance) corrects windows of 1500 and 2000 bases
+    exactly as the oracle does -- synthetic piles at three depths, and a near-identical pile in which almost every template k-mer is an anchor (more than
+    1240 of them: what the default chain instance cannot hold) -- and a template beyond 2048 k-mers is a reported capacity (CW_WHY_TEMPLATE)."""
+    rng = random.Random(61)
+    prm = ca.Params(9, 4, 8, 2, 150)
+    eng = ca.Engine(prm)
+    eng.configure(2056)
+    for wlen, depth, n in ((1500, 30, 24), (2000, 12, 16), (1500, 90, 8), (1100, 150, 6)):
+        hb = synth_host(ca.SynthSpec.pacbio(n, depth, first_window=4000 + wlen, window_len=wlen))
+        exp, _ = oracle_lib.oracle_run(prm, hb, threads=os.cpu_count() or 1)
+        got = eng.run(hb)
+        assert_same(got, exp, n, f"window length {wlen}, depth {depth}")
+        assert int((np.asarray(got.status[:n]) == 0).sum()) >= n - 1, got.status[:n]  # consensus windows, not template fallbacks or stops
+    truth = rand_seq(rng, 1800)
+    piles = [[truth] + [mutate(rng, truth, 0.01) for _ in range(12)], [rand_seq(rng, 2056)] + [rand_seq(rng, 2056) for _ in range(3)]]
+    hb = ca.pack_piles(piles)
+    exp, _ = oracle_lib.oracle_run(prm, hb, threads=2)
+    got = eng.run(hb)
+    assert_same(got, exp, 2, "near-identical pile of 1800 bases")
+    # without cw_configure the same windows never give a wrong answer: they are corrected or stop on a capacity
+    plain = ca.Engine(prm)
+    got2 = plain.run(hb)
+    for w in range(2):
+        assert int(got2.status[w]) == 2 or (int(got2.status[w]) == int(exp.status[w]) and got2.consensus(w) == exp.consensus(w))
+    # beyond the index kernel's 2048 k-mers: a capacity, and cw_configure says so up front
+    hb3 = ca.pack_piles([[rand_seq(rng, 2100)] * 4])
+    got3 = eng.run(hb3)
+    assert int(got3.status[0]) == 2
+    with pytest.raises(ca.EngineError):
+        eng.configure(2100)
+    eng.close(); plain.close()

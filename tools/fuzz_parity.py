@@ -16,7 +16,7 @@ import oracle_lib  # noqa: E402
 
 
 WHY = {1: "SETUP", 2: "COUNT", 3: "SOLIDCAP", 4: "TEMPLATE", 5: "MATRIX", 6: "SEGMENTS", 7: "TASKS", 8: "POA", 9: "FIN_LEN", 10: "FIN_SOLID", 11: "FIN_POLISH",
-       12: "OUT_CONS", 13: "OUT_SOLID", 14: "ARENA"}  # cw_device.h CW_WHY_*
+       12: "OUT_CONS", 13: "OUT_SOLID", 14: "ARENA", 15: "ANCHORS"}  # cw_device.h CW_WHY_*
 MAX_OVERFLOW_SHARE = float(os.environ.get("CW_FUZZ_CAP_BAR", "0.001"))  # a capacity stop is never a wrong answer, but more than one window in a thousand is a regression
 # (CW_FUZZ_CAP_BAR: tools/fuzz_policy.sh raises the bar for the heaviest-bundle build, whose consensuses are longer on chance-anchor piles)
 
