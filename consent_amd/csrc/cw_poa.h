@@ -1415,6 +1415,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
     unsigned long long* dslab = (unsigned long long*)(my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC));
     uint8_t* cold = my_slab + CW_POA_HSLAB_BYTES(CW_POA_NC, CW_POA_LC) + CW_POA_DSLAB_BYTES(CW_POA_NC, CW_POA_LC);
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * CW_POA_SLAB_BYTES, CW_POA_NC, CW_POA_EC, CW_POA_LC, (CW_POA_NC + 1) * (CW_POA_LC + 1), 0, hslab, dslab, cold, !CW_S_EDGES_LDS, true);
+    static_assert(CW_POA_SMAX * (CW_POA_NC + CW_POA_LC) <= CW_POA_I16_BOUND && 4 * CW_POA_SMAX * (CW_POA_NC + 64) <= CW_POA_I16_BOUND, "include/cw_policy.h \"Bounds\": tier S");
     M.H = hslab; M.dirs = dslab;
     {
         uint8_t* extra = lds + (size_t)wave * CW_POA_SLAB_BYTES + (CW_POA_SLAB_BYTES - 4 * CW_S_LCODES_WORDS - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(CW_POA_NC));
@@ -1515,6 +1516,12 @@ cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     PoaMem<int16_t> M = poa_carve<int16_t>(lds + (size_t)wave * slab, NC, EC, LC, (NC + 1) * (LC + 1), (TIER >= 3 || (TIER == 2 && CW_M2_DIRS)) ? CW_POA_DSLAB_PAIRS(NC, LC) : 0, hslab, dslab, cold,
                                            true, TIER == 1 || (TIER == 2 && (CW_M2_CHAIN_TABS || CW_M2_CODES)), TIER >= 3 && CW_L_COLD_NODES);
     M.H = hslab; M.dirs = dslab; /* again, without poa_carve's either-or: these two are now provably global pointers */
+    /* include/cw_policy.h "Bounds": the int16 values of this tier's fills stay inside +-CW_POA_I16_BOUND -- by its capacities, or (tier L under scores
+       beyond 11) by handing a graph of more nodes than that allows on to tier G */
+    static_assert(TIER == 3 || CW_POA_SMAX * (NC + LC) <= CW_POA_I16_BOUND, "matrix / packed fills of this tier");
+    static_assert(4 * CW_POA_SMAX * (NC + 64) <= CW_POA_I16_BOUND || !(TIER == 1 || (TIER == 2 && CW_M2_CODES)), "recorded decisions of this tier");
+    if constexpr (TIER == 3 && CW_POA_SMAX * (NC + LC) > CW_POA_I16_BOUND) M.n_cap = (uint32_t)(CW_POA_I16_BOUND / CW_POA_SMAX - LC);
+    static_assert(TIER != 3 || CW_POA_I16_BOUND / CW_POA_SMAX > LC + 64, "tier L keeps a useful node capacity under these scores");
     if (TIER <= 2 && CW_POA_HOTC_OF_TIER(TIER)) { /* cw_poa_c.h: ring and flags behind the hot arrays in LDS, code words where tier L keeps its direction words */
         uint8_t* extra = lds + (size_t)wave * slab + (slab - CW_POA_RING_BYTES - CW_POA_GFLAG_BYTES(NC));
         M.ring = (int16_t*)extra; M.gflag = (uint32_t*)(extra + CW_POA_RING_BYTES);

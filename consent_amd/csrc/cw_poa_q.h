@@ -103,6 +103,7 @@ typedef PoaQT<16, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_RING, false> PoaQ16;
 #define CW_POAQ_WAVES (CW_CONS_HEAVIEST_BUNDLE ? 10 : 12) /* at most, per CU: 48 tasks (40 with the edge weights of the heaviest-bundle policy: 3576 bytes a task) */
 #endif
 static_assert(PoaQ16::TASK_BYTES * 4 * CW_POAQ_WAVES <= 163840, "tier Q: CW_POAQ_WAVES waves of four tasks fit a CU's LDS");
+static_assert(4 * CW_POA_SMAX * (CW_POAQ_NC + 64) <= CW_POA_I16_BOUND, "include/cw_policy.h \"Bounds\": tier Q's recorded decisions (values x 4 in 16-bit halves)");
 #ifndef CW_POAQ_ROUTE_NODES
 #define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
 #endif

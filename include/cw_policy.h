@@ -23,7 +23,7 @@
 /* Overridable at build time on BOTH sides (-DCW_POA_MATCH=2 -DCW_POA_MISMATCH=-4 -DCW_POA_GAP=-4 ...): spoa's library defaults differ   */
 /* between its versions, and the version BMEAN bundles is unknown.  Everything in the engine is derived from these three (the recorded-   */
 /* decision fill's scaled constants 4 * (MATCH - GAP), 4 * (MISMATCH - GAP), 4 * GAP included); tests/test_gpu_policy.py builds both      */
-/* sides with another triple.  Bounds: the int16 tiers keep |score| <= 8 * (nodes + columns) inside 15 bits.                              */
+/* sides with another triple.  Bounds: below.                                                                                             */
 #ifndef CW_POA_MATCH
 #define CW_POA_MATCH      5
 #endif
@@ -33,9 +33,19 @@
 #ifndef CW_POA_GAP
 #define CW_POA_GAP      (-8)
 #endif
-#if CW_POA_GAP >= 0 || CW_POA_GAP < -8 || CW_POA_MATCH <= 0 || CW_POA_MATCH > 8 || CW_POA_MISMATCH > 0 || CW_POA_MISMATCH < -8 || CW_POA_MATCH <= CW_POA_MISMATCH
-#error "cw_policy.h: CW_POA_MATCH in 1..8, CW_POA_MISMATCH in -8..0, CW_POA_GAP in -8..-1 (linear gap, int16 DP tiers)"
+#if CW_POA_GAP >= 0 || CW_POA_GAP < -16 || CW_POA_MATCH <= 0 || CW_POA_MATCH > 16 || CW_POA_MISMATCH > 0 || CW_POA_MISMATCH < -16 || CW_POA_MATCH <= CW_POA_MISMATCH
+#error "cw_policy.h: CW_POA_MATCH in 1..16, CW_POA_MISMATCH in -16..0, CW_POA_GAP in -16..-1 (linear gap, int16 DP tiers)"
 #endif
+/* Bounds (round 6: |score| <= 16; <= 8 through round 5).  With SMAX the largest absolute score, a DP value of a graph of n nodes against L bases lies
+   inside +-SMAX * (n + L); the engine's int16 tiers keep every value inside +-29000 (their "no value" is -30000):
+     matrix and packed fills (members of more than 63 bases, tiers M2 / L):  SMAX * (nodes + bases) <= 29000;
+     recorded decisions (values x 4, members of at most 63 bases):            4 * SMAX * (nodes + 64) <= 29000.
+   Every tier's capacities satisfy both up to SMAX = 16 except tier L's 1536 nodes + 1023 bases, which do up to SMAX = 11: beyond that tier L hands a
+   graph of more than 29000 / SMAX - 1023 nodes on to the int32 tier G (cw_poa.h CW_POA_NCAP_I16).  The oracle computes in int32. */
+#define CW_POA_ABS_(x) ((x) < 0 ? -(x) : (x))
+#define CW_POA_MAX2_(a, b) ((a) > (b) ? (a) : (b))
+#define CW_POA_SMAX CW_POA_MAX2_(CW_POA_MATCH, CW_POA_MAX2_(CW_POA_ABS_(CW_POA_MISMATCH), CW_POA_ABS_(CW_POA_GAP)))
+#define CW_POA_I16_BOUND 29000
 
 /* Traceback preference at a cell (spoa sisd engine order): diagonal through the in-edges in     */
 /* insertion order, then vertical (graph node against a gap) through the in-edges in insertion   */

@@ -199,3 +199,21 @@ def test_missing_anchor_extrapolation_is_implemented_on_both_sides(tmp_path):
     assert digest_default != digest_ex
     mixed, _ = run_child({"CONSENT_AMD_LIB": alt_lib})
     assert not mixed
+
+
+@pytest.mark.timeout(1500)
+def test_alignment_scores_up_to_sixteen(tmp_path):
+    """-DCW_POA_MATCH=16 -DCW_POA_MISMATCH=-12 -DCW_POA_GAP=-16 (round 6: the legal range is |score| <= 16, <= 8 through round 5; cw_policy.h "Bounds").
+    Every int16 tier keeps its values inside +-29000 by its capacities except tier L, which under such scores hands graphs of more than
+    29000 / 16 - 1023 = 789 nodes on to the int32 tier G -- the deep piles of this test have such graphs.  The two sides agree window by window, and
+    the consensus is not the default scores'."""
+    from consent_amd import _build
+
+    sc = ["-DCW_POA_MATCH=16", "-DCW_POA_MISMATCH=-12", "-DCW_POA_GAP=-16"]
+    alt_lib = str(tmp_path / "libconsent_amd_s16.so")
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sc, *_build.SRC, "-o", alt_lib])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "policy", f"OUT={tmp_path}", "POLICY=" + " ".join(sc)])
+    same_default, digest_default = run_child({})
+    same_sc, digest_sc = run_child({"CONSENT_AMD_LIB": alt_lib, "CW_ORACLE_LIB": str(tmp_path / "liboracle.so")})
+    assert same_default and same_sc
+    assert digest_default != digest_sc
