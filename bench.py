@@ -238,6 +238,8 @@ def main():
     prm = ca.Params(9, 4, 8, 2, max_msa)
     # (an engine allocates its scratch in its first run: no more engines than warm-up steps, so that no first run falls into the timed region)
     engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, min(args.engines, max(1, args.warmup))))]
+    for e_ in engines:  # the caller knows its window size, as the native driver does (cw_configure: the scratch plan goes by it -- 492 k-mers per template, not 1024)
+        e_.configure(500)
     eng = engines[0]
     lib = eng.lib
     dev = torch.device("cuda", local_rank)

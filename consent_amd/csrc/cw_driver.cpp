@@ -151,7 +151,9 @@ struct Worker {
         cw_params prm{a.mer_size, a.solid_thresh, a.common_kmers, a.min_anchors, a.max_msa};
         rc = cw_create(&prm, phys, &eng);
         if (rc != CW_OK) return rc;
-        if (a.window_size > 1024u + a.mer_size - 1u && (rc = cw_configure(eng, a.window_size)) != CW_OK) return rc; /* templates are windows: at most window_size bases */
+        /* templates are windows: at most window_size bases -- longer than the default plan assumes, or shorter (beyond what the engine takes at all, every
+           window reports its capacity as before: CW_WHY_TEMPLATE) */
+        (void)cw_configure(eng, a.window_size);
         if (hipStreamCreate(&st) != hipSuccess) return CW_E_NO_DEVICE;
         if (owner) {
             if ((rc = reads_of_owner.get()) != CW_OK) return rc;

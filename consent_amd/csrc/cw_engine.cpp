@@ -73,7 +73,7 @@ uint32_t tier_wgs_cap(int t, uint32_t n_windows, uint32_t full) {
    set's piles, fewer in the synthetic ones -- and long: one work-group per CU at most */
 uint32_t lw_wgs_cap(uint32_t n_windows, uint32_t cus) {
     if (!CW_POA_LW) return 0u;
-    const uint32_t want = n_windows / 128u + 8u, most = cus / 2u ? cus / 2u : 1u; /* (measured: eight such tasks in a 16 384-window batch of the depth-150 bench piles) */
+    const uint32_t want = n_windows / 256u + 8u, most = cus / 4u ? cus / 4u : 1u; /* (measured: eight such tasks in a 16 384-window batch of the depth-150 bench piles) */
     return want < most ? want : most;
 }
 
@@ -84,9 +84,11 @@ void tier_config(int cus, uint32_t big_slots, uint32_t n_windows, TierCfg (&t)[C
     uint32_t l_wgs = tier_wgs_cap(3, n_windows, (uint32_t)cus * mix.l); /* (3.5 MB a slab: a generous count here was 12 GB, and allocating it stalled an engine's first job by 1-2 s) */
     if (l_wgs < pass1) l_wgs = pass1; /* the overflow pass launches its own tier-L work-groups */
     t[0] = {(tier_wgs_cap(0, n_windows, (uint32_t)cus * mix.s) * 2u + 8u) * CW_POA_WAVES, CW_POA_SLAB2_TOTAL(CW_POA_NC, CW_POA_EC, CW_POA_LC)}; /* tier S (round 4: cold arrays, flagged rows and code words in a slab) */
-    t[1] = {(tier_wgs_cap(1, n_windows, (uint32_t)cus * mix.m1) * 3u / 2u + 8u) * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
-    t[2] = {(tier_wgs_cap(2, n_windows, (uint32_t)cus * mix.m2) * 3u / 2u + 8u) * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
-    t[3] = {(l_wgs * 3u / 2u + 8u) * CW_POAL_WAVES + lw_wgs_cap(n_windows, (uint32_t)cus), CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)}; /* (+ tier LW's work-groups: they claim tier L's slabs) */
+    /* round 6: a margin of an eighth over the waves the grids hold (a half through round 5): the plan of a 10 240-window job was 16.6 GB, most of it slabs,
+       and a fresh process with four workers on a device spent 0.6-1.6 s allocating before its first job ran (tools/plan_sizes.py) */
+    t[1] = {(tier_wgs_cap(1, n_windows, (uint32_t)cus * mix.m1) * 9u / 8u + 8u) * CW_POAM1_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM1_NC, CW_POAM1_EC, CW_POAM1_LC)};
+    t[2] = {(tier_wgs_cap(2, n_windows, (uint32_t)cus * mix.m2) * 9u / 8u + 8u) * CW_POAM2_WAVES, CW_POA_SLAB2_TOTAL(CW_POAM2_NC, CW_POAM2_EC, CW_POAM2_LC)};
+    t[3] = {(l_wgs * 9u / 8u + 8u) * CW_POAL_WAVES + lw_wgs_cap(n_windows, (uint32_t)cus), CW_POA_SLAB2_TOTAL(CW_POAL_NC, CW_POAL_EC, CW_POAL_LC)}; /* (+ tier LW's work-groups: they claim tier L's slabs) */
     const uint64_t bs = (uint64_t)n_windows / 16u + 8u;
     t[4] = {bs < big_slots ? (uint32_t)bs / 4u * 4u : big_slots, big_slab_bytes()};
     t[5] = {8u, 64u}; /* (tier H's slabs go by resident task, not by claim: ScratchPlan::hslab) */
@@ -145,7 +147,12 @@ ScratchPlan plan_scratch(const cw_params& prm, uint32_t n_windows, uint32_t n_se
        (a pile of many pieces only k bases long has few packed words but a full-width matrix) */
     p.ablock_units = ((uint64_t)n_seqs * (2ull * tmax + 2 + tmax / 8) + (uint64_t)n_windows * (tmax * (4ull + 8 + 8 + 8) + 256)) / 16 + 64;
     put(p.ablock, (size_t)p.ablock_units * 16);
-    p.pfall_elems = (uint64_t)tmax * 4100; /* up to tmax anchors x ~4096 sequences */
+    /* the position matrix of a window whose matrix does not fit LDS: up to tmax anchors x the sequences of a pile -- sixteen times the batch's mean depth, at
+       least 1024 and at most ~4096 of them (round 6; 4100 whatever the batch through round 5: 2.1 GB of a driver job's plan at depth 30).  A pile deeper
+       than that with more anchors than LDS holds is a reported capacity (CW_WHY_MATRIX), as it always was beyond 4100 */
+    const uint64_t mean_n = n_windows ? (uint64_t)n_seqs / n_windows + 1 : 1;
+    const uint64_t pf_n = mean_n * 16 < 1024 ? 1024 : mean_n * 16 > 4100 ? 4100 : mean_n * 16;
+    p.pfall_elems = (uint64_t)tmax * pf_n;
     const size_t idx_wgs = n_windows < (uint32_t)cus ? n_windows : (size_t)cus; /* work-groups of the index kernel: one fallback slot each */
     put(p.pfall, idx_wgs * p.pfall_elems * 2);
     for (int t = 0; t < CW_TIERS; ++t) put(p.sbusy[t], (size_t)p.tier[t].slots * 4);
@@ -334,7 +341,7 @@ int run_device_locked(cw_engine* e, const cw_batch* batch, const cw_result* res,
     CW_HIP(hipSetDevice(e->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
 
-    uint32_t big_slots = 256;
+    uint32_t big_slots = 64; /* tier G's kernel is sixteen work-groups of four waves at most (big_wgs below): 64 slabs of 16.8 MB are all it can use (256 through round 5: 4.3 GB) */
     if (const char* env = CW_AID_ENV("CW_BIG_SLOTS")) { int v = atoi(env); if (v >= 4 && v <= 4096) big_slots = (uint32_t)v / 4 * 4; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
     const ScratchPlan p = plan_scratch(e->prm, batch->n_windows, batch->n_seqs, batch->n_words, cus, big_slots, e->cap_scale, e->tmax_plan);
@@ -616,7 +623,8 @@ int cw_configure(cw_engine* e, uint32_t max_template_len) {
     const uint32_t k = e->prm.k ? e->prm.k : 1u;
     uint32_t kmers = max_template_len >= k ? max_template_len - k + 1u : 1u;
     if (kmers > (uint32_t)CW_TMAX) return CW_E_INVALID; /* beyond what the index kernel holds (CW_WHY_TEMPLATE) */
-    if (kmers < 1024u) kmers = 1024u;                   /* never below the default plan */
+    if (kmers < 128u) kmers = 128u; /* (a caller that knows its windows are shorter than the default plan assumes -- the native driver: `-l 500` is 492
+                                       k-mers -- gets the smaller plan: anchor blocks, segment slots and the arena go by this number) */
     e->tmax_plan = kmers;
     return CW_OK;
 }
@@ -666,6 +674,20 @@ int cw_last_timings(cw_engine* e, float* ms, const char** names, int cap, int* n
         ++k;
     }
     *n_stages = k;
+    return CW_OK;
+}
+
+/* Debug/inspection (cw_private.h): what plan_scratch would allocate, component by component (host arithmetic only). */
+int cw_debug_plan(uint32_t k, uint32_t solid, uint32_t n_windows, uint32_t n_seqs, uint64_t n_words, int cus, uint32_t scale, uint32_t tmax, uint64_t* out15) {
+    if (!out15 || !n_windows || !solid) return CW_E_INVALID;
+    cw_params prm{k, solid, 8, 2, 150};
+    const ScratchPlan p = plan_scratch(prm, n_windows, n_seqs, n_words, cus, 64, scale ? scale : 1, tmax ? tmax : 1024);
+    auto slab = [&](int t) { return (uint64_t)p.tier[t].slots * p.tier[t].slab_bytes; };
+    const uint64_t v[15] = {p.total, (uint64_t)n_windows * sizeof(WinInfo), p.solid_cap * 8, p.seg_cap * 8, p.arena_cap,
+                            ((uint64_t)p.task_cap + 1) * sizeof(PoaTask) + (uint64_t)p.member_cap * sizeof(PoaMember), (uint64_t)p.task_cap * 4 * 2 * CW_TIERS,
+                            slab(0), slab(1), slab(2), slab(3), slab(4), (uint64_t)p.hslab - p.qslab + ((uint64_t)p.ablock - p.hslab), p.ablock_units * 16,
+                            (uint64_t)(p.exg - p.pfall) + (uint64_t)(p.tdbg - p.exg)};
+    for (int i = 0; i < 15; ++i) out15[i] = v[i];
     return CW_OK;
 }
 
@@ -1158,10 +1180,10 @@ static int grow_if_that_helps(cw_engine* e, bool* again, hipStream_t st, int kno
     if (!kinds) return CW_OK;
     const uint32_t next = e->cap_scale * 4u;
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, next, e->tmax_plan);
+    const ScratchPlan p = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 64, next, e->tmax_plan);
     {   /* does the larger plan grow what ran out?  (the arena's own scale is clamped to 32-bit offsets: a batch stopped on its arena slices
            at a clamped scale is the same batch with the same arena at x4, x16 and x64) */
-        const ScratchPlan cur = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale, e->tmax_plan);
+        const ScratchPlan cur = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 64, e->cap_scale, e->tmax_plan);
         const bool helps = ((kinds & 1) && (p.task_cap > cur.task_cap || p.member_cap > cur.member_cap)) || ((kinds & 2) && p.arena_scale > cur.arena_scale);
         if (!helps) {
             fprintf(stderr, "[consent_amd] windows stopped on the batch's %s capacity; a plan x%u does not enlarge it: keeping the run's result\n", (kinds & 2) ? "arena" : "task / member", next);
@@ -1198,7 +1220,7 @@ static void decay_scale(cw_engine* e, hipStream_t st, uint32_t n_windows, uint32
     else if (hipMemcpyAsync(used, (uint8_t*)e->scratch + e->last_ctr_off + offsetof(BatchCounters, n_tasks), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
     const int cus = e->prop.multiProcessorCount > 0 ? e->prop.multiProcessorCount : 256;
-    const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 256, e->cap_scale / 4u, e->tmax_plan);
+    const ScratchPlan lower = plan_scratch(e->prm, n_windows, n_seqs, n_words, cus, e->last_big_slots ? e->last_big_slots : 64, e->cap_scale / 4u, e->tmax_plan);
     if ((uint64_t)used[0] * 2u > lower.task_cap || (uint64_t)used[1] * 2u > lower.member_cap) return;
     e->cap_scale /= 4u;
     bool in_flight = false;

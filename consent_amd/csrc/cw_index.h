@@ -197,16 +197,13 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     uint32_t* scan_tmp = (uint32_t*)(lds + 131072 + CW_EX_SLOTS * 8);         /* 32 words                  */
     uint32_t* flags = scan_tmp + 32;                                          /* [0] overflow [1..] misc   */
     /* phase B..D carve (reuses the same bytes once phase A has been exported) */
+    /* Two layouts, chosen per window by the template's length (round 6): a template of at most 1024 k-mers -- every window of the wrappers' defaults --
+       keeps arrays of 1024 entries and the position matrix gets what is left (107 KB: 6 KB more than round 5's layout, which carried 15 KB of arrays
+       that moved to the chain kernel in round 3); up to 2048 k-mers the arrays are twice as long.  The template table has 1024 buckets either way. */
     uint32_t* th = (uint32_t*)lds;                                            /* 4096 x u32      @0      */
-    uint32_t* tkey = (uint32_t*)(lds + 16384);                                /* 2048 x u32      @16384  */
-    uint32_t* tsup = (uint32_t*)(lds + 24576);                                /* 2048 x u32      @24576  */
-    uint8_t* trep = lds + 32768;                                              /* 2048 x u8       @32768  */
-    int16_t* tcand = (int16_t*)(lds + 34816);                                 /* 2048 x i16      @34816  */
-    uint16_t* cand_tp = (uint16_t*)(lds + 38912);                             /* 2048 x u16      @38912  */
-    uint32_t* seen = (uint32_t*)(lds + 43008);                                /* 16 x 64 x u32   @43008  */
-    uint32_t* misc = (uint32_t*)(lds + 47104);                                /* 64 words                */
-    uint16_t* const P_lds = (uint16_t*)(lds + 47360);
-    const uint32_t p_cap = (CW_IDX_STAGE_OFF - 47360) / 2;
+    uint32_t* tkey = (uint32_t*)(lds + 16384);                                /* 1024 | 2048 x u32       */
+    uint32_t* tsup; uint8_t* trep; int16_t* tcand; uint16_t* cand_tp; uint32_t* seen; uint32_t* misc; uint16_t* P_lds; /* set per window, below */
+    uint32_t p_cap = 0, seen_words = 32;
     uint32_t* st_hdr = (uint32_t*)(lds + CW_IDX_STAGE_OFF);                    /* [0] words staged          */
     uint32_t* s_len = st_hdr + 4;                                             /* CW_IDX_STAGE_N            */
     uint32_t* s_off = s_len + CW_IDX_STAGE_N;                                 /* CW_IDX_STAGE_N            */
@@ -223,15 +220,28 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) { misc[63] = atomicAdd(&sc.ctr->next_window, 1u); st_hdr[0] = 0; }
+        if (tid == 0) { st_hdr[1] = atomicAdd(&sc.ctr->next_window, 1u); st_hdr[0] = 0; } /* (st_hdr[1..3] are free: the staged lengths start at st_hdr + 4) */
         __syncthreads();
-        const uint32_t w = misc[63];
+        const uint32_t w = st_hdr[1];
         if (w >= b.n_windows) break;
         WinInfo* wi = &sc.win[w];
         if (wi->status == CW_WIN_OVERFLOW) continue;
         const uint32_t s0 = b.win_first_seq[w];
         const uint32_t N = wi->n_seqs;
         const uint32_t L0 = wi->tpl_len;
+        {   /* the phase B..D carve for this window's template (wave-uniform values: a few scalar registers) */
+            const bool wide = L0 >= k && L0 - k + 1u > 1024u;
+            tsup = (uint32_t*)(lds + (wide ? 24576u : 20480u));      /* 1024 | 2048 x u32 */
+            trep = lds + (wide ? 32768u : 24576u);                    /* 1024 | 2048 x u8  */
+            tcand = (int16_t*)(lds + (wide ? 34816u : 25600u));      /* 1024 | 2048 x i16 */
+            cand_tp = (uint16_t*)(lds + (wide ? 38912u : 27648u));   /* 1024 | 2048 x u16 */
+            seen = (uint32_t*)(lds + (wide ? 43008u : 29696u));      /* 16 waves x 32 | 64 words: one bit per template k-mer; later 2 | 4 KiB of flags */
+            seen_words = wide ? 64u : 32u;
+            misc = (uint32_t*)(lds + (wide ? 47104u : 31744u));      /* 64 words */
+            const uint32_t p_off = wide ? 47360u : 32000u;
+            P_lds = (uint16_t*)(lds + p_off);
+            p_cap = (CW_IDX_STAGE_OFF - p_off) / 2u;
+        }
         /* read once: a store to the solid table may alias *wi as far as the compiler knows, and every use inside a store loop would be a
            dependent global load (the export's write loop: 24 of them per thread, ~50 k cycles per window) */
         const uint32_t w_solid_base = wi->solid_base, w_solid_cap = wi->solid_cap, w_ab_cap = wi->ab_cap, w_ab_base = wi->ab_base, w_n_kmers = wi->n_kmers;
@@ -857,7 +867,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
         const bool hl = !tfit && N <= 1024u; /* (a list entry holds the sequence in ten bits) */
         if (tid == 0) { misc[4] = 0; misc[5] = 0; }
         for (uint32_t i = tid; i < CW_TH_SLOTS; i += CW_IDX_THREADS) th[i] = 0;
-        for (uint32_t i = tid; i < CW_TMAX; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; }
+        for (uint32_t i = tid; i < seen_words * 32u; i += CW_IDX_THREADS) { tsup[i] = 0; trep[i] = 0; tcand[i] = -1; } /* 1024 or 2048 entries */
         /* (one thread per template k-mer, two rounds for a template of more than 1024 k-mers: round 6) */
         for (uint32_t tp = tid; tp < nk0; tp += CW_IDX_THREADS) tkey[tp] = stw ? cw_kmer_at(s_words, tp, k) : cw_kmer_at(b.bases + b.seq_word_off[s0], tp, k);
         __syncthreads();
@@ -949,8 +959,8 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             }
         };
         for (uint32_t s = wave; s < N; s += CW_IDX_WAVES) {
-            uint32_t* my_seen = seen + wave * 64; /* one bit per template k-mer */
-            my_seen[lane] = 0;
+            uint32_t* my_seen = seen + wave * seen_words; /* one bit per template k-mer */
+            if ((uint32_t)lane < seen_words) my_seen[lane] = 0;
             cw_wave_sync();
             if (stw) support_seq((cw_l32)(s_words + s_off[s]), s_len[s], s, my_seen);
             else support_seq((cw_g32)(b.bases + b.seq_word_off[s0 + s]), stm ? s_len[s] : b.seq_len[s0 + s], s, my_seen);

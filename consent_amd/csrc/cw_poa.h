@@ -608,9 +608,15 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
 
 #include "cw_poa_c.h"
 #ifndef CW_POA_LW
-#define CW_POA_LW (!CW_POA_SW) /* round 6, tier "LW": tier-L tasks whose members are wide on average run on the four waves of a work-group (cw_poa_w.h; a second
-                                  instance of the tier-L kernel on its own list and stream); 0 = every tier-L task on one wave, as through round 5
-                                  (tests/test_gpu_variants.py; the local alignment mode has no multi-wave fill) */
+#define CW_POA_LW 0 /* round 6, tier "LW" (-DCW_POA_LW=1; not with the local alignment mode): tier-L tasks whose members are wide on average run on the four waves
+                       of a work-group (cw_poa_w.h; a second instance of the tier-L kernel on its own list and stream).  Bit-identical (tests/test_gpu_variants.py)
+                       and OFF: measured on one box at depth 150 (three runs each, alternating), a batch alone on the GPU takes 76.3 -> 70.6 ms with it (the
+                       batch's eight such tasks: the longest 26 -> 19 ms; tier L's kernel 60 -> 40 ms), and the step with three batches in flight 52.5 -> 53.1 ms
+                       (four engines: 50.8 -> 52.1): the fifth stream and the four-wave work-groups cost the other tiers more than the stragglers' tail,
+                       which other batches' work fills anyway, was costing.  The native driver's runs did not move (0.92-1.24 s either way). */
+#endif
+#if CW_POA_LW && CW_POA_SW
+#error "cw_poa.h: tier LW (cw_poa_w.h) has no local alignment mode"
 #endif
 #define CW_POAL_MW 4 /* waves of such a work-group */
 #if CW_POA_LW

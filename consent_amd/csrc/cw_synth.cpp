@@ -4,7 +4,7 @@
 #include "cw_private.h"
 
 static int check_spec(const cw_synth_spec* s) {
-    if (!s || s->window_len < 16 || s->window_len > 1000) return CW_E_INVALID;
+    if (!s || s->window_len < 16 || s->window_len > 2100) return CW_E_INVALID;
     if (s->sub_w + s->ins_w + s->del_w == 0 || s->err_permille > 500) return CW_E_INVALID;
     if ((uint64_t)s->seq_stride_words * 16 < (uint64_t)s->window_len + 24) return CW_E_INVALID;
     return CW_OK;

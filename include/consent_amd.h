@@ -118,7 +118,8 @@ void cw_destroy(cw_engine* e);
  * templates of up to 2048 + k - 1 bases; its scratch plan provides for 1024 k-mers per template unless told otherwise -- call this once, before the
  * first run, with the longest template the engine will see (the window size): anchor blocks, segment slots and the chain kernel's work-groups are then
  * sized for it (up to twice the scratch).  Without it, windows with longer templates may stop on a capacity (status 2: CW_WHY_SETUP / CW_WHY_ANCHORS),
- * never with a wrong result.  CW_E_INVALID beyond 2048 + k - 1 (such a window's status is 2, CW_WHY_TEMPLATE).  cw_run_correction calls it itself. */
+ * never with a wrong result.  CW_E_INVALID beyond 2048 + k - 1 (such a window's status is 2, CW_WHY_TEMPLATE).  A caller whose windows are all SHORTER than
+ * 1024 + k - 1 bases may say so too: the plan shrinks with the number (anchor blocks, segment slots, arena).  cw_run_correction calls it with its window size. */
 int cw_configure(cw_engine* e, uint32_t max_template_len);
 
 /* Largest batch one call accepts (per-window offsets into the engine's scratch are 32-bit); CW_E_INVALID beyond it.  Split larger

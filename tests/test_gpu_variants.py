@@ -4,9 +4,9 @@
   -DCW_POA_CODES=0  tiers S / M1 on the matrix path (fill writes the DP matrix, the traceback reads tiles of it back) instead of the
                     recorded-decision path of cw_poa_c.h,
   -DCW_M2_CODES=1   tier M2 on the recorded-decision path too,
-  -DCW_POA_LW=0     no tier LW: every tier-L task on one wave, as through round 5 (the default since round 6 runs the tier-L tasks whose members are wide
-                    on average on the four waves of a work-group, the chunks of a wide packed row pipelined by rows: cw_poa_w.h),
-  -DCW_POALW_MIN_MEAN=1 -DCW_POALW_MIN_MEMBERS=2   EVERY tier-L task in tier LW (narrow members too: the one-chunk rows stay on wave 0),
+  -DCW_POA_LW=1     tier LW (round 6, cw_poa_w.h): the tier-L tasks whose members are wide on average on the four waves of a work-group, the chunks of a wide
+                    packed row pipelined by rows (measured: a batch alone on the GPU 7 % faster, the step with batches in flight 1-2 % slower: off by default),
+  ... -DCW_POALW_MIN_MEAN=1 -DCW_POALW_MIN_MEMBERS=2   EVERY tier-L task in tier LW (narrow members too: the one-chunk rows stay on wave 0),
   -DCW_POA_GROUP_FILL=0  tiers M2 / L fill every member on its own (round 5's default fills up to four consecutive short members together),
   -DCW_POA_VPROBE=0 the tile traceback without the look down the column inside a long vertical run,
   -DCW_Q_CODES=0    tier Q with the DP matrix in LDS and a walk over its values (rounds 3-4, cw_poa_q0.h) instead of recorded decisions,
@@ -19,7 +19,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "lwoff": ["-DCW_POA_LW=0"], "lwall": ["-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
+VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "lw": ["-DCW_POA_LW=1"], "lwall": ["-DCW_POA_LW=1", "-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
 
 CHILD = r"""
 import os, sys
