@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # Must be in the environment before the HIP runtime starts (i.e. before torch is imported): HIP multiplexes a process's streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4).  Three engines have twelve kernel streams (main + three tier streams each); with four
 # queues a stream of the second engine lands behind the first engine's long-running tier-L kernel and the batches do not overlap.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # (round 6: four engines, sixteen kernel streams + the process's own: 24 queues -- 49.1-51.6 ms per step against 52.4-54.7 with three engines on 16)
 
 WORKLOADS = {
     # name: (depth, maxMSA, windows per step per GPU)
@@ -161,7 +161,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="windows timed on the CPU oracle (rank 0, N=1); 0 disables")
     # (round 5: three -- four alternating runs each on one box: 53.4 52.8 54.2 52.2 ms per step with two engines and eight queues, 52.0 52.5 52.9 51.7 with three
     # and sixteen; the native driver takes a third worker per device on long runs for the same reason)
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "3")),
+    # (round 6: four, with 24 hardware queues -- four alternating runs each on one box: 52.4 54.7 53.0 53.1 ms per step with three engines on 16 queues, 50.6 49.1 49.5 51.6 with
+    # four on 24, 51.5 51.9 52.2 50.3 with four on 16; the scratch plan went from 24 to 18 GB an engine in the same round)
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "4")),
                     help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
     ap.add_argument("--alone-steps", type=int, default=3, help="untimed steps after the timed region with ONE batch in flight: per-kernel HIP-event times that are work, not waiting (roofline.launch_ms)")
     ap.add_argument("--pcie-engines", type=int, default=2, help="engines the PCIe-inclusive leg spreads its host batches over")
@@ -198,6 +200,18 @@ def main():
                 }
             except (SystemExit, Exception) as exc:  # the contract line must survive a failure of the extra leg
                 driver_leg = {"error": str(exc)[-400:]}
+            # ... and on EIGHT copies of that set (2.6e6 windows): the set on which every device of an 8-GPU node still gets full-size jobs -- the x1 set is
+            # 0.8 s of work for ONE GPU, and a fresh process spends 0.5 s starting the runtime and loading the code object whatever N is (round 6)
+            if args.driver_leg >= 1 and isinstance(driver_leg, dict) and "error" not in driver_leg:
+                try:
+                    da8 = argparse.Namespace(**vars(args))
+                    da8.driver_copies, da8.driver_reps = 8, 1
+                    d8 = driver_measure(da8, dry_reps=1)
+                    driver_leg["x8"] = {"windows_per_s": d8["value"], "s_total": d8["s_inside_cw_run_correction"], "wall_s_process": d8["wall_s_process"], "windows": d8["config"]["windows"],
+                                        "jobs": d8["config"]["jobs"], "workers": d8["config"]["workers"], "ms_index": d8["ms_index"], "ms_engines": d8["ms_engines"],
+                                        "workload": d8["config"]["workload"], "scaling": "strong"}
+                except (SystemExit, Exception) as exc:
+                    driver_leg["x8"] = {"error": str(exc)[-400:]}
 
     import torch
     import torch.distributed as dist

@@ -58,7 +58,7 @@ int main(int argc, char* argv[]) {
        long-running tier-L kernel (E. coli-scale run: 1.68-2.84 s with 4 queues, 1.57-1.58 s with 12; sixteen since a long run takes three
        workers per device -- measured equal to twelve on the eight-copy set).  Set here, in the executable and
        before anything touches HIP -- a library call must not change its host process's environment; a caller's own value is kept. */
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
     std::string alignment_file, reads_file, proof_file, ignored;
     cw_driver_args a{};
     a.min_support = 3; a.max_support = 1000; a.max_msa = 150; a.window_size = 500; a.mer_size = 9; a.common_kmers = 8;  /* src/main.cpp:17-26 */

@@ -14,7 +14,7 @@ import tempfile
 
 # Before the HIP runtime starts (the library is loaded lazily, below): the driver's two workers per GPU have a dozen streams and HIP spreads a
 # process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  The host process sets it, not the library; a caller's own value wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .engine import EngineError, load_library  # noqa: E402
 

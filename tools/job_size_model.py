@@ -46,6 +46,34 @@ if os.environ.get("JSM_MODE") == "parts":
         print(json.dumps({"set": "x1 / %d" % n, "windows": int(st.windows), "jobs": int(st.jobs), "s_total": st.ms_total / 1e3, "s_index": st.ms_index / 1e3,
                           "modelled_T_N": t_n, "speed_up_over_one_gpu": full.ms_total / 1e3 / t_n}), flush=True)
     sys.exit(0)
+if os.environ.get("JSM_MODE") == "sweep1":
+    # Round 6: the whole x1 set on one GPU under (workers per device, windows per job): is the driver's choice (two workers, jobs of 32 768) still the best
+    # one now that an engine's plan is a quarter smaller and the bench runs four batches at a time?
+    for workers in (2, 3, 4):
+        for per_job in (0, 32768, 24576, 16384, 12288, 8192):
+            if per_job == 0 and workers != 2:
+                continue
+            if per_job == 0:
+                os.environ.pop("CW_WORKERS_PER_DEVICE", None)
+            else:
+                os.environ["CW_WORKERS_PER_DEVICE"] = str(workers)
+            st = run(fa, paf, None, per_job)
+            print(json.dumps({"set": "x1", "workers": "driver's own" if per_job == 0 else workers, "windows_per_job": per_job or "driver's own", "jobs": int(st.jobs), "s_total": round(st.ms_total / 1e3, 4),
+                              "s_after_index": round((st.ms_total - st.ms_index) / 1e3, 4), "windows_per_s": round(st.windows / (st.ms_total / 1e3))}), flush=True)
+    os.environ.pop("CW_WORKERS_PER_DEVICE", None)
+    sys.exit(0)
+if os.environ.get("JSM_MODE") == "parts8":
+    # The x8 set (eight copies of the x1 set: 2.6e6 windows, full-size jobs on every device up to N = 8): what one of N GPUs sees is 8 / N copies.
+    # T(N) = read index of the whole x8 set + the part's time after its own index.
+    res = {}
+    for copies in (8, 4, 2, 1):
+        fa_c, paf_c = pb.replicate(fa, paf, copies)
+        st = run(fa_c, paf_c, None, 0)
+        res[copies] = st
+        t_n = res[8].ms_index / 1e3 + (st.ms_total - st.ms_index) / 1e3
+        print(json.dumps({"set": "x8 / %d" % (8 // copies), "copies_per_device": copies, "windows": int(st.windows), "jobs": int(st.jobs), "s_total": round(st.ms_total / 1e3, 4),
+                          "s_index": round(st.ms_index / 1e3, 4), "modelled_T_N": round(t_n, 4), "speed_up_over_one_gpu": round(res[8].ms_total / 1e3 / t_n, 3)}), flush=True)
+    sys.exit(0)
 if os.environ.get("JSM_MODE") == "sweep":
     # Round 6: what one of N GPUs sees of the x1 set (a set of 1/N of the genome), under every (workers per device, windows per job) the driver could
     # choose -- the table its own choice (cw_driver.cpp: workers by windows per device, eight jobs per device) is checked against.
