@@ -517,10 +517,11 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
            run -- no longer hide behind one other job: four workers per device then (measured on one GPU with jobs of 5000 windows:
            1.97e5 windows/s with two workers, 2.36e5 with three, 2.77e5 with four; with jobs of 32768: 3.3e5 / 2.8e5 / 2.8e5) */
         const uint64_t est_per_dev = (tpl_bases / (a->window_size - a->window_overlap) + 1) / (uint64_t)(n_dev < want ? n_dev : want);
-        int per_dev = est_per_dev < 100000ull ? (int)std::min<uint64_t>(4, est_per_dev / 4096 + 1) : 2; /* (no more workers than jobs: an engine costs ~60 ms and 1.3 GB to set up) */
-        /* a long run (dozens of jobs per device) takes a third worker: with round 5's shorter re-assembly two jobs are more often both in a tail
-           (tier L's longest tasks, the longest read) -- 80 jobs of 32768 on one GPU: 6.18 / 6.57 s with two workers, 5.89 / 5.94 with three,
-           6.18 / 6.23 with four; the 10-job set is no faster for it */
+        /* round 6: two workers also for a small per-device load (four from round 4 on, when such a run was cut into jobs of ~5000 windows).  With three larger jobs
+           per device (below) two workers are as fast (a device's 4.2e4 windows: 0.134-0.138 s with two workers on two or three jobs, 0.133-0.134 s with four
+           on two or four; profiles/r06_job_size_sweep.txt) and set up half the engines: an engine's scratch is ~10 GB, and obtaining that much new device
+           memory is where a fresh process can stall for a second or more (hipMalloc: 0.2 ms or 0.5-1.9 s a call) */
+        int per_dev = 2; /* (never more workers than jobs is implied: three jobs per device at least) */
         if (est_per_dev >= 1000000ull) per_dev = 3;
         if (const char* env = getenv("CW_WORKERS_PER_DEVICE")) { const int v = atoi(env); if (v >= 1 && v <= 8) per_dev = v; }
         for (int k = 0; k < per_dev; ++k) for (int d = 0; d < n_dev && d < want; ++d) devs.push_back(d);
@@ -578,12 +579,12 @@ extern "C" int cw_run_correction(const cw_driver_args* a, int out_fd, cw_driver_
     uint32_t per_job = a->windows_per_batch ? (a->windows_per_batch > CW_MAX_BATCH_WINDOWS ? CW_MAX_BATCH_WINDOWS : a->windows_per_batch) : 32768u;
     if (!a->windows_per_batch) {
         const uint64_t est_windows = tpl_bases / (a->window_size - a->window_overlap) + 1;
-        /* jobs per device.  Eight (four per worker with two workers) while a device gets 1e5 windows or more; FOUR below that (round 6): a device that gets
+        /* jobs per device.  Eight (four per worker with two workers) while a device gets 1e5 windows or more; THREE below that (round 6): a device that gets
            4e4 windows -- the E. coli-scale set on eight GPUs -- ran its nine jobs of 5 200 windows on four workers in 0.234 s, and four jobs of 10 400 on the
            same four workers in 0.134 s (two jobs of 20 800 on two: 0.138; tools/job_size_model.py JSM_MODE=sweep, profiles/r06_job_size_sweep.txt): a job's
            fixed costs -- its longest POA task, its longest read, its launches and synchronisation points -- are paid once per job and worker, and small
            jobs do not fill the GPU while they are paid */
-        const uint64_t jobs_per_dev = est_windows / n_distinct_devs < 100000ull ? 4ull : 8ull;
+        const uint64_t jobs_per_dev = est_windows / n_distinct_devs < 100000ull ? 3ull : 8ull;
         const uint64_t want = est_windows / (jobs_per_dev * n_distinct_devs) + 1;
         if (want < per_job) per_job = (uint32_t)(want < 4096 ? 4096 : want);
     }

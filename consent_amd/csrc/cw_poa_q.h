@@ -104,6 +104,9 @@ typedef PoaQT<16, CW_POAQ_NC, CW_POAQ_EC, CW_POAQ_RING, false> PoaQ16;
 #endif
 static_assert(PoaQ16::TASK_BYTES * 4 * CW_POAQ_WAVES <= 163840, "tier Q: CW_POAQ_WAVES waves of four tasks fit a CU's LDS");
 static_assert(4 * CW_POA_SMAX * (CW_POAQ_NC + 64) <= CW_POA_I16_BOUND, "include/cw_policy.h \"Bounds\": tier Q's recorded decisions (values x 4 in 16-bit halves)");
+#ifndef CW_POAQ_REPLAY
+#define CW_POAQ_REPLAY 1 /* 0: every member is aligned, as through round 5 (tests/test_gpu_variants.py) */
+#endif
 #ifndef CW_POAQ_ROUTE_NODES
 #define CW_POAQ_ROUTE_NODES 60 /* tasks expected to stay below this many nodes come here (cw_chain.h; the estimate overshoots by ~10 %) */
 #endif
@@ -403,8 +406,32 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
     const unsigned lt_mask = (1u << gl) - 1u;
 
     if (t.n_members > 255u) return 2; /* coverage counts and edge weights are bytes here */
+    /* Round 6, the replay of a repeated member (CW_POAQ_REPLAY).  A member that is, base for base, the member aligned just before it -- and that one changed nothing
+       in the graph but coverage counts -- meets the same graph with the same bases: the same fill, the same walk back, the same path.  Its merge is the coverage
+       counts of that path once more (M.pcur still holds it, M.sq the bases), and the alignment is not run.  Measured on the checker (a scratch build of the
+       restatement over the bench piles, every replayed path compared with the one the alignment gives: 0 of 14 000 differ): 38 % of this tier's members at depth
+       150 -- the error-free copy of a short piece comes again and again.  The four tasks of a wave share one instruction stream, so a group does not skip a round
+       the others run: it takes its repeated members in a short loop of its own HERE and joins the round with the first member that needs an alignment.
+       (Not under the heaviest-bundle policy: a replay would have to raise the path's edge weights too.) */
+    bool prev_clean = false; /* the member before this one was aligned and added neither a node nor an edge */
+    int prev_L = -1;
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
-        const PoaMember pm = sc.members[t.member_off + mi];
+        PoaMember pm = sc.members[t.member_off + mi];
+#if CW_POAQ_REPLAY
+        if (!CW_CONS_HEAVIEST_BUNDLE) {
+            while (prev_clean && (int)pm.len == prev_L) {
+                const uint32_t* words_ = b.bases + b.seq_word_off[pm.seq];
+                bool same = true;
+                for (int j = gl; j < prev_L; j += GW) same = same && M.sq[j] == (uint8_t)cw_base_at(words_, pm.start + j);
+                if (g_ballot<T>(!same) != 0u) break;
+                for (int j = gl; j < prev_L; j += GW) { const int cur = M.pcur[j]; M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1); } /* (a path visits a node once; lane j owns position j, as in the merge) */
+                nseq++;
+                if (++mi >= t.n_members) break;
+                pm = sc.members[t.member_off + mi];
+            }
+            if (mi >= t.n_members) break;
+        }
+#endif
         const int L = (int)pm.len;
         if ((uint32_t)L > (uint32_t)T::LC) return 2;
         {
@@ -413,6 +440,7 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
         }
         cw_wave_sync();
         nseq++;
+        prev_clean = false; prev_L = L;
         if (n == 0) { /* first member: a chain */
             if ((uint32_t)L > (uint32_t)T::NC || (uint32_t)L > (uint32_t)T::EC) return 2;
             for (int j = gl; j < L; j += GW) {
@@ -478,6 +506,7 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
         {
             const int n_old = n;
             const int chunks = (L + GW - 1) / GW;
+            bool edges_added = false;
             int next_rank = -1;
             for (int c = chunks - 1; c >= 0; --c) {
                 const int j = c * GW + gl;
@@ -612,9 +641,10 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
                     M.indeg[cur] = (uint8_t)(M.indeg[cur] + 1);
                     M.has_out[head] = 1;
                 }
-                if (total) { ne += total; meta_ok = false; }
+                if (total) { ne += total; meta_ok = false; edges_added = true; }
             }
             cw_wave_sync();
+            prev_clean = n == n_old && !edges_added; /* nothing but coverage counts changed: the next member may be a replay of this one */
         }
         POAQ_PROF(3);
     }

@@ -43,6 +43,19 @@ def test_consent_correction_with_the_wrappers_argv(tmp_path):
     assert out.returncode == 0 and out.stdout == got, out.stderr[-1500:]
 
 
+def test_windows_of_1500_bases_run_end_to_end(tmp_path):
+    """`-l 1500` (round 6: the reference takes any window size, src/main.cpp:46-47; through round 5 a template beyond 1032 bases stopped its window).  The
+    driver tells its engines the window size (cw_configure), the index kernel holds 2048 template k-mers, the re-assembly slices of 1600 bases; with
+    k = 12, as anybody would choose for such windows, the FASTA equals the loop assembled from the oracle's pieces."""
+    fa, paf = make_dataset(tmp_path, 43, n_reads=40, glen=12000, rate=0.08, read_len=(3000, 7000))
+    argv = ["-a", paf, "-s", 3, "-S", 150, "-l", 1500, "-k", 12, "-c", 8, "-A", 2, "-f", 4, "-m", 50, "-j", 1, "-r", fa, "-M", 150, "-p", str(tmp_path)]
+    got, err = run_bin("CONSENT-correction", argv)
+    want = oracle_pipeline(fa, paf, min_support=3, max_support=150, window_size=1500, mer_size=12, common_kmers=8, min_anchors=2, solid_thresh=4, window_overlap=50, max_msa=150)
+    assert len(want) > 10
+    assert got == fasta(want)
+    assert sum(c.isupper() for _, s_ in want for c in s_) > 20000  # windows were corrected, not passed through
+
+
 def make_polishing_dataset(tmp_path, seed, glen=5200, n_reads=40, rate=0.1, mix=(0.3, 0.3), read_len=(900, 2400), cuts=((0, 2600), (2500, 5200))):
     rng = random.Random(seed)
     genome = rand_seq(rng, glen)

@@ -12,6 +12,7 @@ bash tools/verify_codes.sh > $EV/verify.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $EV/bench_r06_pacbio_d150_msa150.json 2> $EV/bench_d150.err
 python bench.py --steps 20 --warmup 5 --workload pacbio_d30_msa20 > $EV/bench_r06_pacbio_d30_msa20.json 2> $EV/bench_d30.err
 python bench.py --steps 10 --warmup 3 --engines 1 --cpu-sample 0 --pcie-steps 0 --driver-leg 0 > $EV/bench_r06_pacbio_d150_msa150_one_engine.json 2>/dev/null
+python bench.py --steps 10 --warmup 3 --engines 1 --windows 2048 --cpu-sample 0 --pcie-steps 0 --driver-leg 0 > $EV/bench_r06_pacbio_d150_msa150_one_engine_2048.json 2>/dev/null
 for wl in pacbio_d150_msa150 pacbio_d30_msa20; do
   W=16384
   bash tools/profile_r03.sh r06 $wl all > $EV/prof_$wl.log 2>&1
@@ -29,7 +30,12 @@ python bench.py --mode driver --gpus 1 --driver-copies 1 > $EV/driver_r06_x1.jso
 python bench.py --mode driver --gpus 1 --driver-copies 8 > $EV/driver_r06_x8.json 2> $EV/driver_x8.err
 python tools/job_size_model.py > $EV/r06_job_size_model.txt 2>&1
 JSM_MODE=parts python tools/job_size_model.py > $EV/r06_job_size_parts.txt 2>/dev/null
+JSM_MODE=parts8 python tools/job_size_model.py > $EV/r06_job_size_parts_x8.txt 2>/dev/null
+JSM_MODE=sweep1 python tools/job_size_model.py > $EV/r06_job_size_sweep_x1.txt 2>/dev/null
 python tools/codeobj_audit.py > $EV/r06_codeobj.txt 2>&1
+python tools/plan_sizes.py > $EV/r06_plan_sizes.txt 2>&1
+CW_TASK_TRACE=1 python tools/task_trace.py > $EV/r06_task_trace_16384.txt 2>&1
+CW_TRACE_WINDOWS=2048 CW_TASK_TRACE=1 python tools/task_trace.py > $EV/r06_task_trace_2048.txt 2>&1
 unset CW_KEEP_DATA
 bash tools/profile_pipeline.sh r06 > $EV/pipeline.log 2>&1
 python - <<'PY' > $EV/r06_pipeline.txt 2>&1
