@@ -59,8 +59,8 @@
 /* tier G: everything in a per-wave global slab (int32 cells) */
 #define CW_POAB_NC 4096 /* (2048 until round 5: the graphs that stopped a window in the fuzzers were all this tier's) */
 #define CW_POAB_EC 8192
-#define CW_POAB_LC 1023
-#define CW_POAB_HC ((CW_POAB_NC + 1) * (CW_POAB_LC + 1))
+#define CW_POAB_LC 2047 /* round 6 (1023 through round 5): a window of 1500 bases whose chain is sparse has pieces of more than 1023 bases; the cell budget is what it was */
+#define CW_POAB_HC ((CW_POAB_NC + 1) * 1024) /* cells of the int32 matrix: rows x (bases + 1) of an alignment must fit (4096 nodes against 1023 bases, 2047 against 2047) */
 
 /* bytes of the graph part of a slab when every array lives in it (tiers S and G) */
 #define CW_POA_EW_BYTES(EC) (CW_CONS_HEAVIEST_BUNDLE ? 2 * (EC) : 0) /* edge weights, kept only under the heaviest-bundle policy (cw_policy.h) */
@@ -907,7 +907,8 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
             else if (cols <= 128) poa_fill<HT, 2, PK == 2>(M, n, cols, lane, use_dirs);
             else if (cols <= 256) poa_fill<HT, 4, PK == 2>(M, n, cols, lane, use_dirs);
             else if (cols <= 512) poa_fill<HT, 8, PK == 2>(M, n, cols, lane, use_dirs);
-            else poa_fill<HT, 16, PK == 2>(M, n, cols, lane, use_dirs);
+            else if (cols <= 1024) poa_fill<HT, 16, PK == 2>(M, n, cols, lane, use_dirs);
+            else poa_fill<HT, 32, PK == 2>(M, n, cols, lane, use_dirs); /* tier G only: members of up to 2047 bases (round 6) */
         }
         POA_PROF(1);
         if (PK == 2 && LCAP > 511 && lane == 0) { atomicAdd(&sc.ctr->prof[46], (unsigned long long)n * (unsigned long long)nch); atomicAdd(&sc.ctr->prof[47], (unsigned long long)n); }
