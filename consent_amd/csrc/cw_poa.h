@@ -607,6 +607,9 @@ __device__ __forceinline__ void poa_fill_pk4(const PoaMem<int16_t>& M, const int
 }
 
 #include "cw_poa_c.h"
+#ifndef CW_POA_REPLAY
+#define CW_POA_REPLAY 1 /* 0: every member is aligned, as through round 5 (tests/test_gpu_variants.py builds both replay switches off) */
+#endif
 #ifndef CW_POA_LW
 #define CW_POA_LW 0 /* round 6, tier "LW" (-DCW_POA_LW=1; not with the local alignment mode): tier-L tasks whose members are wide on average run on the four waves
                        of a work-group (cw_poa_w.h; a second instance of the tier-L kernel on its own list and stream).  Bit-identical (tests/test_gpu_variants.py)
@@ -725,18 +728,41 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
     bool meta_ok = false;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int gf_left = 0, gf_idx = 0; /* group fill (poa_fill_pk4): members behind the current one whose rows are already in the matrix; the current one's place in the group */
+    /* the replay of a repeated member (round 6; cw_poa_q.h has the same in its per-group form): a member that is, base for base, the member aligned just before
+       it -- which changed nothing in the graph but coverage counts -- would make the same fill, walk and path: its merge is that path's coverage counts
+       once more (M.pcur, M.sq still hold path and bases).  Measured on the checker: half of the members of the large tiers' tasks (the short ragged pieces of a
+       window's first and last segment), 2 % of tier S's.  Not under the heaviest-bundle policy (the path's edge weights would have to go up too). */
+    bool prev_clean = false; /* the member before this one was aligned and added neither a node nor an edge */
+    int prev_L = -1;
 
     for (uint32_t mi = 0; mi < t.n_members; ++mi) {
         const PoaMember pm = sc.members[t.member_off + mi];
         const int L = __builtin_amdgcn_readfirstlane((int)pm.len); /* sizes steer every loop below: keep them in scalar registers */
         n = __builtin_amdgcn_readfirstlane(n); ne = __builtin_amdgcn_readfirstlane(ne);
         if ((uint32_t)L > M.l_cap) return 2;
+#if CW_POA_REPLAY
+        if (!CW_CONS_HEAVIEST_BUNDLE && prev_clean && L == prev_L) {
+            const uint32_t* words_ = b.bases + b.seq_word_off[pm.seq];
+            bool same = true;
+            for (int j = lane; j < L; j += 64) same = same && M.sq[j] == (uint8_t)cw_base_at(words_, pm.start + j);
+            if (__ballot(!same) == 0ull) {
+                for (int j = lane; j < L; j += 64) { const int cur = M.pcur[j]; M.ncov[cur] = (uint16_t)(M.ncov[cur] + 1); } /* (a path visits a node once; lane j owns position j, as in the merge) */
+                nseq++;
+                if constexpr (CW_POA_GROUP_FILL != 0 && PK != 0 && CM == 0 && sizeof(HT) == 2 && LCAP >= 511) {
+                    if (gf_left > 0 && meta_ok) { ++gf_idx; --gf_left; } /* its rows of a group fill stay unread */
+                }
+                cw_wave_sync();
+                continue;
+            }
+        }
+#endif
         {
             const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
             for (int j = lane; j < L; j += 64) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
         }
         cw_wave_sync();
         nseq++;
+        prev_clean = false; prev_L = L;
         if (n == 0) { /* first member: a chain */
             if ((uint32_t)L > M.n_cap || (uint32_t)L > M.e_cap) return 2;
             for (int j = lane; j < L; j += 64) {
@@ -1162,6 +1188,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         /* ---- merge the path into the graph: one lane per sequence position ---- */
         {
             const int n_old = n;
+            bool edges_added = false;
             const int chunks = (L + 63) >> 6;
             /* pass A (last chunk first): resolve existing nodes, find the rank slot of fresh ones */
             int next_rank = -1; /* rank aligned to the nearest later position that has one */
@@ -1303,9 +1330,10 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
                     M.indeg[cur] = (uint16_t)(M.indeg[cur] + 1);
                     M.has_out[head] = 1;
                 }
-                if (total) { ne += total; meta_ok = false; }
+                if (total) { ne += total; meta_ok = false; edges_added = true; }
             }
             cw_wave_sync();
+            prev_clean = n == n_old && !edges_added; /* nothing but coverage counts changed: the next member may be a replay of this one */
         }
         POA_PROF(3);
     }

@@ -9,7 +9,7 @@
   ... -DCW_POALW_MIN_MEAN=1 -DCW_POALW_MIN_MEMBERS=2   EVERY tier-L task in tier LW (narrow members too: the one-chunk rows stay on wave 0),
   -DCW_POA_GROUP_FILL=0  tiers M2 / L fill every member on its own (round 5's default fills up to four consecutive short members together),
   -DCW_POA_VPROBE=0 the tile traceback without the look down the column inside a long vertical run,
-  -DCW_POAQ_REPLAY=0  tier Q aligns every member (round 6's default does not align a member that repeats the one before it: cw_poa_q.h),
+  -DCW_POAQ_REPLAY=0 -DCW_POA_REPLAY=0  every tier aligns every member (round 6's default does not align a member that repeats the one before it: cw_poa_q.h),
   -DCW_Q_CODES=0    tier Q with the DP matrix in LDS and a walk over its values (rounds 3-4, cw_poa_q0.h) instead of recorded decisions,
 each compared with the oracle on piles of several depths (all tiers)."""
 import os
@@ -20,7 +20,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "noreplay": ["-DCW_POAQ_REPLAY=0"], "lw": ["-DCW_POA_LW=1"], "lwall": ["-DCW_POA_LW=1", "-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
+VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "noreplay": ["-DCW_POAQ_REPLAY=0", "-DCW_POA_REPLAY=0"], "lw": ["-DCW_POA_LW=1"], "lwall": ["-DCW_POA_LW=1", "-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
 
 CHILD = r"""
 import os, sys
