@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--engines", type=int, default=int(os.environ.get("CW_BENCH_ENGINES", "4")),
                     help="engines per GPU taking the steps in turn (each has its own scratch and streams): batch n+1's index/chain kernels fill the CUs that the tail of batch n's POA stage leaves idle")
     ap.add_argument("--alone-steps", type=int, default=3, help="untimed steps after the timed region with ONE batch in flight: per-kernel HIP-event times that are work, not waiting (roofline.launch_ms)")
-    ap.add_argument("--pcie-engines", type=int, default=2, help="engines the PCIe-inclusive leg spreads its host batches over")
+    ap.add_argument("--pcie-engines", type=int, default=3, help="engines the PCIe-inclusive leg spreads its host batches over (round 6: three, six host batches in flight)")
     ap.add_argument("--pcie-steps", type=int, default=-1, help="batches timed through cw_submit/cw_wait from pinned host memory (rank 0, N=1); 0 disables")
     args = ap.parse_args()
 
@@ -495,7 +495,8 @@ def main():
         ne_p = max(1, min(ne, args.pcie_engines))
         # host batches in flight.  Round 5, one box: two on one engine 2.41e5 windows/s, two over two engines 2.74e5, three over two 2.89e5, three over three 2.72e5
         # (rounds 2-3, with longer steps and the results copied back whole: four over two engines 1.59e5, two over two 1.75e5, two on one 1.87e5)
-        depth_p = int(os.environ.get("CW_BENCH_PCIE_DEPTH", "3" if ne_p >= 2 else "2"))
+        # (round 6, one box, 16 batches each: two engines / three in flight 2.58e5 windows/s, two / four 2.83e5, three / four 2.85e5, three / six 3.00e5, four / six 2.96e5)
+        depth_p = int(os.environ.get("CW_BENCH_PCIE_DEPTH", str(2 * ne_p)))
         for _ in range(depth_p):
             arrs = (np.zeros(n_win * cons_cap, np.uint8), np.zeros(n_win, np.uint32), np.zeros(n_win, np.uint8), np.zeros(n_win * solid_cap, np.uint32), np.zeros(n_win, np.uint32))
             res_h.append((arrs, Result(arrs[0].ctypes.data, coff_h.ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, soff_h.ctypes.data, arrs[4].ctypes.data)))
@@ -509,8 +510,12 @@ def main():
         def wait(tk):
             assert lib.cw_wait(engines[tk[0]].handle, tk[1]) in (0, -4)
 
-        for i in range(ne_p):  # warm-up: allocations, pinned staging (per engine)
-            wait(submit(i))
+        # warm-up: allocations and pinned staging of EVERY slot the timed loop will use (round 6: one submit per engine left the engines' second slots to be
+        # allocated inside the timed region -- and obtaining new device memory can stall a call for a second)
+        for _ in range(2):
+            warm = [submit(i) for i in range(depth_p)]
+            for tk in warm:
+                wait(tk)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         flight = []
