@@ -1690,7 +1690,8 @@ __device__ __forceinline__ uint32_t cw_sort_class(uint32_t n_members, uint32_t l
         /* round 5: a wave's four tasks end when its longest one does, and a task's time is members x rows x ...: since tier Q also takes the deep piles'
            tasks (up to maxMSA members), the member count comes first -- eight classes, roughly geometric -- then the longest member in steps of two */
         /* (round 6, after the replay of repeated members: sixteen classes of member count and eight of length instead -- tier Q's kernel 8.86 -> 8.70 ms, the step
-           unchanged within its noise over four alternating runs: not kept) */
+           unchanged within its noise over four alternating runs: not kept.  Nor is the order by the members that are NOT repeats, counted by the chain kernel where
+           it writes the member lists: tier Q's kernel 8.85 -> 8.45 ms, the chain kernel 2.61 -> 3.05 ms for reading every member's bases: even) */
         const uint32_t mc = n_members < 4u ? 0u : n_members < 8u ? 1u : n_members < 12u ? 2u : n_members < 16u ? 3u : n_members < 24u ? 4u : n_members < 32u ? 5u : n_members < 64u ? 6u : 7u;
         return (CW_SORT_CLASSES - 1) - (mc * 16u + ((max_len < 32u ? max_len : 31u) >> 1));
 #endif
