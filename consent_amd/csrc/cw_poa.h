@@ -1508,7 +1508,7 @@ __global__ void __launch_bounds__(64 * CW_POA_WAVES, CW_S_EU) cw_poa_kernel(DevB
 /* MW > 1 (tier LW, TIER = 3): ONE task per work-group of MW waves -- wave 0 is "the" wave of the code below, the others serve its FILL commands
    (cw_poa_w.h) and share its LDS arrays; LIST: the routed list the kernel works through (tier LW: list 5, which the product build has free) */
 template <int NC, int EC, int LC, int WAVES, int TIER, int PASS, int MW = 1, int LIST = TIER>
-__global__ void __launch_bounds__(64 * WAVES * MW, TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1 and M2: four waves per SIMD (128 VGPRs; M1 at five spilled 17 VGPRs, round 6) */
+__global__ void __launch_bounds__(64 * WAVES * MW, TIER == 1 ? CW_M1_EU : TIER == 2 ? 4 : 1) /* M1 and M2: four waves per SIMD (128 VGPRs; M1 at five spilled 17 VGPRs, round 6; M2 spills 3 at four and none at three -- 148 VGPRs -- where a batch alone on the GPU measured 60.2-60.4 ms against 59.6-59.7: left at four) */
 cw_poa_slab_kernel(DevBatch b, DevScratch sc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
