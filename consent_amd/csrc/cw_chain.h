@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             if (g_n == 1u) {
                                 const uint32_t* words = b.bases + b.seq_word_off[s0 + q_fs[q]];
                                 const uint32_t fst = q_fst[q];
-                                for (uint32_t i = lane; i < g_mx; i += 64) sc.arena[g_off + i] = "ACGT"[cw_base_at(words, fst + i)];
+                                for (uint32_t i = lane; i < g_mx; i += 64) sc.arena[g_off + i] = CW_ACGT(cw_base_at(words, fst + i));
                                 if (lane == 0) { sc.seg_off[seg_base + g_seg] = g_off; sc.seg_len[seg_base + g_seg] = g_mx; }
                             } else {
                                 const uint32_t g_moff = (uint32_t)cw_lane_value((int)m_off, (int)q);
@@ -594,11 +594,11 @@ __global__ void __launch_bounds__(64 * CW_CH_WAVES) cw_chain_kernel(DevBatch b, 
                             if (n_mem == 0) { sc.seg_off[slot] = arena_base; sc.seg_len[slot] = 0; }
                             else if (by_anchor) {
                                 const uint32_t key = ckey[ca];
-                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = "ACGT"[(key >> (2 * (k - 1 - i))) & 3u];
+                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = CW_ACGT((key >> (2 * (k - 1 - i))) & 3u);
                                 sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx;
                             } else if (single && mx <= 16u) {
                                 const uint32_t* words = b.bases + b.seq_word_off[s0 + first_seq];
-                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = "ACGT"[cw_base_at(words, first_start + i)];
+                                for (uint32_t i = 0; i < mx; ++i) sc.arena[abs_off + i] = CW_ACGT(cw_base_at(words, first_start + i));
                                 sc.seg_off[slot] = abs_off; sc.seg_len[slot] = mx;
                             } else serial = true;
                         }

@@ -154,6 +154,9 @@ struct DevScratch {
 };
 
 /* ---- packed-sequence access ------------------------------------------------------------------- */
+/* the letter of a 2-bit code, by arithmetic (round 6: `"ACGT"[code]` is a load from constant memory -- s_getpc + global_load_ubyte -- and sat in front of a store in
+   every consensus loop and, on lane 0, in every step of the finish kernel's serial walks) */
+#define CW_ACGT(code) ((char)((0x54474341u >> (8u * ((uint32_t)(code) & 3u))) & 0xFFu))
 __device__ __forceinline__ uint32_t cw_base_at(const uint32_t* w, uint32_t j) { return (w[j >> 4] >> (30 - 2 * (j & 15))) & 3u; }
 
 /* k-mer starting at base p (k <= 16), str2num order (first base most significant). */

@@ -254,14 +254,14 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                 found = (ck == dst);
                 if (!found && !seen) {
                     if (plen + 2 > M.cb) return -1;
-                    if (lane == 0) { fin_vis_or(M, ci >> 5, 1u << (ci & 31)); M.path[plen] = "ACGT"[ck & 3u]; }
+                    if (lane == 0) { fin_vis_or(M, ci >> 5, 1u << (ci & 31)); M.path[plen] = CW_ACGT(ck & 3u); }
                     plen++; dist++;
                     cw_wave_sync();
                     n = fin_neighbours(c, ck, 0, nbk, nbi, lane);
                     it = 0;
                 } else if (found) {
                     if (plen + 2 > M.cb) return -1;
-                    if (lane == 0) M.path[plen] = "ACGT"[ck & 3u];
+                    if (lane == 0) M.path[plen] = CW_ACGT(ck & 3u);
                     plen++;
                 } else {
                     it++;
@@ -287,7 +287,7 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                         for (int q = 0; q < 4; ++q) { M.f_nbk[depth * 4 + q] = nbk[q]; M.f_nbi[depth * 4 + q] = nbi[q]; }
                         M.f_meta[depth] = (uint32_t)n | ((uint32_t)it << 8) | (plen << 16);
                         M.f_dist[depth] = dist; M.f_key[depth] = cur;
-                        M.path[plen] = "ACGT"[ck & 3u];
+                        M.path[plen] = CW_ACGT(ck & 3u);
                     }
                     cw_wave_sync();
                     depth++; plen++; dist++; cur = ck;
@@ -296,7 +296,7 @@ __device__ int fin_link(const FinCtx& c, const FinLds& M, uint32_t src, uint32_t
                     break;
                 } else if (found) {
                     if (plen + 2 > M.cb) return -1;
-                    if (lane == 0) M.path[plen] = "ACGT"[ck & 3u];
+                    if (lane == 0) M.path[plen] = CW_ACGT(ck & 3u);
                     plen++;
                 } else {
                     it++;
@@ -340,7 +340,7 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
         int n = fin_neighbours(c, key, 1, nbk, nbi, lane);
         while (n == 1 && dist < ext_len) { /* DBG.cpp:66 */
             key = nbk[0];
-            if (lane == 0) M.s[i - 1 - dist] = "ACGT"[key >> (2 * (k - 1))];
+            if (lane == 0) M.s[i - 1 - dist] = CW_ACGT(key >> (2 * (k - 1)));
             dist++;
             cw_wave_sync();
             n = fin_neighbours(c, key, 1, nbk, nbi, lane);
@@ -426,7 +426,7 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
                 const double t2 = __dadd_rn(t1, (double)gap);
                 const double t3 = __dadd_rn(t2, (double)k);
                 const uint32_t max_size = (uint32_t)t3;
-                for (uint32_t q = lane; q < k; q += 64) M.path[q] = "ACGT"[(src >> (2 * (k - 1 - q))) & 3u];
+                for (uint32_t q = lane; q < k; q += 64) M.path[q] = CW_ACGT((src >> (2 * (k - 1 - q))) & 3u);
                 cw_wave_sync();
                 const int r = fin_link(c, M, src, dst, max_size, lane);
                 if (r < 0) return -1;
@@ -471,7 +471,7 @@ __device__ int fin_polish(const FinCtx& c, FinLds& M, uint32_t len, int lane) {
         int n = fin_neighbours(c, key, 0, nbk, nbi, lane);
         while (n > 0 && dist < ext_len) { /* DBG.cpp:87 */
             key = nbk[0];
-            if (lane == 0) M.s[i + 1 + dist] = "ACGT"[key & 3u];
+            if (lane == 0) M.s[i + 1 + dist] = CW_ACGT(key & 3u);
             dist++;
             cw_wave_sync();
             n = fin_neighbours(c, key, 0, nbk, nbi, lane);
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(64 * WAVES, RETRY ? 4 : 1) /* (the second pass
             const uint32_t* words = b.bases + b.seq_word_off[s0];
             if (wi.tpl_len > o_cap) { status = CW_WIN_OVERFLOW; why = CW_WHY_OUT_CONS; }
             else {
-                for (uint32_t q = lane; q < wi.tpl_len; q += 64) out.cons[o_beg + q] = "ACGT"[cw_base_at(words, q)];
+                for (uint32_t q = lane; q < wi.tpl_len; q += 64) out.cons[o_beg + q] = CW_ACGT(cw_base_at(words, q));
                 len = (int)wi.tpl_len;
             }
         } else if (status == CW_WIN_CONSENSUS) {

@@ -700,7 +700,7 @@ __device__ __forceinline__ uint32_t poa_consensus_hb(const PoaMem<HT>& M, const 
     for (int v = end; v >= 0; v = pred[v] == CW_NONE16 ? -1 : (int)pred[v]) ++len;
     if (len <= t.out_cap) {
         uint32_t k = len;
-        for (int v = end; v >= 0; v = pred[v] == CW_NONE16 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = "ACGT"[M.nbase[v]];
+        for (int v = end; v >= 0; v = pred[v] == CW_NONE16 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = CW_ACGT(M.nbase[v]);
     }
     return len;
 }
@@ -1377,7 +1377,7 @@ __device__ __forceinline__ int poa_run(const PoaMem<HT>& M, const PoaTask& t, co
         }
         const unsigned long long bal = __ballot(emit >= 0);
         const uint32_t idx = out_len + (uint32_t)__popcll(bal & lt_mask);
-        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
+        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = CW_ACGT(emit);
         out_len += (uint32_t)__popcll(bal);
     }
 #endif

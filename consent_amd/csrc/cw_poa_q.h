@@ -236,7 +236,7 @@ __device__ __forceinline__ uint32_t poaq_consensus_hb(const PoaQ<T>& M, const in
     for (int v = end; v >= 0; v = pred[v] == CW_NONE8 ? -1 : (int)pred[v]) ++len;
     if (len <= t.out_cap) {
         uint32_t k = len;
-        for (int v = end; v >= 0; v = pred[v] == CW_NONE8 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = "ACGT"[M.nbase[v]];
+        for (int v = end; v >= 0; v = pred[v] == CW_NONE8 ? -1 : (int)pred[v]) sc.arena[t.out_off + --k] = CW_ACGT(M.nbase[v]);
     }
     return len;
 }
@@ -688,7 +688,7 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
         }
         const unsigned bal = g_ballot<T>(emit >= 0);
         const uint32_t idx = out_len + (uint32_t)__popc(bal & lt_mask);
-        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
+        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = CW_ACGT(emit);
         out_len += (uint32_t)__popc(bal);
     }
 #endif

@@ -390,7 +390,7 @@ __device__ int poaq_run(const PoaMem<int16_t>& M, const PoaTask& t, const DevBat
         }
         const unsigned bal = q_ballot(emit >= 0);
         const uint32_t idx = out_len + (uint32_t)__popc(bal & lt_mask);
-        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = "ACGT"[emit];
+        if (emit >= 0 && idx < t.out_cap) sc.arena[t.out_off + idx] = CW_ACGT(emit);
         out_len += (uint32_t)__popc(bal);
     }
 #endif

@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(SYS ? 64 * CW_STS_WAVES : 64 * WAVES, NCHK == 
                 clen = st_uni((a.batch.win_first_seq[w + 1] > ts) ? a.batch.seq_len[ts] : 0u);
                 if (clen > QMAX) { status = too_big; break; }
                 const uint32_t* tw = a.batch.bases + a.batch.seq_word_off[ts];
-                for (uint32_t x = lane; x < clen; x += 64) cur[x] = "ACGT"[cw_base_at(tw, x)];
+                for (uint32_t x = lane; x < clen; x += 64) cur[x] = CW_ACGT(cw_base_at(tw, x));
             }
             st_mem_sync();
             const int al_pos = max(0, cur_pos - (int)a.window_overlap);                                    /* :83 */
