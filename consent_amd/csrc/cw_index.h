@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
     const uint32_t k = prm.k;
     const bool direct = k <= 9;                             /* 4^k nibbles fit the LDS table */
     const uint32_t n_keys = direct ? 1u << (2 * k) : 0u;
+    const uint32_t kmask32_ = k >= 16u ? 0xFFFFFFFFu : (1u << (2u * k)) - 1u;
     const uint32_t nib_words = direct ? (n_keys >= 8 ? n_keys / 8 : 1) : 0u;
 
     /* phase A carve */
@@ -318,13 +319,17 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     const uint32_t p0 = pb + ((((uint32_t)tid & 127u) * 4u + ((uint32_t)tid >> 7) * 64u) & 511u);      \
                     if (p0 >= nk) continue;                                                                             \
                     const uint32_t wi_ = p0 >> 4;                                                                       \
-                    uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);               \
-                    x_ <<= 2u * (p0 & 15u);                                                                             \
-                    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4u; ++q_, x_ <<= 2) {                                  \
-                        const uint32_t p = p0 + q_;                                                                     \
-                        if (p >= nk) break;                                                                             \
-                        const uint32_t key = (uint32_t)(x_ >> (64u - 2u * k));                                          \
-                        __VA_ARGS__                                                                                     \
+                    const uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);         \
+                    /* (direct tables: k <= 9.  The four k-mers of a thread start in the first four bases of the window's upper word once base p0 is \
+                       at its top: 32-bit field extracts -- round 6; the running 64-bit shift cost two double-width shifts per k-mer) */ \
+                    const uint32_t yh_ = (uint32_t)((x_ << (2u * (p0 & 15u))) >> 32), nv_ = nk - p0;                    \
+                    _Pragma("unroll") for (uint32_t q_ = 0; q_ < 4u; ++q_) {                                            \
+                        if (q_ < nv_) do {                                                                              \
+                            const uint32_t p = p0 + q_;                                                                 \
+                            const uint32_t keyraw = yh_ >> (32u - 2u * k - 2u * q_), key = keyraw & kmask32_; /* keyraw: bases before the k-mer above it */ \
+                            (void)p; (void)keyraw;                                                                      \
+                            __VA_ARGS__                                                                                 \
+                        } while (0);                                                                                    \
                     }                                                                                                   \
                 }
 #define CW_IDX_PASS_BLOCKR(...)                                                                                         \
@@ -462,8 +467,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
             if (tid < 8) flags[tid] = 0;
             for (uint32_t h = 0; h < n_half; ++h) {
                 for (uint32_t i = tid; i < bwords; i += CW_IDX_THREADS) tab[i] = 0;
-                if (tid == 1 || tid == 2) flags[tid] = 0;
-                __syncthreads();
+                __syncthreads(); /* (flags[2], the byte sum, runs on over the halves: cleared with the other flags above) */
                 if (h == 0) CW_PROF(sc.ctr, 55, tid == 0);
 #if CW_IDX_BYTES_RTN /* rounds 4: a returning add, the old byte looked at */
                 CW_IDX_PASS_BLOCKR({
@@ -479,14 +483,15 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                    of all bytes of the table by 255 (a carry into the next byte) or 256 (out of the word) against the number of adds made.  The export
                    scan reads every word anyway and adds the bytes up (v_sad_u8); a table whose byte sum is not the number of k-mers counted sends the
                    window to the nibble path below, as a counter at 200 did. */
-                uint32_t my_adds = 0;
+                /* Round 6: the adds are not counted any more -- every k-mer of the pile is added in exactly one half, so after the last half the byte sums of
+                   the halves must add up to the pile's k-mer count (w_n_kmers, cw_setup_need_kernel); an overflow in the first half is then seen a half
+                   later, on a window that takes the nibble path anyway.  The word's offset and the half test are one subtraction and one compare. */
+                const uint32_t half_off = h * bkeys;
                 CW_IDX_PASS_BLOCKR({
-                    if (n_half > 1u && (key >> 17) != h) continue;
-                    const uint32_t kk = key & (bkeys - 1u), sh8 = (kk & 3u) * 8u;
-                    (void)__hip_atomic_fetch_add((cw_l32w)(tab + (kk >> 2)), 1u << sh8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ++my_adds;
+                    const uint32_t off = (key & ~3u) - half_off; /* byte offset of the counter's word in this half's table; wraps for a key of the other half */
+                    if (off >= bkeys) continue;
+                    (void)__hip_atomic_fetch_add((cw_l32w)((__attribute__((address_space(3))) uint8_t*)tab + off), 1u << ((keyraw << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 })
-                { const uint32_t ws_ = (uint32_t)cw_wave_sum((int)my_adds); if (lane == 0) atomicAdd(&flags[1], ws_); }
 #endif
                 __syncthreads();
                 CW_PROF(sc.ctr, 0, tid == 0);
@@ -526,10 +531,10 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 uint32_t woff = cw_block_exscan(lane == 0 ? wtot : 0u, scan_tmp, &total);
                 woff = (uint32_t)cw_lane_value((int)woff, 0);
 #if !CW_IDX_BYTES_RTN
-                if (flags[1] != flags[2]) { ok8 = false; break; } /* a counter passed 255: the bytes are not the counts */
+                if (h + 1u == n_half && flags[2] != w_n_kmers) { ok8 = false; break; } /* a counter passed 255 in one of the halves: the bytes are not the counts */
 #endif
                 fits8 = written + total <= w_solid_cap;
-                if (!fits8) break;
+                if (!fits8) { if (h + 1u != n_half) ok8 = false; /* (the counts of this half are not verified yet: the nibble path decides) */ break; }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     uint32_t mm = m[i], o = w_solid_base + written + woff + offs[i];
@@ -895,45 +900,55 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                 const uint32_t wi_ = p0 >> 4;
                 uint64_t x_ = ((uint64_t)words[wi_] << 32) | (wi_ + 1u < nwd ? words[wi_ + 1u] : 0u);
                 x_ <<= 2u * (p0 & 15u);
-                uint32_t key4[4], bkt4[4], e1[4]; /* e1[q]: the key's entry, 0 = not a template k-mer */
+                uint32_t key4[4], bkt4[4], e1[4];
+                if (k <= 13u) { /* (wave-uniform) four k-mers of up to 13 bases start in the first four bases of the upper word: 32-bit field extracts */
+                    const uint32_t yh = (uint32_t)(x_ >> 32);
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) { key4[q] = (uint32_t)(x_ >> (64u - 2u * k)); bkt4[q] = CW_TH_HOME(key4[q]); }
+                    for (uint32_t q = 0; q < 4u; ++q) key4[q] = (yh >> (32u - 2u * k - 2u * q)) & kmask32_;
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q, x_ <<= 2) key4[q] = (uint32_t)(x_ >> (64u - 2u * k));
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) bkt4[q] = CW_TH_HOME(key4[q]);
+                /* e1[q]: the k-mer's position in the template, anything >= CW_TMAX = not a template k-mer */
                 if (fp_exact) {
-                    auto match = [&](const uint4 v, const uint32_t fp) -> uint32_t {
-                        return (v.x & ~4095u) == fp ? v.x : (v.y & ~4095u) == fp ? v.y : (v.z & ~4095u) == fp ? v.z : (v.w & ~4095u) == fp ? v.w : 0u;
-                    };
+                    /* An entry of this key is (position + 1) + fp, fp a multiple of 4096: minus (fp + 1) it is the position (< CW_TMAX); an entry of another key
+                       comes out as its position plus a non-zero multiple of 4096, an empty slot as 4095 or more.  So the bucket's answer is the minimum of four
+                       differences (round 6; four masked compares and a chain of selects before) */
+                    auto match = [&](const uint4 v, const uint32_t fp1) -> uint32_t { return min(min(v.x - fp1, v.y - fp1), min(v.z - fp1, v.w - fp1)); };
                     uint4 v4[4];
 #pragma unroll
                     for (uint32_t q = 0; q < 4u; ++q) v4[q] = p0 + q < nk ? *(const uint4*)&th[bkt4[q] * 4u] : make_uint4(0u, 0u, 0u, 0u);
                     uint32_t pend = 0;
 #pragma unroll
-                    for (uint32_t q = 0; q < 4u; ++q) { e1[q] = match(v4[q], CW_TH_FP(key4[q])); if (e1[q] == 0u && v4[q].w != 0u) pend |= 1u << q; }
+                    for (uint32_t q = 0; q < 4u; ++q) { e1[q] = match(v4[q], CW_TH_FP(key4[q]) + 1u); if (e1[q] >= (uint32_t)CW_TMAX && v4[q].w != 0u) pend |= 1u << q; }
                     while (__ballot(pend != 0u) != 0ull) { /* a full bucket without the key: the next one (rare) */
 #pragma unroll
                         for (uint32_t q = 0; q < 4u; ++q) {
                             if ((pend >> q) & 1u) {
                                 bkt4[q] = (bkt4[q] + 1u) & (CW_TH_BUCKETS - 1);
                                 const uint4 v = *(const uint4*)&th[bkt4[q] * 4u];
-                                e1[q] = match(v, CW_TH_FP(key4[q]));
-                                if (e1[q] != 0u || v.w == 0u) pend &= ~(1u << q);
+                                e1[q] = match(v, CW_TH_FP(key4[q]) + 1u);
+                                if (e1[q] < (uint32_t)CW_TMAX || v.w == 0u) pend &= ~(1u << q);
                             }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (uint32_t q = 0; q < 4u; ++q) e1[q] = p0 + q < nk ? (uint32_t)(cw_tpl_lookup(th, tkey, key4[q]) + 1) : 0u;
+                    for (uint32_t q = 0; q < 4u; ++q) e1[q] = p0 + q < nk ? (uint32_t)cw_tpl_lookup(th, tkey, key4[q]) : 0xFFFFFFFFu; /* (-1: not there) */
                 }
                 uint32_t old4[4];
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; ++q) {
-                    const uint32_t e = CW_TH_POS(e1[q]) - 1u;
-                    old4[q] = e1[q] != 0u ? atomicOr(&my_seen[e >> 5], 1u << (e & 31u)) : 0u;
+                    const uint32_t e = e1[q];
+                    old4[q] = e < (uint32_t)CW_TMAX ? atomicOr(&my_seen[e >> 5], 1u << (e & 31u)) : 0u;
                 }
                 uint32_t n_list = 0, my_list = 0;
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; ++q) {
-                    const bool hit = e1[q] != 0u;
-                    const uint32_t e = CW_TH_POS(e1[q]) - 1u, p = p0 + q;
+                    const uint32_t e = e1[q], p = p0 + q;
+                    const bool hit = e < (uint32_t)CW_TMAX;
                     if (hit) {
                         if (old4[q] & (1u << (e & 31u))) trep[e] = 1;
                         else atomicAdd(&tsup[e], 1u);
@@ -953,7 +968,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
 #pragma unroll
                     for (uint32_t q = 0; q < 4u; ++q) {
                         const uint32_t p = p0 + q, hi_ = base + ((my_list >> (8u * q)) & 255u);
-                        if (e1[q] != 0u && p < 2048u && hi_ < hit_cap) hitlist[hi_] = ((CW_TH_POS(e1[q]) - 1u) << 21) | (s << 11) | p; /* template k-mer (11 bits), sequence (10), position (11) */
+                        if (e1[q] < (uint32_t)CW_TMAX && p < 2048u && hi_ < hit_cap) hitlist[hi_] = (e1[q] << 21) | (s << 11) | p; /* template k-mer (11 bits), sequence (10), position (11) */
                     }
                 }
             }
