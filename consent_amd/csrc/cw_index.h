@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(CW_IDX_THREADS) cw_index_kernel(DevBatch b, De
                     if (hit) {
                         if (old4[q] & (1u << (e & 31u))) trep[e] = 1;
                         else atomicAdd(&tsup[e], 1u);
-                        if (tfit) P_lds[e * Np + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do */
+                        if (tfit) P_lds[__umul24(e, Np) + s] = (uint16_t)p; /* a k-mer seen twice never becomes an anchor: any of its positions will do (both factors fit 24 bits: the full-rate multiply) */
                         else if (hl && p >= 2048u) misc[5] = 1;
                     }
                     if (!tfit && hl) {

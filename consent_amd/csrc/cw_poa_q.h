@@ -396,259 +396,279 @@ __device__ __forceinline__ bool poaq_trace_c(const PoaQ<T>& M, const int n, cons
     return true;
 }
 
-template <class T>
-__device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
-    unsigned long long _pt = __builtin_readcyclecounter();
-#define POAQ_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - _pt; _pt = _n; } while (0)
-    constexpr int GW = T::GW;
-    int n = 0, ne = 0, nseq = 0, tpl_nodes = 0;
-    bool meta_ok = false;
-    const unsigned lt_mask = (1u << gl) - 1u;
+/* What a group carries from member to member of its task (registers; every lane of the group holds the same values). */
+struct PoaQSt {
+    int n, ne, nseq, tpl_nodes, prev_L;
+    bool meta_ok, prev_clean; /* prev_clean: the member before this one was aligned and added neither a node nor an edge */
+    unsigned long long pt;    /* phase clock (POAQ_PROF) */
+    __device__ __forceinline__ void reset() { n = 0; ne = 0; nseq = 0; tpl_nodes = 0; prev_L = -1; meta_ok = false; prev_clean = false; }
+};
+#define POAQ_PROF(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); acc[slot] += _n - S.pt; S.pt = _n; } while (0)
 
-    if (t.n_members > 255u) return 2; /* coverage counts and edge weights are bytes here */
-    /* Round 6, the replay of a repeated member (CW_POAQ_REPLAY).  A member that is, base for base, the member aligned just before it -- and that one changed nothing
-       in the graph but coverage counts -- meets the same graph with the same bases: the same fill, the same walk back, the same path.  Its merge is the coverage
-       counts of that path once more (M.pcur still holds it, M.sq the bases), and the alignment is not run.  Measured on the checker (a scratch build of the
-       restatement over the bench piles, every replayed path compared with the one the alignment gives: 0 of 14 000 differ): 38 % of this tier's members at depth
-       150 -- the error-free copy of a short piece comes again and again.  The four tasks of a wave share one instruction stream, so a group does not skip a round
-       the others run: it takes its repeated members in a short loop of its own HERE and joins the round with the first member that needs an alignment.
-       (Not under the heaviest-bundle policy: a replay would have to raise the path's edge weights too.) */
-    bool prev_clean = false; /* the member before this one was aligned and added neither a node nor an edge */
-    int prev_L = -1;
-    for (uint32_t mi = 0; mi < t.n_members; ++mi) {
-        PoaMember pm = sc.members[t.member_off + mi];
+/* Round 6, the replay of a repeated member (CW_POAQ_REPLAY).  A member that is, base for base, the member aligned just before it -- and that one changed nothing
+   in the graph but coverage counts -- meets the same graph with the same bases: the same fill, the same walk back, the same path.  Its merge is the coverage
+   counts of that path once more (M.pcur still holds it, M.sq the bases), and the alignment is not run.  Measured on the checker (a scratch build of the
+   restatement over the bench piles, every replayed path compared with the one the alignment gives: 0 of 14 000 differ): 38 % of this tier's members at depth
+   150 -- the error-free copy of a short piece comes again and again.  The four tasks of a wave share one instruction stream, so a group does not skip a round
+   the others run: it takes its repeated members in a short loop of its own HERE and joins the round with the first member that needs an alignment.
+   (Not under the heaviest-bundle policy: a replay would have to raise the path's edge weights too.) */
+/* Takes the members from mi on that repeat the member aligned before them; returns with pm = member mi, the first one that needs an alignment (or mi == n_members). */
+template <class T>
+__device__ __forceinline__ void poaq_replay(const PoaQ<T>& M, PoaQSt& S, const PoaTask& t, const DevBatch& b, const DevScratch& sc, uint32_t& mi, PoaMember& pm, const int gl) {
 #if CW_POAQ_REPLAY
-        if (!CW_CONS_HEAVIEST_BUNDLE) {
-            while (prev_clean && (int)pm.len == prev_L) {
-                const uint32_t* words_ = b.bases + b.seq_word_off[pm.seq];
-                bool same = true;
-                for (int j = gl; j < prev_L; j += GW) same = same && M.sq[j] == (uint8_t)cw_base_at(words_, pm.start + j);
-                if (g_ballot<T>(!same) != 0u) break;
-                for (int j = gl; j < prev_L; j += GW) { const int cur = M.pcur[j]; M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1); } /* (a path visits a node once; lane j owns position j, as in the merge) */
-                nseq++;
-                if (++mi >= t.n_members) break;
-                pm = sc.members[t.member_off + mi];
-            }
-            if (mi >= t.n_members) break;
+    constexpr int GW = T::GW;
+    if (!CW_CONS_HEAVIEST_BUNDLE) {
+        while (S.prev_clean && (int)pm.len == S.prev_L) {
+            const uint32_t* words_ = b.bases + b.seq_word_off[pm.seq];
+            bool same = true;
+            for (int j = gl; j < S.prev_L; j += GW) same = same && M.sq[j] == (uint8_t)cw_base_at(words_, pm.start + j);
+            if (g_ballot<T>(!same) != 0u) break;
+            for (int j = gl; j < S.prev_L; j += GW) { const int cur = M.pcur[j]; M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1); } /* (a path visits a node once; lane j owns position j, as in the merge) */
+            S.nseq++;
+            if (++mi >= t.n_members) break;
+            pm = sc.members[t.member_off + mi];
         }
+    }
 #endif
-        const int L = (int)pm.len;
-        if ((uint32_t)L > (uint32_t)T::LC) return 2;
-        {
-            const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
-            for (int j = gl; j < L; j += GW) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
+}
+
+/* the member's bases into M.sq; the first member of a task becomes a chain (returns 1: nothing to align), a later one is aligned by poaq_member (0); 2 = beyond this tier */
+template <class T>
+__device__ __forceinline__ int poaq_take(const PoaQ<T>& M, PoaQSt& S, const PoaMember& pm, const DevBatch& b, const int gl) {
+    constexpr int GW = T::GW;
+    const int L = (int)pm.len;
+    if ((uint32_t)L > (uint32_t)T::LC) return 2;
+    {
+        const uint32_t* words = b.bases + b.seq_word_off[pm.seq];
+        for (int j = gl; j < L; j += GW) M.sq[j] = (uint8_t)cw_base_at(words, pm.start + j);
+    }
+    cw_wave_sync();
+    S.nseq++;
+    S.prev_clean = false; S.prev_L = L;
+    if (S.n != 0) return 0;
+    /* first member: a chain */
+    if ((uint32_t)L > (uint32_t)T::NC || (uint32_t)L > (uint32_t)T::EC) return 2;
+    for (int j = gl; j < L; j += GW) {
+        M.nbase[j] = M.sq[j]; M.ncov[j] = 1; M.nalc[j] = 0;
+        M.in_head[j] = j ? (uint8_t)(j - 1) : CW_NONE8; M.in_tail[j] = M.in_head[j];
+        M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
+        M.r2n[j] = (uint8_t)j; M.n2r[j] = (uint8_t)j;
+        if (j) { M.efrom[j - 1] = (uint8_t)(j - 1); M.enext[j - 1] = CW_NONE8; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
+    }
+    S.n = L; S.ne = L - 1; S.tpl_nodes = L; S.meta_ok = false;
+    cw_wave_sync();
+    return 1;
+}
+
+/* one member (its bases are in M.sq) against the graph: rank metadata, fill, walk back, merge.  0 = done, 2 = beyond this tier, 3 = failed */
+template <class T>
+__device__ __forceinline__ int poaq_member(const PoaQ<T>& M, PoaQSt& S, const int L, const int gl, unsigned long long (&acc)[5]) {
+    constexpr int GW = T::GW;
+    int& n = S.n; int& ne = S.ne; bool& meta_ok = S.meta_ok; bool& prev_clean = S.prev_clean;
+    const unsigned lt_mask = (1u << gl) - 1u;
+    const int cols = L + 1;
+
+    /* ---- per-rank metadata: the row words (CW_RM_WORD), predecessor lists, which rows the fill keeps in the slab ---- */
+    if (!meta_ok) {
+        int run = 0;
+        for (int w = gl; w < T::GFLAG_WORDS; w += GW) M.gflag[w] = 0u;
+        cw_wave_sync();
+        for (int r0 = 0; r0 < n; r0 += GW) {
+            const int r = r0 + gl;
+            const int node = r < n ? M.r2n[r] : 0;
+            const int d = r < n ? M.indeg[node] : 0;
+            const int inc = g_scan_add<T>(d);
+            const int off = run + inc - d;
+            if (r < n) {
+                int q = off, first = 0;
+                for (uint32_t e = M.in_head[node]; e != CW_NONE8; e = M.enext[e]) {
+                    const int pr = M.n2r[M.efrom[e]] + 1;
+                    if (q == off) first = pr;
+                    M.plist[q++] = (uint8_t)pr;
+                    if (r + 1 - pr > T::RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
+                        __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                if (d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                M.rpred0[r] = (uint8_t)first;
+                const uint32_t np_ = (uint32_t)(d ? d : 1);
+                M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, np_ == 1u && first == r, !M.has_out[node], 0u, np_ == 1u ? first : off);
+            }
+            run += g_bcast<T>(inc, GW - 1);
+        }
+        meta_ok = true;
+        cw_wave_sync();
+        for (int r = gl; r < n; r += GW) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
+        cw_wave_sync();
+    }
+    POAQ_PROF(0);
+
+    /* ---- DP fill (records the decisions), end cell ---- */
+    for (int j = gl; j < L; j += GW) M.seqrank[j] = CW_NONE8;
+    cw_wave_sync();
+    const int be = poaq_fill_c<T>(M, n, cols, gl);
+    cw_wave_sync();
+    POAQ_PROF(1);
+
+    /* ---- traceback over the code words ---- */
+    if (!poaq_trace_c<T>(M, n, be & 0xFFFF, be >> 16, gl)) return 3;
+    cw_wave_sync();
+    POAQ_PROF(2);
+
+    /* ---- merge the path into the graph: one lane per sequence position, 16 at a time (cf. poa_run) ---- */
+    {
+        const int n_old = n;
+        const int chunks = (L + GW - 1) / GW;
+        bool edges_added = false;
+        int next_rank = -1;
+        for (int c = chunks - 1; c >= 0; --c) {
+            const int j = c * GW + gl;
+            const bool act = j < L;
+            const uint32_t rk = act ? M.seqrank[j] : CW_NONE8;
+            const unsigned has = g_ballot<T>(act && rk != CW_NONE8);
+            const unsigned later = has & ~(lt_mask | (1u << gl));
+            const int later_rank = (int)(uint32_t)g_bcast<T>((int)rk, later ? (__ffs((int)later) - 1) : 0);
+            const int qr = later ? later_rank : next_rank;
+            const int first_rank = (int)(uint32_t)g_bcast<T>((int)rk, has ? (__ffs((int)has) - 1) : 0);
+            uint32_t cur = CW_NONE8, at = CW_NONE8;
+            if (act) {
+                const int bcode = M.sq[j];
+                if (rk != CW_NONE8) {
+                    const int pn = M.r2n[rk];
+                    if (M.nbase[pn] == bcode) cur = (uint32_t)pn;
+                    else {
+                        const int ac = M.nalc[pn];
+                        int last = (int)rk;
+                        for (int a = 0; a < ac; ++a) {
+                            const int v = M.nal[pn * 3 + a];
+                            if (M.nbase[v] == bcode) cur = (uint32_t)v;
+                            last = max(last, (int)M.n2r[v]);
+                        }
+                        if (cur == CW_NONE8) at = (uint32_t)(last + 1);
+                    }
+                } else if (qr < 0) {
+                    at = (uint32_t)n_old;
+                } else {
+                    const int q = M.r2n[qr];
+                    int first = qr;
+                    for (int a = 0; a < M.nalc[q]; ++a) first = min(first, (int)M.n2r[M.nal[q * 3 + a]]);
+                    at = (uint32_t)first;
+                }
+                M.pcur[j] = (uint8_t)cur;
+                M.pat[j] = (uint8_t)at;
+            }
+            if (has) next_rank = first_rank;
         }
         cw_wave_sync();
-        nseq++;
-        prev_clean = false; prev_L = L;
-        if (n == 0) { /* first member: a chain */
-            if ((uint32_t)L > (uint32_t)T::NC || (uint32_t)L > (uint32_t)T::EC) return 2;
-            for (int j = gl; j < L; j += GW) {
-                M.nbase[j] = M.sq[j]; M.ncov[j] = 1; M.nalc[j] = 0;
-                M.in_head[j] = j ? (uint8_t)(j - 1) : CW_NONE8; M.in_tail[j] = M.in_head[j];
-                M.indeg[j] = j ? 1 : 0; M.has_out[j] = (j < L - 1) ? 1 : 0;
-                M.r2n[j] = (uint8_t)j; M.n2r[j] = (uint8_t)j;
-                if (j) { M.efrom[j - 1] = (uint8_t)(j - 1); M.enext[j - 1] = CW_NONE8; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[j - 1] = 1; }
-            }
-            n = L; ne = L - 1; tpl_nodes = L; meta_ok = false;
-            cw_wave_sync();
-            continue;
-        }
-        const int cols = L + 1;
-
-        /* ---- per-rank metadata: the row words (CW_RM_WORD), predecessor lists, which rows the fill keeps in the slab ---- */
-        if (!meta_ok) {
-            int run = 0;
-            for (int w = gl; w < T::GFLAG_WORDS; w += GW) M.gflag[w] = 0u;
-            cw_wave_sync();
-            for (int r0 = 0; r0 < n; r0 += GW) {
-                const int r = r0 + gl;
-                const int node = r < n ? M.r2n[r] : 0;
-                const int d = r < n ? M.indeg[node] : 0;
-                const int inc = g_scan_add<T>(d);
-                const int off = run + inc - d;
-                if (r < n) {
-                    int q = off, first = 0;
-                    for (uint32_t e = M.in_head[node]; e != CW_NONE8; e = M.enext[e]) {
-                        const int pr = M.n2r[M.efrom[e]] + 1;
-                        if (q == off) first = pr;
-                        M.plist[q++] = (uint8_t)pr;
-                        if (r + 1 - pr > T::RING || q - off > 3) /* read back from further than the ring reaches / compared by the traceback (fourth in-edge and later) */
-                            __hip_atomic_fetch_or((cwc_l32)M.gflag + ((pr - 1) >> 5), 1u << ((pr - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        int fresh_total = 0;
+        for (int c = 0; c < chunks; ++c) {
+            const int j = c * GW + gl;
+            const bool act = j < L;
+            const bool fresh = act && M.pcur[j] == CW_NONE8;
+            const unsigned fb = g_ballot<T>(fresh);
+            if (fresh) {
+                const int cur = n_old + fresh_total + __popc(fb & lt_mask);
+                if ((uint32_t)cur < (uint32_t)T::NC) {
+                    M.pcur[j] = (uint8_t)cur;
+                    M.nbase[cur] = M.sq[j]; M.ncov[cur] = 1; M.nalc[cur] = 0;
+                    M.in_head[cur] = CW_NONE8; M.in_tail[cur] = CW_NONE8; M.indeg[cur] = 0; M.has_out[cur] = 0;
+                    const uint32_t rk = M.seqrank[j];
+                    if (rk != CW_NONE8) {
+                        const int pn = M.r2n[rk];
+                        const int ac = M.nalc[pn];
+                        for (int a = 0; a < ac; ++a) {
+                            const int v = M.nal[pn * 3 + a];
+                            M.nal[cur * 3 + a] = (uint8_t)v;
+                            M.nal[v * 3 + M.nalc[v]] = (uint8_t)cur; M.nalc[v] = (uint8_t)(M.nalc[v] + 1);
+                        }
+                        M.nal[cur * 3 + ac] = (uint8_t)pn; M.nalc[cur] = (uint8_t)(ac + 1);
+                        M.nal[pn * 3 + ac] = (uint8_t)cur; M.nalc[pn] = (uint8_t)(ac + 1);
                     }
-                    if (d > 3) __hip_atomic_fetch_or((cwc_l32)M.gflag + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    M.rpred0[r] = (uint8_t)first;
-                    const uint32_t np_ = (uint32_t)(d ? d : 1);
-                    M.rmeta[r] = CW_RM_WORD(M.nbase[node], np_, np_ == 1u && first == r, !M.has_out[node], 0u, np_ == 1u ? first : off);
+                }
+            } else if (act) {
+                const int cur = M.pcur[j];
+                M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1);
+            }
+            fresh_total += __popc(fb);
+        }
+        if ((uint32_t)(n_old + fresh_total) > (uint32_t)T::NC) return 2;
+        cw_wave_sync();
+        if (fresh_total > 0) {
+            uint32_t* hist = M.hist; /* n_old + 1 counters: the code words (or the row ring) are dead between the traceback and the next fill */
+            for (int r = gl; r <= n_old; r += GW) hist[r] = 0;
+            cw_wave_sync();
+            for (int c = 0; c < chunks; ++c) {
+                const int j = c * GW + gl;
+                if (j < L && M.pat[j] != CW_NONE8) atomicAdd(&hist[M.pat[j]], 1u);
+            }
+            cw_wave_sync();
+            int run = 0;
+            for (int r0 = 0; r0 < n_old; r0 += GW) {
+                const int r = r0 + gl;
+                const int hcount = r < n_old ? (int)hist[r] : 0;
+                const int inc = g_scan_add<T>(hcount);
+                if (r < n_old) {
+                    const int nr = r + run + inc;
+                    const int v = M.r2n[r];
+                    M.rtmp[nr] = (uint8_t)v;
+                    M.n2r[v] = (uint8_t)nr;
                 }
                 run += g_bcast<T>(inc, GW - 1);
             }
-            meta_ok = true;
-            cw_wave_sync();
-            for (int r = gl; r < n; r += GW) if ((M.gflag[r >> 5] >> (r & 31)) & 1u) M.rmeta[r] |= 16u;
-            cw_wave_sync();
-        }
-        POAQ_PROF(0);
-
-        /* ---- DP fill (records the decisions), end cell ---- */
-        for (int j = gl; j < L; j += GW) M.seqrank[j] = CW_NONE8;
-        cw_wave_sync();
-        const int be = poaq_fill_c<T>(M, n, cols, gl);
-        cw_wave_sync();
-        POAQ_PROF(1);
-
-        /* ---- traceback over the code words ---- */
-        if (!poaq_trace_c<T>(M, n, be & 0xFFFF, be >> 16, gl)) return 3;
-        cw_wave_sync();
-        POAQ_PROF(2);
-
-        /* ---- merge the path into the graph: one lane per sequence position, 16 at a time (cf. poa_run) ---- */
-        {
-            const int n_old = n;
-            const int chunks = (L + GW - 1) / GW;
-            bool edges_added = false;
-            int next_rank = -1;
-            for (int c = chunks - 1; c >= 0; --c) {
-                const int j = c * GW + gl;
-                const bool act = j < L;
-                const uint32_t rk = act ? M.seqrank[j] : CW_NONE8;
-                const unsigned has = g_ballot<T>(act && rk != CW_NONE8);
-                const unsigned later = has & ~(lt_mask | (1u << gl));
-                const int later_rank = (int)(uint32_t)g_bcast<T>((int)rk, later ? (__ffs((int)later) - 1) : 0);
-                const int qr = later ? later_rank : next_rank;
-                const int first_rank = (int)(uint32_t)g_bcast<T>((int)rk, has ? (__ffs((int)has) - 1) : 0);
-                uint32_t cur = CW_NONE8, at = CW_NONE8;
-                if (act) {
-                    const int bcode = M.sq[j];
-                    if (rk != CW_NONE8) {
-                        const int pn = M.r2n[rk];
-                        if (M.nbase[pn] == bcode) cur = (uint32_t)pn;
-                        else {
-                            const int ac = M.nalc[pn];
-                            int last = (int)rk;
-                            for (int a = 0; a < ac; ++a) {
-                                const int v = M.nal[pn * 3 + a];
-                                if (M.nbase[v] == bcode) cur = (uint32_t)v;
-                                last = max(last, (int)M.n2r[v]);
-                            }
-                            if (cur == CW_NONE8) at = (uint32_t)(last + 1);
-                        }
-                    } else if (qr < 0) {
-                        at = (uint32_t)n_old;
-                    } else {
-                        const int q = M.r2n[qr];
-                        int first = qr;
-                        for (int a = 0; a < M.nalc[q]; ++a) first = min(first, (int)M.n2r[M.nal[q * 3 + a]]);
-                        at = (uint32_t)first;
-                    }
-                    M.pcur[j] = (uint8_t)cur;
-                    M.pat[j] = (uint8_t)at;
-                }
-                if (has) next_rank = first_rank;
-            }
-            cw_wave_sync();
-            int fresh_total = 0;
             for (int c = 0; c < chunks; ++c) {
                 const int j = c * GW + gl;
-                const bool act = j < L;
-                const bool fresh = act && M.pcur[j] == CW_NONE8;
-                const unsigned fb = g_ballot<T>(fresh);
-                if (fresh) {
-                    const int cur = n_old + fresh_total + __popc(fb & lt_mask);
-                    if ((uint32_t)cur < (uint32_t)T::NC) {
-                        M.pcur[j] = (uint8_t)cur;
-                        M.nbase[cur] = M.sq[j]; M.ncov[cur] = 1; M.nalc[cur] = 0;
-                        M.in_head[cur] = CW_NONE8; M.in_tail[cur] = CW_NONE8; M.indeg[cur] = 0; M.has_out[cur] = 0;
-                        const uint32_t rk = M.seqrank[j];
-                        if (rk != CW_NONE8) {
-                            const int pn = M.r2n[rk];
-                            const int ac = M.nalc[pn];
-                            for (int a = 0; a < ac; ++a) {
-                                const int v = M.nal[pn * 3 + a];
-                                M.nal[cur * 3 + a] = (uint8_t)v;
-                                M.nal[v * 3 + M.nalc[v]] = (uint8_t)cur; M.nalc[v] = (uint8_t)(M.nalc[v] + 1);
-                            }
-                            M.nal[cur * 3 + ac] = (uint8_t)pn; M.nalc[cur] = (uint8_t)(ac + 1);
-                            M.nal[pn * 3 + ac] = (uint8_t)cur; M.nalc[pn] = (uint8_t)(ac + 1);
-                        }
-                    }
-                } else if (act) {
+                if (j < L && M.pat[j] != CW_NONE8) {
                     const int cur = M.pcur[j];
-                    M.ncov[cur] = (uint8_t)(M.ncov[cur] + 1);
+                    const int nr = (int)M.pat[j] + (cur - n_old);
+                    M.rtmp[nr] = (uint8_t)cur;
+                    M.n2r[cur] = (uint8_t)nr;
                 }
-                fresh_total += __popc(fb);
-            }
-            if ((uint32_t)(n_old + fresh_total) > (uint32_t)T::NC) return 2;
-            cw_wave_sync();
-            if (fresh_total > 0) {
-                uint32_t* hist = M.hist; /* n_old + 1 counters: the code words (or the row ring) are dead between the traceback and the next fill */
-                for (int r = gl; r <= n_old; r += GW) hist[r] = 0;
-                cw_wave_sync();
-                for (int c = 0; c < chunks; ++c) {
-                    const int j = c * GW + gl;
-                    if (j < L && M.pat[j] != CW_NONE8) atomicAdd(&hist[M.pat[j]], 1u);
-                }
-                cw_wave_sync();
-                int run = 0;
-                for (int r0 = 0; r0 < n_old; r0 += GW) {
-                    const int r = r0 + gl;
-                    const int hcount = r < n_old ? (int)hist[r] : 0;
-                    const int inc = g_scan_add<T>(hcount);
-                    if (r < n_old) {
-                        const int nr = r + run + inc;
-                        const int v = M.r2n[r];
-                        M.rtmp[nr] = (uint8_t)v;
-                        M.n2r[v] = (uint8_t)nr;
-                    }
-                    run += g_bcast<T>(inc, GW - 1);
-                }
-                for (int c = 0; c < chunks; ++c) {
-                    const int j = c * GW + gl;
-                    if (j < L && M.pat[j] != CW_NONE8) {
-                        const int cur = M.pcur[j];
-                        const int nr = (int)M.pat[j] + (cur - n_old);
-                        M.rtmp[nr] = (uint8_t)cur;
-                        M.n2r[cur] = (uint8_t)nr;
-                    }
-                }
-                cw_wave_sync();
-                n = n_old + fresh_total;
-                for (int r = gl; r < n; r += GW) M.r2n[r] = M.rtmp[r];
-                meta_ok = false;
-                cw_wave_sync();
-            }
-            for (int c = 0; c < chunks; ++c) {
-                const int j = c * GW + gl;
-                const bool act = j < L && j > 0;
-                int head = 0, cur = 0;
-                bool add = false;
-                if (act) {
-                    head = M.pcur[j - 1]; cur = M.pcur[j];
-                    add = true;
-                    for (uint32_t e = M.in_head[cur]; e != CW_NONE8; e = M.enext[e])
-                        if (M.efrom[e] == (uint8_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint8_t)(M.ew[e] + 1); break; }
-                }
-                const unsigned ab = g_ballot<T>(add);
-                const int total = __popc(ab);
-                if ((uint32_t)(ne + total) > (uint32_t)T::EC) return 2;
-                if (add) {
-                    const int e = ne + __popc(ab & lt_mask);
-                    M.efrom[e] = (uint8_t)head; M.enext[e] = CW_NONE8;
-                    if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = 1;
-                    const uint32_t tl = M.in_tail[cur];
-                    if (tl == CW_NONE8) M.in_head[cur] = (uint8_t)e; else M.enext[tl] = (uint8_t)e;
-                    M.in_tail[cur] = (uint8_t)e;
-                    M.indeg[cur] = (uint8_t)(M.indeg[cur] + 1);
-                    M.has_out[head] = 1;
-                }
-                if (total) { ne += total; meta_ok = false; edges_added = true; }
             }
             cw_wave_sync();
-            prev_clean = n == n_old && !edges_added; /* nothing but coverage counts changed: the next member may be a replay of this one */
+            n = n_old + fresh_total;
+            for (int r = gl; r < n; r += GW) M.r2n[r] = M.rtmp[r];
+            meta_ok = false;
+            cw_wave_sync();
         }
-        POAQ_PROF(3);
+        for (int c = 0; c < chunks; ++c) {
+            const int j = c * GW + gl;
+            const bool act = j < L && j > 0;
+            int head = 0, cur = 0;
+            bool add = false;
+            if (act) {
+                head = M.pcur[j - 1]; cur = M.pcur[j];
+                add = true;
+                for (uint32_t e = M.in_head[cur]; e != CW_NONE8; e = M.enext[e])
+                    if (M.efrom[e] == (uint8_t)head) { add = false; if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = (uint8_t)(M.ew[e] + 1); break; }
+            }
+            const unsigned ab = g_ballot<T>(add);
+            const int total = __popc(ab);
+            if ((uint32_t)(ne + total) > (uint32_t)T::EC) return 2;
+            if (add) {
+                const int e = ne + __popc(ab & lt_mask);
+                M.efrom[e] = (uint8_t)head; M.enext[e] = CW_NONE8;
+                if (CW_CONS_HEAVIEST_BUNDLE) M.ew[e] = 1;
+                const uint32_t tl = M.in_tail[cur];
+                if (tl == CW_NONE8) M.in_head[cur] = (uint8_t)e; else M.enext[tl] = (uint8_t)e;
+                M.in_tail[cur] = (uint8_t)e;
+                M.indeg[cur] = (uint8_t)(M.indeg[cur] + 1);
+                M.has_out[head] = 1;
+            }
+            if (total) { ne += total; meta_ok = false; edges_added = true; }
+        }
+        cw_wave_sync();
+        prev_clean = n == n_old && !edges_added; /* nothing but coverage counts changed: the next member may be a replay of this one */
     }
+    POAQ_PROF(3);
+    return 0;
+}
 
+/* the task's consensus into its arena slot; 1 = done, 3 = the slot is too small */
+template <class T>
+__device__ __forceinline__ int poaq_finish(const PoaQ<T>& M, PoaQSt& S, const PoaTask& t, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
+    constexpr int GW = T::GW;
+    const int n = S.n, nseq = S.nseq, tpl_nodes = S.tpl_nodes;
+    const unsigned lt_mask = (1u << gl) - 1u;
+    (void)nseq; (void)tpl_nodes; (void)lt_mask;
     /* ---- consensus: column-majority vote, or the heaviest bundle (cw_policy.h CW_POA_CONSENSUS) ---- */
     uint32_t out_len = 0;
 #if CW_CONS_HEAVIEST_BUNDLE
@@ -695,11 +715,40 @@ __device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, c
     if (out_len > t.out_cap) return 3;
     if (gl == 0) sc.seg_len[t.seg_slot] = out_len;
     POAQ_PROF(4);
-#undef POAQ_PROF
     return 1;
 }
 
+/* a whole task, member after member */
+template <class T>
+__device__ int poaq_run(const PoaQ<T>& M, const PoaTask& t, const DevBatch& b, const DevScratch& sc, const int gl, unsigned long long (&acc)[5]) {
+    PoaQSt S;
+    S.reset(); S.pt = __builtin_readcyclecounter();
+    if (t.n_members > 255u) return 2; /* coverage counts and edge weights are bytes here */
+    for (uint32_t mi = 0; mi < t.n_members; ++mi) {
+        PoaMember pm = sc.members[t.member_off + mi];
+        poaq_replay<T>(M, S, t, b, sc, mi, pm, gl);
+        if (mi >= t.n_members) break;
+        const int tk = poaq_take<T>(M, S, pm, b, gl);
+        if (tk == 2) return 2;
+        if (tk == 1) continue;
+        const int rc = poaq_member<T>(M, S, (int)pm.len, gl, acc);
+        if (rc) return rc;
+    }
+    return poaq_finish<T>(M, S, t, sc, gl, acc);
+}
+
 /* ---- tier Q (four tasks per wave) and tier H (two): one kernel body ------------------------------------------------------------------ */
+#ifndef CW_POAQ_FLAT
+#define CW_POAQ_FLAT 0 /* 1: the flat loop below (built, bit-identical, measured slower: off; the variant `qflat` of tests/test_gpu_variants.py) */
+#endif
+/* Round 6, the flat loop -- tried, measured, off.  The groups of a wave share one instruction stream, so the loop "per group: take a task, run all its members"
+   makes every group wait, task after task, for the slowest of the four: the consensus phase of the profile, which the first group's clock charges with that wait,
+   is 10.2 of this tier's 62.2 G wave-cycles per depth-150 batch although the tier list is sorted by size.  The flat loop is over ALIGNMENTS instead: each round
+   every group brings one member of its own task to the alignment (a new task, its first member's chain, its repeated members and the consensus of the task it has
+   just finished on the way, in a loop of its own), and a group whose task ends takes the next one without waiting.  Measured (same box, four alternating runs):
+   the kernel 8.84 -> 9.24 ms.  The wait is gone (consensus 10.2 -> 1.3 G) and comes back twice: the work at a task's boundary (a chain of five dependent loads,
+   the chain, the consensus) now runs once per GROUP with the other three idle, where the per-task loop runs it once per wave for all four (+6.0 G), and groups
+   that are at different members of their tasks meet graphs of different sizes -- the fill runs as many rows as the largest (+4.9 G). */
 template <class T, int TIER_LIST, int NEXT_TIER, int PROF_BASE, bool PRODUCER>
 __device__ __forceinline__ void poaq_kernel_body(const DevBatch& b, const DevScratch& sc, uint8_t* lds, uint8_t* slab_base) {
     const int gl = threadIdx.x & (T::GW - 1);
@@ -709,6 +758,52 @@ __device__ __forceinline__ void poaq_kernel_body(const DevBatch& b, const DevScr
     const uint32_t* list = sc.tier_list[TIER_LIST];
     const uint32_t n_work = min(sc.ctr->n_tier[TIER_LIST], sc.list_cap);
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
+#if CW_POAQ_FLAT
+    PoaQSt S;
+    S.reset(); S.pt = __builtin_readcyclecounter();
+    PoaTask t = {};
+    uint32_t ti = 0, mi = 0;
+    bool have = false, done = false;
+    for (;;) {
+        bool aligning = false;
+        int L = 0;
+        while (!done) { /* (per group) until this group has a member to align or the list is empty */
+            if (have && mi >= t.n_members) { /* the task's last member is in: its consensus */
+                const int rc = poaq_finish<T>(M, S, t, sc, gl, acc);
+                if (gl == 0) poa_hand_over(sc, t, ti, rc, NEXT_TIER);
+                cw_wave_sync();
+                have = false;
+            }
+            if (!have) {
+                uint32_t m = 0;
+                if (gl == 0) m = atomicAdd(&sc.ctr->next_tier[TIER_LIST], 1u);
+                m = (uint32_t)g_bcast<T>((int)m, 0);
+                if (m >= n_work) { done = true; break; }
+                ti = list[m];
+                t = sc.tasks[ti];
+                if (t.n_members == 0) continue; /* a neutral entry (cw_chain.h "cap_ok") */
+                if (t.n_members > 255u) { if (gl == 0) poa_hand_over(sc, t, ti, 2, NEXT_TIER); continue; } /* coverage counts and edge weights are bytes here */
+                S.reset();
+                mi = 0; have = true;
+            }
+            PoaMember pm = sc.members[t.member_off + mi];
+            poaq_replay<T>(M, S, t, b, sc, mi, pm, gl);
+            if (mi >= t.n_members) continue;
+            const int tk = poaq_take<T>(M, S, pm, b, gl);
+            if (tk == 2) { if (gl == 0) poa_hand_over(sc, t, ti, 2, NEXT_TIER); cw_wave_sync(); have = false; continue; }
+            if (tk == 1) { ++mi; continue; } /* the first member: a chain */
+            L = (int)pm.len;
+            aligning = true;
+            break;
+        }
+        if (__ballot(aligning) == 0ull) break; /* every group has seen the end of the list */
+        if (aligning) {
+            const int rc = poaq_member<T>(M, S, L, gl, acc);
+            if (rc) { if (gl == 0) poa_hand_over(sc, t, ti, rc, NEXT_TIER); cw_wave_sync(); have = false; }
+            else ++mi;
+        }
+    }
+#else
     for (;;) {
         uint32_t mi = 0;
         if (gl == 0) mi = atomicAdd(&sc.ctr->next_tier[TIER_LIST], 1u);
@@ -721,10 +816,12 @@ __device__ __forceinline__ void poaq_kernel_body(const DevBatch& b, const DevScr
         if (gl == 0) poa_hand_over(sc, t, ti, rc, NEXT_TIER);
         cw_wave_sync();
     }
+#endif
     /* per-phase cycles as the first group of every wave saw them (the groups of a wave share one instruction stream) */
     if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) atomicAdd(&sc.ctr->prof[PROF_BASE + q], acc[q]);
     if (PRODUCER) poa_producer_done(sc);
 }
+#undef POAQ_PROF
 
 /* tier Q: a task that outgrows it (rc 2) is redone in tier S, whose kernel follows on the stream (hand-over list 0) */
 __global__ void __launch_bounds__(64 * CW_POAQ_WAVES) cw_poa_q_kernel(DevBatch b, DevScratch sc) {

@@ -20,7 +20,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "noreplay": ["-DCW_POAQ_REPLAY=0", "-DCW_POA_REPLAY=0"], "lw": ["-DCW_POA_LW=1"], "lwall": ["-DCW_POA_LW=1", "-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
+VARIANTS = {"nopad": ["-DCW_NO_PAD64"], "matrix": ["-DCW_POA_CODES=0"], "m2codes": ["-DCW_M2_CODES=1"], "qmatrix": ["-DCW_Q_CODES=0"], "noreplay": ["-DCW_POAQ_REPLAY=0", "-DCW_POA_REPLAY=0"], "qflat": ["-DCW_POAQ_FLAT=1"], "lw": ["-DCW_POA_LW=1"], "lwall": ["-DCW_POA_LW=1", "-DCW_POALW_MIN_MEAN=1", "-DCW_POALW_MIN_MEMBERS=2"], "nogroup": ["-DCW_POA_GROUP_FILL=0", "-DCW_POA_VPROBE=0"]}
 
 CHILD = r"""
 import os, sys
