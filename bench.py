@@ -250,8 +250,9 @@ def main():
     if args.windows > 0:
         n_win = args.windows
     prm = ca.Params(9, 4, 8, 2, max_msa)
-    # (an engine allocates its scratch in its first run: no more engines than warm-up steps, so that no first run falls into the timed region)
-    engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, min(args.engines, max(1, args.warmup))))]
+    # (an engine allocates its scratch in its first run.  Through round 5 there were no more engines than warm-up steps, which silently measured another configuration when
+    #  --warmup was small; now an engine the warm-up steps do not reach gets one untimed allocation run before them -- `config.engine_allocation_runs`)
+    engines = [ca.Engine(prm, device=local_rank) for _ in range(max(1, args.engines))]
     for e_ in engines:  # the caller knows its window size, as the native driver does (cw_configure: the scratch plan goes by it -- 492 k-mers per template, not 1024)
         e_.configure(500)
     eng = engines[0]
@@ -297,6 +298,9 @@ def main():
     torch.cuda.synchronize(dev)
 
     ne = len(engines)
+    n_alloc_runs = max(0, ne - args.warmup)
+    for i in range(args.warmup, ne):  # set-up, not warm-up: the first run of an engine allocates its scratch
+        engines[i].run_device(batches[i % n_batches], rs[i])
     for i in range(args.warmup):
         engines[i % ne].run_device(batches[i % n_batches], rs[i % ne])
     torch.cuda.synchronize(dev)
@@ -433,6 +437,7 @@ def main():
             "sharding": "windows by rank, no collective",
             "engines_per_gpu": ne,
             "engines_requested": args.engines,
+            "engine_allocation_runs": n_alloc_runs,
             "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "overflow_windows": n_over,
             "template_fallback_windows": n_tpl,

@@ -132,7 +132,7 @@ def test_bench_gpus_2_spawns_two_ranks_without_a_launcher():
 @pytest.mark.timeout(1500)
 def test_bench_gpus_8_runs_eight_ranks_and_the_driver_leg_on_one_box():
     """The command the driver runs once on an 8-GPU node, here with all eight ranks on the one GPU of the box (CW_BENCH_SINGLE_DEVICE, gloo): rank 0's
-    native-driver leg first with `-j 8` while the seven other ranks wait in the rendezvous, then 8 x 3 engines side by side, one JSON line with
+    native-driver leg first with `-j 8` while the seven other ranks wait in the rendezvous, then 8 x 4 engines side by side (the fourth of each rank with an allocation run of its own, three warm-up steps), one JSON line with
     n_gpus 8, a driver_strong_scaling object without an error, three timed repetitions and their median."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(CW_BENCH_SINGLE_DEVICE="1", CW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
@@ -143,7 +143,7 @@ def test_bench_gpus_8_runs_eight_ranks_and_the_driver_leg_on_one_box():
     assert len(line) == 1, out.stdout[-2000:]
     j = json.loads(line[0])
     assert j["n_gpus"] == 8 and j["steps"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
-    assert j["config"]["engines_per_gpu"] == 3 and j["config"]["distinct_windows_per_run"] == 8 * 4 * 1024
+    assert j["config"]["engines_per_gpu"] == 4 and j["config"]["engine_allocation_runs"] == 1 and j["config"]["distinct_windows_per_run"] == 8 * 4 * 1024
     assert j["reps"] == 3 and len(j["ms_per_step_reps"]) == 3 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
     d = j["driver_strong_scaling"]
     assert "error" not in d, d
